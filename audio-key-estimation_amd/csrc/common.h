@@ -1,0 +1,64 @@
+// Shared host-side helpers of libake_hip.so: error reporting across the C ABI and the
+// hipEvent kernel timer used by bench.py's roofline leg.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/ake_hip.h"
+
+namespace ake {
+
+void set_error(const char* fmt, ...);
+
+#define AKE_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            ake::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return AKE_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+#define AKE_REQUIRE(cond, code, ...)   \
+    do {                               \
+        if (!(cond)) {                 \
+            ake::set_error(__VA_ARGS__); \
+            return (code);             \
+        }                              \
+    } while (0)
+
+// ---- kernel timer -------------------------------------------------------------------------
+// When enabled, every launch site brackets its kernel with two hipEvents recorded on the
+// launch stream.  Elapsed times are summed per kernel name by collect().
+struct ProfScope {
+    ProfScope(const char* name, hipStream_t stream);
+    ~ProfScope();
+    int slot;
+    hipStream_t stream;
+};
+bool prof_active();
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Bump allocator over the caller's workspace.
+struct Carver {
+    char* base;
+    size_t off;
+    size_t cap;   // 0 = size query only
+    explicit Carver(void* b, size_t c) : base(static_cast<char*>(b)), off(0), cap(c) {}
+    template <typename T>
+    T* take(size_t n) {
+        off = align_up(off, 256);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+}  // namespace ake

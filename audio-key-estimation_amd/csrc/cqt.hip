@@ -1,0 +1,400 @@
+// CQT front end for gfx950: waveform -> log(1 + |constant-Q transform|).
+//
+// Replaces librosa.cqt + abs + log1p (KeyDataset.py:485,490-499).  Specification: the
+// direct-form transform of oracle/cqt_oracle.py.  Evaluation (MI355X-first):
+//
+//   1. cqt_decimate_kernel   y_{o+1}[m] = sum_j h[j] y_o[2m+j]   (Kaiser half-band, LDS-staged,
+//                            coalesced streaming; one launch per octave step)
+//   2. cqt_bank_kernel       for every (octave o, frame t): the 36 bins of the octave are
+//                            <=277-tap complex FIRs on the 2^o-decimated signal.  A frame centre
+//                            t*hop is not a multiple of 2^o in general, so the plan holds one
+//                            filter bank per fractional phase (t*hop mod 2^o).  Lane = clip:
+//                            filter taps are wave-uniform and come in through SGPRs
+//                            (s_load), each lane streams its own clip's window with 16-byte
+//                            loads, and every v_fma has one scalar operand.  |.| and log1p are
+//                            fused into the epilogue.
+//
+// HBM layout: audio [B][stride] f32 (caller's), y_o [B][len_o] f32 in the workspace
+// (len_o = ceil(n/2^o) + 2*Hh, sample m stored at m + Hh), out [B][n_bins][out_frames] f32.
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxOct = 12;
+constexpr int kNBW = 12;        // bins per wave in the bank kernel
+constexpr int kMaxOddTaps = 32; // decimator: odd taps 1,3,..,2*32-1
+constexpr double kC1 = 32.70319566257483;
+constexpr int kDecimOutPerBlock = 512;
+constexpr int kDecimThreads = 256;
+
+struct GroupDesc {       // one (octave, bin-group): 12 bins sharing a tap window
+    int octave;          // 0 = top octave (full rate)
+    int k0;              // first CQT bin of the group
+    int uh;              // taps u = -uh .. +uh on the decimated grid
+    int table_off;       // float offset of phase 0 in the table
+    int phase_stride;    // floats between consecutive phases
+};
+
+struct DecimTaps {
+    float h0;
+    float hodd[kMaxOddTaps];
+    int n_odd;
+    int half_len;
+};
+
+struct BankCall {
+    const float* x[kMaxOct];   // per octave: sample m at x[m - lo]
+    long long stride[kMaxOct];
+    int lo[kMaxOct];
+    int count[kMaxOct];
+};
+
+}  // namespace
+
+struct ake_cqt_plan {
+    ake_cqt_config cfg;
+    int n_oct;
+    int n_groups;       // n_oct * groups_per_oct
+    int hop_twos;       // trailing zero bits of hop
+    int half_len;
+    DecimTaps taps;
+    std::vector<GroupDesc> groups;
+    GroupDesc* groups_dev = nullptr;
+    float* table_dev = nullptr;
+    size_t table_floats = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// device code
+// ------------------------------------------------------------------------------------------
+
+// y_out[m] = h0*y[2m] + sum_{j odd} h[j]*(y[2m-j] + y[2m+j]);  in: sample s at in[s - in_lo].
+__global__ __launch_bounds__(kDecimThreads) void cqt_decimate_kernel(
+    const float* __restrict__ in, long long in_stride, int in_lo, int in_count,
+    float* __restrict__ out, long long out_stride, int out_lo, int out_count, DecimTaps taps) {
+    __shared__ float tile[2 * kDecimOutPerBlock + 2 * (2 * kMaxOddTaps) + 8];
+    const int clip = blockIdx.y;
+    const int m0 = out_lo + blockIdx.x * kDecimOutPerBlock;     // first output sample of the block
+    const int H = taps.half_len;
+    const int s0 = 2 * m0 - H;                                   // first input sample needed
+    const int need = 2 * kDecimOutPerBlock + 2 * H;
+    const float* src = in + clip * in_stride;
+    for (int i = threadIdx.x; i < need; i += kDecimThreads) {
+        const int idx = s0 + i - in_lo;
+        tile[i] = (idx >= 0 && idx < in_count) ? src[idx] : 0.f;
+    }
+    __syncthreads();
+    float* dst = out + clip * out_stride;
+#pragma unroll
+    for (int r = 0; r < kDecimOutPerBlock / kDecimThreads; ++r) {
+        const int mi = threadIdx.x + r * kDecimThreads;
+        const int o_idx = m0 + mi - out_lo;
+        if (o_idx >= out_count) continue;
+        const int c = 2 * mi + H;                                // tile index of sample 2m
+        float acc = taps.h0 * tile[c];
+        for (int q = 0; q < taps.n_odd; ++q) {
+            const int j = 2 * q + 1;
+            acc = fmaf(taps.hodd[q], tile[c - j] + tile[c + j], acc);
+        }
+        dst[o_idx] = acc;
+    }
+}
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// One wave = 64 clips x 12 bins of one (octave, frame).
+__global__ __launch_bounds__(64) void cqt_bank_kernel(
+    BankCall call, const GroupDesc* __restrict__ groups, const float* __restrict__ table,
+    int batch, int n_frames, int hop, int hop_twos, float* __restrict__ out, long long out_clip_stride,
+    int out_frames) {
+    const int t = blockIdx.x;
+    const GroupDesc g = groups[blockIdx.y];
+    const int lane_clip = blockIdx.z * 64 + threadIdx.x;
+    const int clip = lane_clip < batch ? lane_clip : batch - 1;   // clamp: idle lanes redo the last clip
+    const int o = g.octave;
+    const long long c = static_cast<long long>(t) * hop;
+    const int c_int = static_cast<int>(c >> o);
+    const int ph = static_cast<int>(c & ((1ll << o) - 1));
+    const int sh = hop_twos < o ? hop_twos : o;
+    const float* __restrict__ w = table + g.table_off + static_cast<long long>(ph >> sh) * g.phase_stride;
+
+    const int lo = call.lo[o];
+    const int cnt = call.count[o];
+    const float* __restrict__ x = call.x[o] + clip * call.stride[o];
+
+    // uniform tap range inside the stored signal: sample index s = c_int + u, array index s - lo
+    int u_beg = -g.uh, u_end = g.uh + 1;
+    if (c_int + u_beg < lo) u_beg = lo - c_int;
+    if (c_int + u_end > lo + cnt) u_end = lo + cnt - c_int;
+
+    float acc[2 * kNBW];
+#pragma unroll
+    for (int i = 0; i < 2 * kNBW; ++i) acc[i] = 0.f;
+
+    int u = u_beg;
+    const float* xp = x + (c_int + u - lo);
+    const float* wp = w + (u + g.uh) * (2 * kNBW);
+    for (; u + 4 <= u_end; u += 4) {
+        const f4u xv = *reinterpret_cast<const f4u*>(xp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float xs = xv[q];
+#pragma unroll
+            for (int i = 0; i < 2 * kNBW; ++i) acc[i] = fmaf(xs, wp[q * 2 * kNBW + i], acc[i]);
+        }
+        xp += 4;
+        wp += 4 * 2 * kNBW;
+    }
+    for (; u < u_end; ++u) {
+        const float xs = *xp;
+#pragma unroll
+        for (int i = 0; i < 2 * kNBW; ++i) acc[i] = fmaf(xs, wp[i], acc[i]);
+        xp += 1;
+        wp += 2 * kNBW;
+    }
+    if (lane_clip < batch) {
+        float* dst = out + lane_clip * out_clip_stride + static_cast<long long>(g.k0) * out_frames + t;
+#pragma unroll
+        for (int b = 0; b < kNBW; ++b) {
+            const float re = acc[2 * b], im = acc[2 * b + 1];
+            dst[static_cast<long long>(b) * out_frames] = log1pf(sqrtf(re * re + im * im));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host: plan
+// ------------------------------------------------------------------------------------------
+namespace {
+
+double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    const double q = x * x / 4.0;
+    for (int k = 1; k < 200; ++k) {
+        term *= q / (static_cast<double>(k) * k);
+        sum += term;
+        if (term < 1e-18 * sum) break;
+    }
+    return sum;
+}
+
+std::vector<double> kaiser_halfband(int half_len, double beta) {
+    std::vector<double> h(2 * half_len + 1);
+    double s = 0;
+    for (int j = -half_len; j <= half_len; ++j) {
+        const double x = j / 2.0;
+        const double sinc = (j == 0) ? 1.0 : std::sin(M_PI * x) / (M_PI * x);
+        const double r = static_cast<double>(j) / half_len;
+        const double win = bessel_i0(beta * std::sqrt(std::max(0.0, 1.0 - r * r))) / bessel_i0(beta);
+        h[j + half_len] = 0.5 * sinc * win;
+        s += h[j + half_len];
+    }
+    for (auto& v : h) v /= s;
+    return h;
+}
+
+int len_store(const ake_cqt_plan* p, int o, int64_t n) {   // samples stored for octave o >= 1
+    const int64_t l = (n + (1ll << o) - 1) >> o;
+    return static_cast<int>(l) + 2 * p->half_len;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ake_cqt_default_config(ake_cqt_config* cfg, int sample_rate, int frames_per_second, int octaves) {
+    AKE_REQUIRE(cfg && sample_rate > 0 && octaves > 0, AKE_ERR_INVALID, "ake_cqt_default_config: bad argument");
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->sample_rate = sample_rate;
+    // KeyDataset.py:485  hop_length = round(rate / (opt.frames if opt.frames > 0 else 1)); Python's
+    // round() is round-half-even
+    const double q = static_cast<double>(sample_rate) / (frames_per_second > 0 ? frames_per_second : 1);
+    cfg->hop_length = static_cast<int>(std::nearbyint(q));
+    cfg->n_bins = 36 * octaves;
+    cfg->bins_per_octave = 36;
+    cfg->fmin = kC1;
+    cfg->q_mode = 0;
+    cfg->decim_half_len = 23;
+    cfg->decim_beta = 8.0;
+    return AKE_OK;
+}
+
+int ake_cqt_plan_create(const ake_cqt_config* cfg_in, ake_cqt_plan** out) {
+    AKE_REQUIRE(cfg_in && out, AKE_ERR_INVALID, "ake_cqt_plan_create: null argument");
+    ake_cqt_config cfg = *cfg_in;
+    if (cfg.fmin <= 0) cfg.fmin = kC1;
+    if (cfg.decim_half_len <= 0) cfg.decim_half_len = 23;
+    if (cfg.decim_beta <= 0) cfg.decim_beta = 8.0;
+    AKE_REQUIRE(cfg.sample_rate > 0 && cfg.hop_length > 0 && cfg.n_bins > 0, AKE_ERR_INVALID, "cqt: bad rate/hop/bins");
+    AKE_REQUIRE(cfg.bins_per_octave % kNBW == 0 && cfg.n_bins % cfg.bins_per_octave == 0, AKE_ERR_UNSUPPORTED,
+                "cqt: bins_per_octave must be a multiple of %d and divide n_bins", kNBW);
+    AKE_REQUIRE(cfg.decim_half_len % 2 == 1 && (cfg.decim_half_len + 1) / 2 <= kMaxOddTaps, AKE_ERR_INVALID,
+                "cqt: decim_half_len must be odd and <= %d", 2 * kMaxOddTaps - 1);
+    const int bpo = cfg.bins_per_octave;
+    const int n_oct = cfg.n_bins / bpo;
+    AKE_REQUIRE(n_oct <= kMaxOct, AKE_ERR_INVALID, "cqt: too many octaves (%d)", n_oct);
+    const double sr = cfg.sample_rate;
+    const double r = std::pow(2.0, 1.0 / bpo);
+    const double Q = cfg.q_mode == 0 ? (r * r + 1.0) / (r * r - 1.0) : 1.0 / (r - 1.0);
+    std::vector<double> freq(cfg.n_bins), len(cfg.n_bins);
+    for (int k = 0; k < cfg.n_bins; ++k) {
+        freq[k] = cfg.fmin * std::pow(2.0, static_cast<double>(k) / bpo);
+        len[k] = Q * sr / freq[k];
+    }
+    // librosa refuses a filter bank whose top filter passes Nyquist (hann bandwidth 1.50018)
+    const double cutoff = freq.back() * (1.0 + 0.5 * 1.50018310546875 / Q);
+    AKE_REQUIRE(cutoff <= sr / 2.0, AKE_ERR_INVALID, "cqt: top bin cutoff %.1f Hz exceeds Nyquist %.1f Hz", cutoff, sr / 2.0);
+
+    auto* p = new ake_cqt_plan();
+    p->cfg = cfg;
+    p->n_oct = n_oct;
+    p->half_len = cfg.decim_half_len;
+    p->hop_twos = 0;
+    while (((cfg.hop_length >> p->hop_twos) & 1) == 0) ++p->hop_twos;
+
+    const std::vector<double> h = kaiser_halfband(p->half_len, cfg.decim_beta);
+    std::memset(&p->taps, 0, sizeof(p->taps));
+    p->taps.half_len = p->half_len;
+    p->taps.h0 = static_cast<float>(h[p->half_len]);
+    p->taps.n_odd = (p->half_len + 1) / 2;
+    for (int q = 0; q < p->taps.n_odd; ++q) p->taps.hodd[q] = static_cast<float>(h[p->half_len + 2 * q + 1]);
+    // the even taps of a windowed half-band sinc are exactly zero apart from the centre; what the
+    // float kernel drops is below 1e-17, and the per-bin gain below is computed from the taps it keeps
+    auto cascade_gain = [&](double f_hz, int o) {
+        double gain = 1.0;
+        for (int s = 0; s < o; ++s) {
+            const double wn = 2.0 * M_PI * f_hz / (sr / std::pow(2.0, s));
+            double acc = p->taps.h0;
+            for (int q = 0; q < p->taps.n_odd; ++q) acc += 2.0 * p->taps.hodd[q] * std::cos(wn * (2 * q + 1));
+            gain *= std::fabs(acc);
+        }
+        return gain;
+    };
+
+    const int gpo = bpo / kNBW;
+    std::vector<float> table;
+    for (int o = 0; o < n_oct; ++o) {
+        const int dec = 1 << o;
+        const int sh = std::min(p->hop_twos, o);
+        const int nph = dec >> sh;
+        const int k_hi = cfg.n_bins - bpo * o;
+        for (int gi = 0; gi < gpo; ++gi) {
+            GroupDesc g;
+            g.octave = o;
+            g.k0 = k_hi - bpo + gi * kNBW;
+            double lo_min = 0;
+            for (int b = 0; b < kNBW; ++b) lo_min = std::min(lo_min, std::floor(-len[g.k0 + b] / 2.0));
+            g.uh = static_cast<int>(std::ceil(-lo_min / dec)) + 1;
+            const int ntap = 2 * g.uh + 1;
+            g.phase_stride = ntap * 2 * kNBW;
+            g.table_off = static_cast<int>(table.size());
+            table.resize(table.size() + static_cast<size_t>(nph) * g.phase_stride);
+            for (int pi = 0; pi < nph; ++pi) {
+                const double ph = static_cast<double>(pi << sh);
+                float* dst = table.data() + g.table_off + static_cast<size_t>(pi) * g.phase_stride;
+                for (int b = 0; b < kNBW; ++b) {
+                    const int k = g.k0 + b;
+                    const double lo = std::floor(-len[k] / 2.0);
+                    const double L = std::floor(len[k] / 2.0) - lo;
+                    const double scale = dec * std::sqrt(len[k]) / (L / 2.0) / cascade_gain(freq[k], o);
+                    for (int u = -g.uh; u <= g.uh; ++u) {
+                        const double pos = static_cast<double>(dec) * u - ph;   // full-rate offset from the frame centre
+                        double re = 0, im = 0;
+                        if (pos >= lo && pos <= lo + L) {
+                            const double win = 0.5 - 0.5 * std::cos(2.0 * M_PI * (pos - lo) / L);
+                            const double arg = 2.0 * M_PI * freq[k] * pos / sr;
+                            re = scale * win * std::cos(arg);
+                            im = -scale * win * std::sin(arg);
+                        }
+                        dst[(u + g.uh) * 2 * kNBW + 2 * b] = static_cast<float>(re);
+                        dst[(u + g.uh) * 2 * kNBW + 2 * b + 1] = static_cast<float>(im);
+                    }
+                }
+            }
+            p->groups.push_back(g);
+        }
+    }
+    p->n_groups = static_cast<int>(p->groups.size());
+    p->table_floats = table.size();
+    hipError_t e = hipMalloc(&p->table_dev, table.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&p->groups_dev, p->groups.size() * sizeof(GroupDesc));
+    if (e == hipSuccess) e = hipMemcpy(p->table_dev, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->groups_dev, p->groups.data(), p->groups.size() * sizeof(GroupDesc), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        ake::set_error("cqt plan upload failed: %s", hipGetErrorString(e));
+        ake_cqt_plan_destroy(p);
+        return AKE_ERR_HIP;
+    }
+    *out = p;
+    return AKE_OK;
+}
+
+void ake_cqt_plan_destroy(ake_cqt_plan* p) {
+    if (!p) return;
+    if (p->table_dev) (void)hipFree(p->table_dev);
+    if (p->groups_dev) (void)hipFree(p->groups_dev);
+    delete p;
+}
+
+int ake_cqt_plan_n_bins(const ake_cqt_plan* p) { return p ? p->cfg.n_bins : 0; }
+
+int64_t ake_cqt_num_frames(const ake_cqt_plan* p, int64_t n_samples) {
+    if (!p || n_samples < 0) return -1;
+    return 1 + n_samples / p->cfg.hop_length;
+}
+
+size_t ake_cqt_workspace_bytes(const ake_cqt_plan* p, int batch, int64_t n_samples) {
+    if (!p || batch <= 0 || n_samples <= 0) return 0;
+    ake::Carver c(nullptr, 0);
+    for (int o = 1; o < p->n_oct; ++o) c.take<float>(static_cast<size_t>(batch) * len_store(p, o, n_samples));
+    return ake::align_up(c.off, 256);
+}
+
+int ake_cqt_logmag_f32(const ake_cqt_plan* p, const float* audio, int batch, int64_t n, int64_t audio_stride,
+                       float* out, int64_t out_frames, void* workspace, size_t ws_bytes, ake_stream_t stream_) {
+    AKE_REQUIRE(p && audio && out, AKE_ERR_INVALID, "ake_cqt_logmag_f32: null argument");
+    AKE_REQUIRE(batch > 0 && n > 0 && audio_stride >= n, AKE_ERR_INVALID, "cqt: bad batch/n_samples/stride");
+    AKE_REQUIRE(n < (1ll << 30), AKE_ERR_INVALID, "cqt: clip too long (%lld samples)", static_cast<long long>(n));
+    const int64_t T = ake_cqt_num_frames(p, n);
+    AKE_REQUIRE(out_frames >= T, AKE_ERR_INVALID, "cqt: out_frames %lld < %lld frames", static_cast<long long>(out_frames), static_cast<long long>(T));
+    AKE_REQUIRE(ws_bytes >= ake_cqt_workspace_bytes(p, batch, n) && (workspace || p->n_oct == 1), AKE_ERR_WORKSPACE, "cqt: workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+
+    BankCall call;
+    std::memset(&call, 0, sizeof(call));
+    ake::Carver c(workspace, ws_bytes);
+    call.x[0] = audio;
+    call.stride[0] = audio_stride;
+    call.lo[0] = 0;
+    call.count[0] = static_cast<int>(n);
+    for (int o = 1; o < p->n_oct; ++o) {
+        const int ls = len_store(p, o, n);
+        float* y = c.take<float>(static_cast<size_t>(batch) * ls);
+        call.x[o] = y;
+        call.stride[o] = ls;
+        call.lo[o] = -p->half_len;
+        call.count[o] = ls;
+        dim3 grid((ls + kDecimOutPerBlock - 1) / kDecimOutPerBlock, batch);
+        ake::ProfScope ps("cqt_decimate_kernel", stream);
+        hipLaunchKernelGGL(cqt_decimate_kernel, grid, dim3(kDecimThreads), 0, stream, call.x[o - 1], call.stride[o - 1],
+                           call.lo[o - 1], call.count[o - 1], y, static_cast<long long>(ls), -p->half_len, ls, p->taps);
+    }
+    if (out_frames > T)
+        AKE_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float) * batch * p->cfg.n_bins * out_frames, stream));
+    {
+        dim3 grid(static_cast<unsigned>(T), p->n_groups, (batch + 63) / 64);
+        ake::ProfScope ps("cqt_bank_kernel", stream);
+        hipLaunchKernelGGL(cqt_bank_kernel, grid, dim3(64), 0, stream, call, p->groups_dev, p->table_dev, batch,
+                           static_cast<int>(T), p->cfg.hop_length, p->hop_twos, out,
+                           static_cast<long long>(p->cfg.n_bins) * out_frames, static_cast<int>(out_frames));
+    }
+    AKE_HIP_CHECK(hipGetLastError());
+    return AKE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,723 @@
+// PitchClassNet forward on gfx950: handle, weight registry, BatchNorm folding, packing, launch plan.
+//
+// Replaces PitchClassNet.forward (models.py:747-817) for the default architecture family
+// (models.py:190-197, 227-234, 311-350).  Channel algebra follows models.py:279-308 / 693-710.
+//
+// HBM layout (all fp32, NCHW, per chunk of <= chunk_clips clips so that the pitch-stream
+// activations [chunk][8][288][T] stay inside the 256 MiB Infinity Cache between layers):
+//   mel      [B][1][P][T]                    caller's
+//   fold0    [c][1][12][T]                   semitone conv + octave fold of layer 0
+//   cat_i    [c][prev_pc + out_p][12][T_i]   concat buffer of layer i: producers write their channel slice
+//   psix     [c][prev_pc][36][T_i]           up_sixth output; the x(P/36) row repeat is never materialised
+//   pa / pb  [c][out_p][P][T_i]              pitch-conv ping-pong
+//   pc a/b   [c][out_pc][12][T_i]            pitch-class conv ping-pong
+//   pcf      [c][final][12][T_f]             time-pooled features feeding the heads
+//   hid      [c][2*final][12][.]             head hidden maps;  maps [c][rows][T_m]
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "pcnet_kernels.h"
+
+using namespace ake_k;
+
+namespace {
+
+constexpr double kBnEps = 1e-5;          // nn.BatchNorm2d default
+constexpr size_t kLdsBudget = 64 * 1024; // dynamic LDS per workgroup we allow ourselves
+
+struct TensorSpec {
+    std::string name;
+    int64_t shape[4];
+    int ndim;
+};
+
+struct HostTensor {
+    std::vector<float> data;
+    bool set = false;
+};
+
+struct PackedConv {          // device-resident folded + packed convolution
+    int cin = 0, cout = 0, kh = 0, kw = 0, co = 1, groups = 1;
+    size_t w_off = 0, b_off = 0;   // float offsets into the blob
+};
+
+struct LayerDims {
+    int prev_p = 0, prev_pc = 0, out_p = 0, out_pc = 0;
+};
+
+int pick_co(int cout) { return cout >= 8 ? 8 : (cout >= 2 ? 4 : 1); }
+
+}  // namespace
+
+struct ake_pcnet {
+    ake_pcnet_config cfg;
+    std::vector<LayerDims> dims;
+    int final_ch = 0;
+    std::vector<TensorSpec> specs;
+    std::map<std::string, int> spec_index;
+    std::vector<HostTensor> host;
+    bool finalized = false;
+    int chunk_clips = 64;
+
+    // packed parameters
+    std::vector<float> blob;
+    float* blob_dev = nullptr;
+    std::vector<PackedConv> semi;                 // per layer
+    std::vector<std::vector<PackedConv>> pc2pc;   // per layer, conv_layers entries
+    std::vector<PackedConv> up;                   // per layer (index 0 unused)
+    std::vector<std::vector<PackedConv>> p2p;     // per layer (index 0 empty)
+    std::vector<PackedConv> head_key, head_tonic, head_genre;
+};
+
+namespace {
+
+void add_spec(ake_pcnet* n, const std::string& name, std::initializer_list<int64_t> shape) {
+    TensorSpec s;
+    s.name = name;
+    s.ndim = static_cast<int>(shape.size());
+    int i = 0;
+    for (auto v : shape) s.shape[i++] = v;
+    for (; i < 4; ++i) s.shape[i] = 1;
+    n->spec_index[name] = static_cast<int>(n->specs.size());
+    n->specs.push_back(s);
+}
+
+void add_conv_specs(ake_pcnet* n, const std::string& prefix, int cout, int cin, int kh, int kw) {
+    add_spec(n, prefix + ".weight", {cout, cin, kh, kw});
+    add_spec(n, prefix + ".bias", {cout});
+}
+
+void add_bn_specs(ake_pcnet* n, const std::string& prefix, int c) {
+    for (const char* f : {".weight", ".bias", ".running_mean", ".running_var"}) add_spec(n, prefix + f, {c});
+}
+
+const std::vector<float>& T(const ake_pcnet* n, const std::string& name) {
+    return n->host[n->spec_index.at(name)].data;
+}
+
+// conv weight [cout][cin][kh][kw] + bias, optionally followed by BatchNorm(bn_prefix) in eval mode:
+//   y = (conv(x) - mean) * gamma / sqrt(var + eps) + beta  ==  conv'(x) with w' = w*s, b' = (b - mean)*s + beta
+void fold(const ake_pcnet* n, const std::string& wkey, const std::string& bkey, const std::string& bn_prefix,
+          int cout, size_t per_out, bool transposed_cin_first, int cin, std::vector<double>& w, std::vector<double>& b) {
+    const auto& w32 = T(n, wkey);
+    const auto& b32 = T(n, bkey);
+    w.assign(w32.begin(), w32.end());
+    b.assign(b32.begin(), b32.end());
+    if (bn_prefix.empty()) return;
+    const auto& g = T(n, bn_prefix + ".weight");
+    const auto& be = T(n, bn_prefix + ".bias");
+    const auto& mu = T(n, bn_prefix + ".running_mean");
+    const auto& var = T(n, bn_prefix + ".running_var");
+    for (int co = 0; co < cout; ++co) {
+        const double s = static_cast<double>(g[co]) / std::sqrt(static_cast<double>(var[co]) + kBnEps);
+        if (!transposed_cin_first) {
+            for (size_t i = 0; i < per_out; ++i) w[co * per_out + i] *= s;
+        } else {   // ConvTranspose2d weight is [cin][cout][kh][kw]
+            const size_t k = per_out / cin;   // kh*kw
+            for (int ci = 0; ci < cin; ++ci)
+                for (size_t i = 0; i < k; ++i) w[(static_cast<size_t>(ci) * cout + co) * k + i] *= s;
+        }
+        b[co] = (b[co] - mu[co]) * s + be[co];
+    }
+}
+
+// [cout][cin][kh][kw] -> [group][cin][kh][kw][CO] (zero padded), bias padded to groups*CO
+PackedConv pack_conv(ake_pcnet* n, const std::vector<double>& w, const std::vector<double>& b, int cout, int cin, int kh, int kw) {
+    PackedConv p;
+    p.cin = cin; p.cout = cout; p.kh = kh; p.kw = kw;
+    p.co = pick_co(cout);
+    p.groups = (cout + p.co - 1) / p.co;
+    auto& blob = n->blob;
+    blob.resize(ake::align_up(blob.size(), 64));
+    p.w_off = blob.size();
+    blob.resize(blob.size() + static_cast<size_t>(p.groups) * cin * kh * kw * p.co, 0.f);
+    for (int g = 0; g < p.groups; ++g)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int dy = 0; dy < kh; ++dy)
+                for (int dx = 0; dx < kw; ++dx)
+                    for (int c = 0; c < p.co; ++c) {
+                        const int co = g * p.co + c;
+                        const double v = co < cout ? w[((static_cast<size_t>(co) * cin + ci) * kh + dy) * kw + dx] : 0.0;
+                        blob[p.w_off + ((((static_cast<size_t>(g) * cin + ci) * kh + dy) * kw + dx) * p.co) + c] = static_cast<float>(v);
+                    }
+    blob.resize(ake::align_up(blob.size(), 64));
+    p.b_off = blob.size();
+    blob.resize(blob.size() + static_cast<size_t>(p.groups) * p.co, 0.f);
+    for (int co = 0; co < cout; ++co) blob[p.b_off + co] = static_cast<float>(b[co]);
+    return p;
+}
+
+PackedConv fold_pack(ake_pcnet* n, const std::string& conv_prefix, const std::string& bn_prefix, int cout, int cin, int kh, int kw) {
+    std::vector<double> w, b;
+    fold(n, conv_prefix + ".weight", conv_prefix + ".bias", bn_prefix, cout, static_cast<size_t>(cin) * kh * kw, false, cin, w, b);
+    return pack_conv(n, w, b, cout, cin, kh, kw);
+}
+
+// ---- launch helpers ---------------------------------------------------------------------
+
+struct Tile {
+    int R, TT, Tp, n_row_tiles, n_time_tiles, threads;
+    size_t lds;
+};
+
+// Choose (rows, frames) per workgroup for the generic conv under the LDS budget.
+bool choose_tile(bool fullrows, int cin, int H, int KH, int T_out, Tile* t) {
+    const int T4 = (T_out + TW - 1) / TW * TW;
+    int n_tt = 1;
+    for (;; ++n_tt) {
+        int TT = ((T4 / TW + n_tt - 1) / n_tt) * TW;
+        if (TT > 128 && TT > TW) continue;
+        const int Tp = TT + 8;
+        const int strips = TT / TW;
+        if (fullrows) {
+            const size_t lds = static_cast<size_t>(cin) * H * Tp * sizeof(float);
+            if ((lds > kLdsBudget || H * strips > 1024) && TT > TW) continue;
+            if (lds > 160 * 1024) return false;
+            *t = Tile{H, TT, Tp, 1, n_tt, (H * strips + 63) / 64 * 64, lds};
+            return true;
+        }
+        int bestR = 0;
+        double best = -1;
+        for (int R = 1; R <= std::min(H, 64); ++R) {
+            const size_t lds = static_cast<size_t>(cin) * (R + KH - 1) * Tp * sizeof(float);
+            const int thr = R * strips;
+            if (lds > kLdsBudget || thr > 1024) break;
+            const int padded = (thr + 63) / 64 * 64;
+            const int tiles = (H + R - 1) / R;
+            const double eff = (static_cast<double>(thr) / padded) * (static_cast<double>(R) / (R + KH - 1)) *
+                               (static_cast<double>(H) / (tiles * R));
+            if (eff > best) { best = eff; bestR = R; }
+        }
+        if (bestR == 0) {
+            if (TT > TW) continue;
+            return false;
+        }
+        const int strips_ = TT / TW;
+        *t = Tile{bestR, TT, Tp, (H + bestR - 1) / bestR, n_tt, (bestR * strips_ + 63) / 64 * 64,
+                  static_cast<size_t>(cin) * (bestR + KH - 1) * Tp * sizeof(float)};
+        return true;
+    }
+}
+
+template <int KH, bool FULLROWS>
+int launch_conv_co(int co, const ConvArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+    switch (co) {
+        case 8: hipLaunchKernelGGL((conv_rows_kernel<KH, 7, 8, FULLROWS>), grid, block, lds, s, a); return AKE_OK;
+        case 4: hipLaunchKernelGGL((conv_rows_kernel<KH, 7, 4, FULLROWS>), grid, block, lds, s, a); return AKE_OK;
+        case 1: hipLaunchKernelGGL((conv_rows_kernel<KH, 7, 1, FULLROWS>), grid, block, lds, s, a); return AKE_OK;
+    }
+    ake::set_error("conv: no kernel for CO=%d", co);
+    return AKE_ERR_UNSUPPORTED;
+}
+
+struct Src {
+    const float* p0; int c0; const float* p1; int c1; int h1;
+};
+
+// One convolution of the net.  `kind`: 0 pitch conv (7x7 circular both axes), 1 equivariant pitch-class
+// conv (12 x k, rows circular), 2 genre conv (kh in {1,2}, rows valid).
+int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int batch, int H, int T_in, bool same_time,
+             bool lrelu, float* dst, int dst_ctot, int dst_coff, hipStream_t s, const char* name) {
+    ConvArgs a;
+    std::memset(&a, 0, sizeof(a));
+    AKE_REQUIRE(pc.kw == 7, AKE_ERR_UNSUPPORTED, "conv: kernel width %d not built (only 7)", pc.kw);
+    AKE_REQUIRE(src.c0 + src.c1 == pc.cin, AKE_ERR_STATE, "conv %s: cin mismatch", name);
+    a.src0 = src.p0; a.c0 = src.c0; a.src1 = src.p1; a.c1 = src.c1; a.h1 = src.h1 > 0 ? src.h1 : 1;
+    a.H = H; a.T_in = T_in;
+    a.src0_clip_stride = static_cast<long long>(src.c0) * H * T_in;
+    a.src1_clip_stride = static_cast<long long>(src.c1) * a.h1 * T_in;
+    const bool fullrows = kind != 0;
+    if (kind == 0) { a.py = pc.kh / 2; a.pad_l = pc.kw / 2; a.time_circ = 1; a.T_out = T_in; a.H_out = H; }
+    else {
+        a.py = 0; a.time_circ = 0;
+        a.pad_l = same_time ? pc.kw / 2 : 0;
+        a.T_out = same_time ? T_in : T_in - pc.kw + 1;
+        a.H_out = kind == 1 ? H : H - pc.kh + 1;
+    }
+    AKE_REQUIRE(a.T_out > 0, AKE_ERR_INVALID, "conv %s: %d frames is too short for the valid head convolutions", name, T_in);
+    a.w = n->blob_dev + pc.w_off; a.bias = n->blob_dev + pc.b_off; a.cout = pc.cout;
+    a.dst = dst; a.dst_coff = dst_coff; a.dst_clip_stride = static_cast<long long>(dst_ctot) * a.H_out * a.T_out;
+    a.lrelu = lrelu ? 1 : 0;
+    Tile t;
+    AKE_REQUIRE(choose_tile(fullrows, pc.cin, H, pc.kh, a.T_out, &t), AKE_ERR_UNSUPPORTED,
+                "conv %s: no tile fits LDS (cin=%d H=%d)", name, pc.cin, H);
+    a.R = t.R; a.TT = t.TT; a.Tp = t.Tp; a.n_row_tiles = t.n_row_tiles; a.n_time_tiles = t.n_time_tiles;
+    dim3 grid(t.n_row_tiles * t.n_time_tiles, pc.groups, batch), block(t.threads);
+    ake::ProfScope ps(name, s);
+    if (kind == 0 && pc.kh == 7) return launch_conv_co<7, false>(pc.co, a, grid, block, t.lds, s);
+    if (kind == 1 && pc.kh == 12) return launch_conv_co<12, true>(pc.co, a, grid, block, t.lds, s);
+    if (kind == 2 && pc.kh == 1) return launch_conv_co<1, true>(pc.co, a, grid, block, t.lds, s);
+    if (kind == 2 && pc.kh == 2) return launch_conv_co<2, true>(pc.co, a, grid, block, t.lds, s);
+    ake::set_error("conv %s: kernel height %d not built", name, pc.kh);
+    return AKE_ERR_UNSUPPORTED;
+}
+
+int run_semi(const ake_pcnet* n, const PackedConv& pc, const float* src, int batch, int H, int Tn, float* dst,
+             int dst_ctot, int dst_coff, hipStream_t s, const char* name) {
+    SemiArgs a;
+    a.src = src; a.C = pc.cin; a.H = H; a.T = Tn;
+    a.src_clip_stride = static_cast<long long>(pc.cin) * H * Tn;
+    a.w = n->blob_dev + pc.w_off; a.bias = n->blob_dev + pc.b_off;
+    a.dst = dst; a.dst_coff = dst_coff; a.dst_clip_stride = static_cast<long long>(dst_ctot) * 12 * Tn;
+    a.n_strips = (Tn + TW - 1) / TW;
+    const int per_clip = 12 * a.n_strips;
+    const int threads = per_clip >= 256 ? 256 : (per_clip + 63) / 64 * 64;
+    dim3 grid((per_clip + threads - 1) / threads, pc.groups, batch), block(threads);
+    ake::ProfScope ps(name, s);
+    switch (pc.co) {
+        case 8: hipLaunchKernelGGL((semi_fold_kernel<8>), grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((semi_fold_kernel<4>), grid, block, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((semi_fold_kernel<1>), grid, block, 0, s, a); break;
+        default: ake::set_error("semi: bad CO"); return AKE_ERR_UNSUPPORTED;
+    }
+    return AKE_OK;
+}
+
+struct Buffers {           // workspace carve for one chunk; also the tap table
+    struct Tap { float* p; int64_t shape[4]; };
+    std::map<std::string, Tap> taps;
+    float *fold0 = nullptr, *pcf = nullptr, *hid_k = nullptr, *hid_t = nullptr, *hid_g = nullptr;
+    float *map_k = nullptr, *map_t = nullptr, *map_g = nullptr;
+    std::vector<float*> cat, psix, pa, pb, pca, pcb, ppool;
+    std::vector<int> Tl;    // frames at layer i
+    int Tf = 0;             // frames after the last layer
+    size_t bytes = 0;
+};
+
+int plan_buffers(const ake_pcnet* n, int chunk, int frames, void* ws, Buffers* b) {
+    const auto& c = n->cfg;
+    const int L = c.num_layers, P = c.pitches;
+    ake::Carver cv(ws, 0);
+    b->Tl.assign(L, frames);
+    for (int i = 2; i < L; ++i) b->Tl[i] = b->Tl[i - 1] / c.time_pool_size;
+    if (L > 1) b->Tl[1] = frames;
+    b->Tf = L > 1 ? b->Tl[L - 1] / c.time_pool_size : frames;
+    AKE_REQUIRE(b->Tf >= 1, AKE_ERR_INVALID, "pcnet: %d frames vanish under the time pooling", frames);
+    b->cat.assign(L + 1, nullptr); b->psix.assign(L, nullptr); b->pa.assign(L, nullptr); b->pb.assign(L, nullptr);
+    b->pca.assign(L, nullptr); b->pcb.assign(L, nullptr); b->ppool.assign(L, nullptr);
+    const size_t B = chunk;
+    b->fold0 = cv.take<float>(B * 12 * frames);
+    for (int i = 0; i < L; ++i) {
+        const int Ti = b->Tl[i];
+        const auto& d = n->dims[i];
+        const int pc_out = i == 0 ? c.n_filters : d.out_pc;
+        if (i >= 1) {
+            b->cat[i] = cv.take<float>(B * (d.prev_pc + d.out_p) * 12 * Ti);
+            b->psix[i] = cv.take<float>(B * d.prev_pc * 36 * Ti);
+            b->pa[i] = cv.take<float>(B * d.out_p * P * Ti);
+            b->pb[i] = cv.take<float>(B * d.out_p * P * Ti);
+            if (i + 1 < L) b->ppool[i] = cv.take<float>(B * d.out_p * P * (Ti / c.time_pool_size));
+        }
+        b->pca[i] = cv.take<float>(B * pc_out * 12 * Ti);
+        b->pcb[i] = cv.take<float>(B * pc_out * 12 * Ti);
+    }
+    b->pcf = cv.take<float>(B * n->final_ch * 12 * b->Tf);
+    const int k = c.kernel_size;
+    const size_t hid = B * 2 * n->final_ch * 12 * b->Tf;
+    b->hid_k = cv.take<float>(2 * hid); b->hid_t = cv.take<float>(2 * hid);
+    b->map_k = cv.take<float>(B * 12 * b->Tf); b->map_t = cv.take<float>(B * 12 * b->Tf);
+    if (c.genre) { b->hid_g = cv.take<float>(2 * hid); b->map_g = cv.take<float>(B * 12 * b->Tf); }
+    (void)k;
+    b->bytes = ake::align_up(cv.off, 256);
+    return AKE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ake_pcnet_default_config(ake_pcnet_config* cfg, int octaves, int genre) {
+    AKE_REQUIRE(cfg && octaves > 0, AKE_ERR_INVALID, "ake_pcnet_default_config: bad argument");
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->pitches = 36 * octaves;      // train_model.py:92-95
+    cfg->pitch_classes = 12;
+    cfg->num_layers = 2; cfg->kernel_size = 7; cfg->conv_layers = 3; cfg->n_filters = 4;   // train_model.py:190-197
+    cfg->head_layers = 2; cfg->time_pool_size = 2;                                          // train_model.py:212-217
+    cfg->genre = genre ? 1 : 0;
+    return AKE_OK;
+}
+
+int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
+    AKE_REQUIRE(cfg && out, AKE_ERR_INVALID, "ake_pcnet_create: null argument");
+    const ake_pcnet_config& c = *cfg;
+    AKE_REQUIRE(!(c.resblock || c.denseblock || c.stay_sixth || c.only_semitones || c.p2pc_conv || c.pc2p_mem || c.local),
+                AKE_ERR_UNSUPPORTED,
+                "pcnet: resblock/denseblock/stay_sixth/only_semitones/p2pc_conv/pc2p_mem/local variants are not built");
+    AKE_REQUIRE(c.pitch_classes == 12, AKE_ERR_UNSUPPORTED, "pcnet: pitch_classes must be 12");
+    AKE_REQUIRE(c.pitches > 0 && c.pitches % 36 == 0, AKE_ERR_INVALID, "pcnet: pitches must be a multiple of 36");
+    AKE_REQUIRE(c.kernel_size == 7, AKE_ERR_UNSUPPORTED, "pcnet: only kernel_size 7 is built");
+    AKE_REQUIRE(c.num_layers >= 1 && c.num_layers <= 4 && c.conv_layers >= 1 && c.n_filters >= 1 && c.head_layers >= 1,
+                AKE_ERR_INVALID, "pcnet: bad layer counts");
+    AKE_REQUIRE(c.time_pool_size >= 1, AKE_ERR_INVALID, "pcnet: bad time_pool_size");
+    auto* n = new ake_pcnet();
+    n->cfg = c;
+    if (const char* e = std::getenv("AKE_PCNET_CHUNK")) n->chunk_clips = std::max(1, std::atoi(e));
+    const int nf = c.n_filters, L = c.num_layers, k = c.kernel_size;
+    n->dims.resize(L);
+    for (int i = 1; i < L; ++i) {           // models.py:281-308
+        LayerDims d;
+        if (i == 1) { d.prev_p = 1; d.prev_pc = nf; d.out_p = 2 * nf; d.out_pc = 2 * d.out_p; }
+        else {
+            d.prev_p = i == 2 ? 2 * nf : 2 * nf * static_cast<int>(std::pow(4, i - 2));
+            d.prev_pc = 2 * d.prev_p; d.out_p = 4 * d.prev_p; d.out_pc = 4 * d.prev_pc;
+        }
+        n->dims[i] = d;
+    }
+    n->final_ch = L == 1 ? nf : n->dims[L - 1].out_pc;   // models.py:694-710
+    // ---- expected state_dict entries ----
+    for (int i = 0; i < L; ++i) {
+        const std::string m = "model." + std::to_string(i) + ".";
+        const LayerDims& d = n->dims[i];
+        const int cs = i == 0 ? 1 : d.out_p;
+        add_conv_specs(n, m + "pool_semi", cs, cs, 3, 3);                     // models.py:313 / :337
+        add_bn_specs(n, m + "pool_semi_b", cs);
+        const int pc_in = i == 0 ? 1 : d.out_p + d.prev_pc, pc_out = i == 0 ? nf : d.out_pc;
+        for (int j = 0; j < c.conv_layers; ++j) {                             // models.py:191-197
+            add_conv_specs(n, m + "pc2pc.layer." + std::to_string(3 * j) + ".conv2d", pc_out, j == 0 ? pc_in : pc_out, 12, k);
+            add_bn_specs(n, m + "pc2pc.layer." + std::to_string(3 * j + 1), pc_out);
+        }
+        if (i >= 1) {
+            add_spec(n, m + "up_sixth.weight", {d.prev_pc, d.prev_pc, 3, 1}); // models.py:325
+            add_spec(n, m + "up_sixth.bias", {d.prev_pc});
+            add_bn_specs(n, m + "up_sixth_b", d.prev_pc);
+            for (int j = 0; j < c.conv_layers; ++j) {                         // models.py:228-234
+                add_conv_specs(n, m + "p2p.layer." + std::to_string(3 * j), d.out_p, j == 0 ? d.prev_pc + d.prev_p : d.out_p, k, k);
+                add_bn_specs(n, m + "p2p.layer." + std::to_string(3 * j + 1), d.out_p);
+            }
+        }
+    }
+    for (const char* head : {"tonic_classifier", "key_classifier", "genre_classifier"}) {   // models.py:716-737
+        const bool g = std::strcmp(head, "genre_classifier") == 0;
+        if (g && !c.genre) continue;
+        int ch = n->final_ch;
+        for (int i = 0; i < c.head_layers; ++i) {
+            const std::string base = std::string(head) + "." + std::to_string(3 * i) + (g ? "" : ".conv2d");
+            if (i == c.head_layers - 1) {
+                add_conv_specs(n, base, 1, ch, g ? 2 : 12, k);
+            } else {
+                const int co = i == 0 ? 2 * ch : ch;
+                add_conv_specs(n, base, co, ch, g ? 1 : 12, k);
+                add_bn_specs(n, std::string(head) + "." + std::to_string(3 * i + 1), co);
+                ch = co;
+            }
+        }
+    }
+    n->host.resize(n->specs.size());
+    *out = n;
+    return AKE_OK;
+}
+
+void ake_pcnet_destroy(ake_pcnet* n) {
+    if (!n) return;
+    if (n->blob_dev) (void)hipFree(n->blob_dev);
+    delete n;
+}
+
+int ake_pcnet_pitches(const ake_pcnet* n) { return n ? n->cfg.pitches : 0; }
+
+int ake_pcnet_num_tensors(const ake_pcnet* n) { return n ? static_cast<int>(n->specs.size()) : 0; }
+
+int ake_pcnet_tensor_info(const ake_pcnet* n, int index, const char** name, int64_t shape[4], int* ndim) {
+    AKE_REQUIRE(n && index >= 0 && index < static_cast<int>(n->specs.size()), AKE_ERR_INVALID, "tensor_info: index out of range");
+    const TensorSpec& s = n->specs[index];
+    if (name) *name = s.name.c_str();
+    if (shape) std::memcpy(shape, s.shape, sizeof(s.shape));
+    if (ndim) *ndim = s.ndim;
+    return AKE_OK;
+}
+
+int ake_pcnet_set_tensor(ake_pcnet* n, const char* name, const float* host_data, const int64_t* shape, int ndim) {
+    AKE_REQUIRE(n && name && host_data && shape, AKE_ERR_INVALID, "set_tensor: null argument");
+    auto it = n->spec_index.find(name);
+    AKE_REQUIRE(it != n->spec_index.end(), AKE_ERR_INVALID, "set_tensor: unexpected key '%s' for this configuration", name);
+    const TensorSpec& s = n->specs[it->second];
+    AKE_REQUIRE(ndim == s.ndim, AKE_ERR_INVALID, "set_tensor: '%s' has %d dims, expected %d", name, ndim, s.ndim);
+    size_t count = 1;
+    for (int i = 0; i < ndim; ++i) {
+        AKE_REQUIRE(shape[i] == s.shape[i], AKE_ERR_INVALID, "set_tensor: '%s' dim %d is %lld, expected %lld", name, i,
+                    static_cast<long long>(shape[i]), static_cast<long long>(s.shape[i]));
+        count *= static_cast<size_t>(shape[i]);
+    }
+    HostTensor& h = n->host[it->second];
+    h.data.assign(host_data, host_data + count);
+    h.set = true;
+    n->finalized = false;
+    return AKE_OK;
+}
+
+int ake_pcnet_finalize(ake_pcnet* n) {
+    AKE_REQUIRE(n, AKE_ERR_INVALID, "finalize: null handle");
+    for (size_t i = 0; i < n->specs.size(); ++i)
+        AKE_REQUIRE(n->host[i].set, AKE_ERR_STATE, "finalize: missing key '%s' (load_state_dict strict=True)", n->specs[i].name.c_str());
+    const auto& c = n->cfg;
+    const int L = c.num_layers, k = c.kernel_size;
+    n->blob.clear();
+    n->semi.assign(L, PackedConv()); n->up.assign(L, PackedConv());
+    n->pc2pc.assign(L, {}); n->p2p.assign(L, {});
+    n->head_key.clear(); n->head_tonic.clear(); n->head_genre.clear();
+    for (int i = 0; i < L; ++i) {
+        const std::string m = "model." + std::to_string(i) + ".";
+        const LayerDims& d = n->dims[i];
+        const int cs = i == 0 ? 1 : d.out_p;
+        n->semi[i] = fold_pack(n, m + "pool_semi", m + "pool_semi_b", cs, cs, 3, 3);
+        const int pc_in = i == 0 ? 1 : d.out_p + d.prev_pc, pc_out = i == 0 ? c.n_filters : d.out_pc;
+        for (int j = 0; j < c.conv_layers; ++j)
+            n->pc2pc[i].push_back(fold_pack(n, m + "pc2pc.layer." + std::to_string(3 * j) + ".conv2d",
+                                            m + "pc2pc.layer." + std::to_string(3 * j + 1), pc_out, j == 0 ? pc_in : pc_out, 12, k));
+        if (i >= 1) {
+            std::vector<double> w, b;
+            fold(n, m + "up_sixth.weight", m + "up_sixth.bias", m + "up_sixth_b", d.prev_pc,
+                 static_cast<size_t>(d.prev_pc) * 3, true, d.prev_pc, w, b);
+            PackedConv u;
+            u.cin = u.cout = d.prev_pc; u.kh = 3; u.kw = 1;
+            n->blob.resize(ake::align_up(n->blob.size(), 64));
+            u.w_off = n->blob.size();
+            for (double v : w) n->blob.push_back(static_cast<float>(v));   // stays [ci][co][3]
+            n->blob.resize(ake::align_up(n->blob.size(), 64));
+            u.b_off = n->blob.size();
+            for (double v : b) n->blob.push_back(static_cast<float>(v));
+            n->up[i] = u;
+            for (int j = 0; j < c.conv_layers; ++j)
+                n->p2p[i].push_back(fold_pack(n, m + "p2p.layer." + std::to_string(3 * j), m + "p2p.layer." + std::to_string(3 * j + 1),
+                                              d.out_p, j == 0 ? d.prev_pc + d.prev_p : d.out_p, k, k));
+        }
+    }
+    for (const char* head : {"tonic_classifier", "key_classifier", "genre_classifier"}) {
+        const bool g = std::strcmp(head, "genre_classifier") == 0;
+        if (g && !c.genre) continue;
+        auto& vec = g ? n->head_genre : (std::strcmp(head, "key_classifier") == 0 ? n->head_key : n->head_tonic);
+        int ch = n->final_ch;
+        for (int i = 0; i < c.head_layers; ++i) {
+            const std::string base = std::string(head) + "." + std::to_string(3 * i) + (g ? "" : ".conv2d");
+            if (i == c.head_layers - 1) vec.push_back(fold_pack(n, base, "", 1, ch, g ? 2 : 12, k));
+            else {
+                const int co = i == 0 ? 2 * ch : ch;
+                vec.push_back(fold_pack(n, base, std::string(head) + "." + std::to_string(3 * i + 1), co, ch, g ? 1 : 12, k));
+                ch = co;
+            }
+        }
+    }
+    n->blob.resize(ake::align_up(n->blob.size() + 64, 64), 0.f);
+    if (n->blob_dev) { (void)hipFree(n->blob_dev); n->blob_dev = nullptr; }
+    AKE_HIP_CHECK(hipMalloc(&n->blob_dev, n->blob.size() * sizeof(float)));
+    AKE_HIP_CHECK(hipMemcpy(n->blob_dev, n->blob.data(), n->blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    n->finalized = true;
+    return AKE_OK;
+}
+
+size_t ake_pcnet_workspace_bytes(const ake_pcnet* n, int batch, int frames) {
+    if (!n || batch <= 0 || frames <= 0) return 0;
+    Buffers b;
+    if (plan_buffers(n, std::min(batch, n->chunk_clips), frames, nullptr, &b) != AKE_OK) return 0;
+    return b.bytes;
+}
+
+static int forward_chunk(const ake_pcnet* n, Buffers& b, const float* mel, int clip0, int B, int frames,
+                         const int64_t* seq, float* key_out, float* tonic_out, float* genre_out, hipStream_t s) {
+    const auto& c = n->cfg;
+    const int L = c.num_layers, P = c.pitches, tp = c.time_pool_size;
+    int rc;
+    const float* p_cur = mel;     // pitch stream: [B][cp][P][Tcur]
+    int cp = 1;
+    float* pc_cur = nullptr;      // pitch-class stream
+    int cpc = 0;
+    for (int i = 0; i < L; ++i) {
+        const int Ti = b.Tl[i];
+        const LayerDims& d = n->dims[i];
+        if (i == 0) {
+            // models.py:361-369  pool_semi -> fold -> pc2pc
+            if ((rc = run_semi(n, n->semi[0], mel, B, P, Ti, b.fold0, 1, 0, s, "semi_fold_kernel/L0"))) return rc;
+            const float* src = b.fold0;
+            int cin = 1;
+            for (int j = 0; j < c.conv_layers; ++j) {
+                const bool last = j == c.conv_layers - 1;
+                float* dst; int ctot, coff = 0;
+                if (last && L > 1) { dst = b.cat[1]; ctot = n->dims[1].prev_pc + n->dims[1].out_p; }
+                else { dst = (j & 1) ? b.pcb[0] : b.pca[0]; ctot = c.n_filters; }
+                if ((rc = run_conv(n, n->pc2pc[0][j], 1, Src{src, cin, nullptr, 0, 0}, B, 12, Ti, true, true, dst, ctot, coff, s,
+                                   "conv_rows_kernel/pc2pc0")))
+                    return rc;
+                src = dst; cin = c.n_filters;
+                if (last) { pc_cur = dst; cpc = c.n_filters; }
+            }
+            if (L > 1) {
+                // pc_cur lives in cat[1] channels [0, nf); layer 1 reads it through the concat buffer
+            }
+        } else {
+            const int ctot = d.prev_pc + d.out_p;
+            // models.py:372-374  up_sixth (+BN+LReLU).  Input = first prev_pc channels of cat[i].
+            {
+                const long long total = static_cast<long long>(B) * d.prev_pc * 36 * Ti;
+                // the pitch-class features are the first prev_pc channels of this layer's concat buffer
+                ake::ProfScope ps("up_sixth_kernel", s);
+                hipLaunchKernelGGL(up_sixth_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, pc_cur,
+                                   static_cast<long long>(ctot) * 12 * Ti, n->blob_dev + n->up[i].w_off,
+                                   n->blob_dev + n->up[i].b_off, b.psix[i], d.prev_pc, Ti, total);
+            }
+            // models.py:378-384  repeat + concat (never materialised) + pitch convs
+            const float* src = p_cur;
+            Src sdesc{src, cp, b.psix[i], d.prev_pc, 36};
+            float* out = nullptr;
+            for (int j = 0; j < c.conv_layers; ++j) {
+                out = (j & 1) ? b.pb[i] : b.pa[i];
+                if ((rc = run_conv(n, n->p2p[i][j], 0, sdesc, B, P, Ti, true, true, out, d.out_p, 0, s, "conv_rows_kernel/p2p")))
+                    return rc;
+                sdesc = Src{out, d.out_p, nullptr, 0, 0};
+            }
+            // models.py:386-392  pool_semi -> fold, written next to pc in the concat buffer
+            if ((rc = run_semi(n, n->semi[i], out, B, P, Ti, b.cat[i], ctot, d.prev_pc, s, "semi_fold_kernel/L1+"))) return rc;
+            // models.py:393  pc2pc
+            const float* psrc = b.cat[i];
+            int cin = ctot;
+            float* pdst = nullptr;
+            for (int j = 0; j < c.conv_layers; ++j) {
+                pdst = (j & 1) ? b.pcb[i] : b.pca[i];
+                if ((rc = run_conv(n, n->pc2pc[i][j], 1, Src{psrc, cin, nullptr, 0, 0}, B, 12, Ti, true, true, pdst, d.out_pc, 0, s,
+                                   "conv_rows_kernel/pc2pc")))
+                    return rc;
+                psrc = pdst; cin = d.out_pc;
+            }
+            // models.py:395-396  time pooling (the pitch stream of the last layer feeds nothing: skipped)
+            const bool last_layer = i == L - 1;
+            {
+                float* dstp = last_layer ? b.pcf : b.cat[i + 1];
+                const int dct = last_layer ? d.out_pc : n->dims[i + 1].prev_pc + n->dims[i + 1].out_p;
+                const long long total = static_cast<long long>(B) * d.out_pc * 12 * (Ti / tp);
+                ake::ProfScope ps("time_pool_kernel", s);
+                hipLaunchKernelGGL(time_pool_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, pdst, dstp,
+                                   d.out_pc, 12, Ti, tp, dct, 0, total);
+                pc_cur = dstp; cpc = d.out_pc;
+            }
+            if (!last_layer) {
+                const long long total = static_cast<long long>(B) * d.out_p * P * (Ti / tp);
+                ake::ProfScope ps("time_pool_kernel", s);
+                hipLaunchKernelGGL(time_pool_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, out, b.ppool[i],
+                                   d.out_p, P, Ti, tp, d.out_p, 0, total);
+                p_cur = b.ppool[i]; cp = d.out_p;
+            }
+        }
+    }
+    if (L == 1) {   // single layer: no pooling, features are the layer-0 pc stack output
+        AKE_HIP_CHECK(hipMemcpyAsync(b.pcf, pc_cur, sizeof(float) * B * cpc * 12 * b.Tf, hipMemcpyDeviceToDevice, s));
+    }
+    // ---- heads (models.py:750-753) ----
+    const int Tf = b.Tf;
+    struct HeadRun { const std::vector<PackedConv>* convs; float* hid; float* map; int kind; int rows; };
+    HeadRun heads[3] = {{&n->head_key, b.hid_k, b.map_k, 1, 12}, {&n->head_tonic, b.hid_t, b.map_t, 1, 12},
+                        {&n->head_genre, b.hid_g, b.map_g, 2, 11}};
+    int Tm = Tf;
+    for (int h = 0; h < (c.genre ? 3 : 2); ++h) {
+        const float* src = b.pcf;
+        int cin = n->final_ch, Tcur = Tf;
+        const size_t hid_half = static_cast<size_t>(B) * 2 * n->final_ch * 12 * Tf;
+        for (int j = 0; j < c.head_layers; ++j) {
+            const PackedConv& pcv = (*heads[h].convs)[j];
+            const bool last = j == c.head_layers - 1;
+            float* dst = last ? heads[h].map : heads[h].hid + (j & 1) * hid_half;
+            if ((rc = run_conv(n, pcv, heads[h].kind, Src{src, cin, nullptr, 0, 0}, B, 12, Tcur, false, !last, dst, pcv.cout, 0, s,
+                               h == 2 ? "conv_rows_kernel/genre_head" : "conv_rows_kernel/head")))
+                return rc;
+            src = dst; cin = pcv.cout; Tcur -= c.kernel_size - 1;
+        }
+        Tm = Tcur;
+    }
+    // ---- masked temporal mean, sigmoid (models.py:754-804) ----
+    PoolHeadArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    pa.maps[0] = b.map_k; pa.maps[1] = b.map_t; pa.maps[2] = c.genre ? b.map_g : nullptr;
+    pa.outs[0] = key_out; pa.outs[1] = tonic_out; pa.outs[2] = genre_out;
+    pa.rows[0] = 12; pa.rows[1] = 12; pa.rows[2] = 11;
+    pa.Tm = Tm; pa.seq = reinterpret_cast<const long long*>(seq);
+    pa.n_pool_layers = L - 1; pa.tp = tp; pa.shrink = (c.kernel_size - 1) * c.head_layers;
+    pa.max_pool = c.max_pool; pa.batch = B; pa.clip0 = clip0;
+    {
+        ake::ProfScope ps("head_pool_kernel", s);
+        hipLaunchKernelGGL(head_pool_kernel, dim3((B * 12 + 63) / 64, 3), dim3(64), 0, s, pa);
+    }
+    AKE_HIP_CHECK(hipGetLastError());
+    return AKE_OK;
+}
+
+int ake_pcnet_forward_f32(const ake_pcnet* n, const float* mel, int batch, int frames, const int64_t* seq_length,
+                          float* key_out, float* tonic_out, float* genre_out, void* workspace, size_t ws_bytes,
+                          ake_stream_t stream) {
+    AKE_REQUIRE(n && mel && key_out && tonic_out, AKE_ERR_INVALID, "ake_pcnet_forward_f32: null argument");
+    AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
+    AKE_REQUIRE(batch > 0 && frames > 0, AKE_ERR_INVALID, "pcnet: bad batch/frames");
+    AKE_REQUIRE(!n->cfg.genre || genre_out, AKE_ERR_INVALID, "pcnet: genre head enabled but genre_out is null");
+    const int chunk = std::min(batch, n->chunk_clips);
+    Buffers b;
+    int rc = plan_buffers(n, chunk, frames, workspace, &b);
+    if (rc) return rc;
+    AKE_REQUIRE(workspace && ws_bytes >= b.bytes, AKE_ERR_WORKSPACE, "pcnet: workspace %zu < %zu bytes", ws_bytes, b.bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int c0 = 0; c0 < batch; c0 += chunk) {
+        const int B = std::min(chunk, batch - c0);
+        rc = forward_chunk(n, b, mel + static_cast<size_t>(c0) * n->cfg.pitches * frames, c0, B, frames,
+                           seq_length ? seq_length + c0 : nullptr, key_out + static_cast<size_t>(c0) * 12,
+                           tonic_out + static_cast<size_t>(c0) * 12, genre_out ? genre_out + static_cast<size_t>(c0) * 11 : nullptr, s);
+        if (rc) return rc;
+    }
+    return AKE_OK;
+}
+
+// ---- debug taps ---------------------------------------------------------------------------
+static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frames, const void* ws, float** p, int64_t shape[4]) {
+    AKE_REQUIRE(n && name, AKE_ERR_INVALID, "tap: null argument");
+    AKE_REQUIRE(batch <= n->chunk_clips, AKE_ERR_INVALID, "tap: batch %d exceeds the chunk size %d", batch, n->chunk_clips);
+    Buffers b;
+    int rc = plan_buffers(n, batch, frames, const_cast<void*>(ws), &b);
+    if (rc) return rc;
+    const auto& c = n->cfg;
+    const int L = c.num_layers, P = c.pitches;
+    const std::string nm = name;
+    auto set = [&](float* ptr, int64_t C, int64_t H, int64_t Tn) { *p = ptr; shape[0] = batch; shape[1] = C; shape[2] = H; shape[3] = Tn; return AKE_OK; };
+    if (nm == "model.0.pool") return set(b.fold0, 1, 12, frames);
+    for (int i = 0; i < L; ++i) {
+        const std::string m = "model." + std::to_string(i) + ".";
+        const LayerDims& d = n->dims[i];
+        const int Ti = b.Tl[i];
+        const int last_j = c.conv_layers - 1;
+        for (int j = 0; j < c.conv_layers; ++j) {
+            if (nm == m + "pc2pc.layer." + std::to_string(3 * j + 2)) {
+                if (i == 0 && j == last_j && L > 1) break;   // lives inside the concat buffer (strided)
+                return set((j & 1) ? b.pcb[i] : b.pca[i], i == 0 ? c.n_filters : d.out_pc, 12, Ti);
+            }
+            if (i >= 1 && nm == m + "p2p.layer." + std::to_string(3 * j + 2)) return set((j & 1) ? b.pb[i] : b.pa[i], d.out_p, P, Ti);
+        }
+        if (i >= 1 && nm == m + "up_sixth_a") return set(b.psix[i], d.prev_pc, 36, Ti);
+        if (i >= 1 && nm == m + "cat") return set(b.cat[i], d.prev_pc + d.out_p, 12, Ti);
+        if (i == L - 1 && i >= 1 && nm == m + "time_pool_pc") return set(b.pcf, d.out_pc, 12, b.Tf);
+    }
+    const int Tm = b.Tf - (c.kernel_size - 1) * c.head_layers;
+    if (nm == "key_map") return set(b.map_k, 1, 12, Tm);
+    if (nm == "tonic_map") return set(b.map_t, 1, 12, Tm);
+    if (nm == "genre_map" && c.genre) return set(b.map_g, 1, 11, Tm);
+    ake::set_error("tap: '%s' is not a materialised activation", name);
+    return AKE_ERR_INVALID;
+}
+
+int ake_pcnet_tap_info(const ake_pcnet* n, const char* name, int batch, int frames, int64_t shape[4]) {
+    float* p = nullptr;
+    return tap_lookup(n, name, batch, frames, nullptr, &p, shape);
+}
+
+int ake_pcnet_tap_copy(const ake_pcnet* n, const char* name, int batch, int frames, const void* workspace, float* out_dev,
+                       ake_stream_t stream) {
+    AKE_REQUIRE(workspace && out_dev, AKE_ERR_INVALID, "tap_copy: null argument");
+    float* p = nullptr;
+    int64_t shape[4];
+    int rc = tap_lookup(n, name, batch, frames, workspace, &p, shape);
+    if (rc) return rc;
+    AKE_HIP_CHECK(hipMemcpyAsync(out_dev, p, sizeof(float) * shape[0] * shape[1] * shape[2] * shape[3], hipMemcpyDeviceToDevice,
+                                 static_cast<hipStream_t>(stream)));
+    return AKE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,337 @@
+// Device kernels of the PitchClassNet forward pass (gfx950).  Included by pcnet.hip only.
+//
+// Everything here is fp32.  All convolutions of the net are "rows circular, time local":
+//
+//     out[co][y][t] = b[co] + sum_{ci,dy,dx} w[co][ci][dy][dx] * in[ci][(y + dy - py) mod H][t + dx - pad_l]
+//
+//   pitch conv 7x7 (models.py:230-232): H = pitches, py = 3, time wraps too (circular)
+//   equivariant pitch-class conv (models.py:45-47): H = 12, KH = 12, py = 0, time zero-pad / valid
+//   genre convs (models.py:724,733): KH = 1 / 2, py = 0, valid; the row H_out..H-1 is not stored
+//
+// so one kernel template covers them.  MI355X mapping:
+//   * a workgroup owns (clip, R rows, TT frames, CO output channels); its input patch
+//     [Cin][R+KH-1][TT+KW-1] is staged once in LDS with both halos materialised (no modulo in
+//     the inner loop);
+//   * a thread owns CO x 4 outputs (CO channels x 4 consecutive frames): per (ci,dy) it reads
+//     one 40-byte strip from LDS (three ds_read_b128) and issues KW*4*CO FMAs;
+//   * the weights of a workgroup are wave-uniform: they are packed [group][ci][dy][dx][CO] so
+//     that the compiler fetches them with s_load_dwordx8/x16 into SGPRs -- the FMA's second
+//     operand is a scalar register and costs no VGPR, no LDS bandwidth;
+//   * BatchNorm (eval) is folded into w/b on the host, LeakyReLU is the epilogue.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace ake_k {
+
+constexpr int TW = 4;              // frames per thread
+constexpr float kSlope = 0.01f;    // nn.LeakyReLU() default (models.py:197)
+
+struct ConvArgs {
+    const float* src0;        // [B][c0][H][T_src]
+    const float* src1;        // [B][c1][h1][T_src] rows repeated: row y reads y % h1 (PitchClass2Pitch, models.py:140-143)
+    long long src0_clip_stride, src1_clip_stride;
+    int c0, c1, h1;
+    int H;                    // circular row count
+    int T_in;                 // frames of the input
+    int T_out;                // frames of the output
+    int H_out;                // rows stored
+    int py;                   // row anchor
+    int pad_l;                // time anchor: input frame = t + dx - pad_l
+    int time_circ;            // 1: frames wrap (padding_mode="circular"), 0: zeros outside
+    const float* w;           // [groups][cin][KH][KW][CO]
+    const float* bias;        // [groups*CO]
+    int cout;
+    float* dst;               // [B][dst_ctot][H_out][T_out]
+    long long dst_clip_stride;
+    int dst_coff;
+    int lrelu;
+    int R;                    // output rows per workgroup (ignored when FULLROWS)
+    int TT;                   // output frames per workgroup (multiple of TW)
+    int n_row_tiles, n_time_tiles;
+    int Tp;                   // LDS row pitch in floats (multiple of 4, >= TT + KW - 1)
+};
+
+__device__ __forceinline__ int wrap(int i, int n) {
+    i %= n;
+    return i < 0 ? i + n : i;
+}
+
+template <int KH, int KW, int CO, bool FULLROWS>
+__global__ void conv_rows_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int cin = a.c0 + a.c1;
+    const int tile = blockIdx.x;
+    const int row_tile = tile / a.n_time_tiles;
+    const int time_tile = tile - row_tile * a.n_time_tiles;
+    const int grp = blockIdx.y;
+    const int clip = blockIdx.z;
+    const int y0 = FULLROWS ? 0 : row_tile * a.R;
+    const int t0 = time_tile * a.TT;
+    const int R_in = FULLROWS ? a.H : a.R + KH - 1;
+    const int Tp = a.Tp;
+
+    // ---- stage the input patch (both halos resolved here) ----
+    const float* s0 = a.src0 + clip * a.src0_clip_stride;
+    const float* s1 = a.src1 ? a.src1 + clip * a.src1_clip_stride : nullptr;
+    const int rowsz = R_in * Tp;
+    const int total = cin * rowsz;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int ci = idx / rowsz;
+        const int rem = idx - ci * rowsz;
+        const int rj = rem / Tp;
+        const int tj = rem - rj * Tp;
+        const int row = FULLROWS ? rj : wrap(y0 - a.py + rj, a.H);
+        int ti = t0 - a.pad_l + tj;
+        float v = 0.f;
+        bool ok = true;
+        if (a.time_circ) ti = wrap(ti, a.T_in);
+        else ok = (ti >= 0) && (ti < a.T_in);
+        if (ok) {
+            if (ci < a.c0) v = s0[(static_cast<long long>(ci) * a.H + row) * a.T_in + ti];
+            else v = s1[(static_cast<long long>(ci - a.c0) * a.h1 + (row % a.h1)) * a.T_in + ti];
+        }
+        lds[idx] = v;
+    }
+    __syncthreads();
+
+    // ---- compute ----
+    const int strips = a.TT / TW;
+    const int r = threadIdx.x / strips;
+    const int s = threadIdx.x - r * strips;
+    const int rows_here = FULLROWS ? a.H : a.R;
+    if (r >= rows_here) return;
+    const int y = y0 + r;
+    if (y >= a.H) return;
+
+    float acc[CO][TW];
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int j = 0; j < TW; ++j) acc[co][j] = 0.f;
+
+    const float* __restrict__ wg = a.w + static_cast<long long>(grp) * cin * (KH * KW * CO);
+    constexpr int NIN = TW + KW - 1;
+    constexpr int NV4 = (NIN + 3) / 4;
+    int lrow = FULLROWS ? wrap(y - a.py, a.H) : r;
+    for (int ci = 0; ci < cin; ++ci) {
+        int lr = lrow;
+        for (int dy = 0; dy < KH; ++dy) {
+            const float4* p4 = reinterpret_cast<const float4*>(lds + (ci * R_in + lr) * Tp + s * TW);
+            float in[NV4 * 4];
+#pragma unroll
+            for (int q = 0; q < NV4; ++q) {
+                const float4 v = p4[q];
+                in[4 * q + 0] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
+            }
+            const float* __restrict__ wp = wg + (ci * KH + dy) * (KW * CO);
+#pragma unroll
+            for (int dx = 0; dx < KW; ++dx)
+#pragma unroll
+                for (int co = 0; co < CO; ++co) {
+                    const float wv = wp[dx * CO + co];
+#pragma unroll
+                    for (int j = 0; j < TW; ++j) acc[co][j] = fmaf(in[j + dx], wv, acc[co][j]);
+                }
+            if (FULLROWS) { lr = lr + 1; if (lr == a.H) lr = 0; }
+            else lr = lr + 1;
+        }
+    }
+
+    // ---- epilogue: bias (BN folded), LeakyReLU, store ----
+    if (y >= a.H_out) return;
+    float* d = a.dst + clip * a.dst_clip_stride;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        const int c = grp * CO + co;
+        if (c >= a.cout) break;
+        const float b = a.bias[c];
+        float* drow = d + (static_cast<long long>(a.dst_coff + c) * a.H_out + y) * a.T_out;
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            const int t = t0 + s * TW + j;
+            if (t < a.T_out) {
+                float v = acc[co][j] + b;
+                if (a.lrelu) v = v > 0.f ? v : v * kSlope;
+                drow[t] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Semitone conv (3x3, stride (3,1), time circular; models.py:313-315 / 337-339) + BN + LeakyReLU
+// fused with the pitch -> pitch-class fold (dilated max over octaves, models.py:95-106).
+// thread = (clip, CO channels, pitch class p, 4 frames); loops over the octaves.
+// ------------------------------------------------------------------------------------------
+struct SemiArgs {
+    const float* src;   // [B][C][H][T]
+    long long src_clip_stride;
+    int C, H, T;
+    const float* w;     // [groups][C][3][3][CO]
+    const float* bias;
+    float* dst;         // [B][dst_ctot][12][T]
+    long long dst_clip_stride;
+    int dst_coff;
+    int n_strips;       // ceil(T / TW)
+};
+
+template <int CO>
+__global__ void semi_fold_kernel(SemiArgs a) {
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_clip = 12 * a.n_strips;
+    if (item >= per_clip) return;
+    const int p = item / a.n_strips;
+    const int s = item - p * a.n_strips;
+    const int grp = blockIdx.y;
+    const int clip = blockIdx.z;
+    const int t0 = s * TW;
+    int tix[TW + 2];
+#pragma unroll
+    for (int j = 0; j < TW + 2; ++j) tix[j] = wrap(t0 - 1 + j, a.T);
+    const float* src = a.src + clip * a.src_clip_stride;
+    const float* __restrict__ wg = a.w + static_cast<long long>(grp) * a.C * (9 * CO);
+    float best[CO][TW];
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int j = 0; j < TW; ++j) best[co][j] = -INFINITY;
+    const int n_oct = a.H / 36;
+    for (int o = 0; o < n_oct; ++o) {
+        const int row0 = 3 * (p + 12 * o);
+        float acc[CO][TW];
+#pragma unroll
+        for (int co = 0; co < CO; ++co)
+#pragma unroll
+            for (int j = 0; j < TW; ++j) acc[co][j] = 0.f;
+        for (int ci = 0; ci < a.C; ++ci) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const float* rowp = src + (static_cast<long long>(ci) * a.H + row0 + dy) * a.T;
+                float in[TW + 2];
+#pragma unroll
+                for (int j = 0; j < TW + 2; ++j) in[j] = rowp[tix[j]];
+                const float* __restrict__ wp = wg + (ci * 3 + dy) * (3 * CO);
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) {
+                        const float wv = wp[dx * CO + co];
+#pragma unroll
+                        for (int j = 0; j < TW; ++j) acc[co][j] = fmaf(in[j + dx], wv, acc[co][j]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            const int c = grp * CO + co;
+            const float b = c < a.C ? a.bias[c] : 0.f;
+#pragma unroll
+            for (int j = 0; j < TW; ++j) {
+                float v = acc[co][j] + b;
+                v = v > 0.f ? v : v * kSlope;
+                best[co][j] = fmaxf(best[co][j], v);
+            }
+        }
+    }
+    float* d = a.dst + clip * a.dst_clip_stride;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        const int c = grp * CO + co;
+        if (c >= a.C) break;
+        float* drow = d + (static_cast<long long>(a.dst_coff + c) * 12 + p) * a.T;
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+            if (t0 + j < a.T) drow[t0 + j] = best[co][j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// up_sixth: ConvTranspose2d(C, C, (3,1), stride (3,1)) + BN + LeakyReLU (models.py:325-327):
+// out[co][3p+j][t] = lrelu(b[co] + sum_ci in[ci][p][t] * w[ci][co][j])
+// ------------------------------------------------------------------------------------------
+__global__ void up_sixth_kernel(const float* __restrict__ src, long long src_clip_stride, const float* __restrict__ w,
+                                const float* __restrict__ bias, float* __restrict__ dst, int C, int T, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int t = static_cast<int>(i % T);
+    long long q = i / T;
+    const int row = static_cast<int>(q % 36);
+    q /= 36;
+    const int co = static_cast<int>(q % C);
+    const long long clip = q / C;
+    const int p = row / 3, j = row - 3 * p;
+    const float* s = src + clip * src_clip_stride + static_cast<long long>(p) * T + t;   // src may be a channel slice of a concat buffer
+    float acc = bias[co];
+    for (int ci = 0; ci < C; ++ci) acc = fmaf(s[static_cast<long long>(ci) * 12 * T], w[(ci * C + co) * 3 + j], acc);
+    dst[i] = acc > 0.f ? acc : acc * kSlope;
+}
+
+// nn.MaxPool2d((1, tp)) (models.py:349-350): [B][C][H][T] -> [B][dst_ctot][H][T/tp] at channel dst_coff
+__global__ void time_pool_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int T, int tp,
+                                 int dst_ctot, int dst_coff, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int To = T / tp;
+    const int t = static_cast<int>(i % To);
+    long long q = i / To;
+    const int y = static_cast<int>(q % H);
+    q /= H;
+    const int c = static_cast<int>(q % C);
+    const long long clip = q / C;
+    const float* s = src + ((clip * C + c) * H + y) * T + static_cast<long long>(t) * tp;
+    float m = s[0];
+    for (int j = 1; j < tp; ++j) m = fmaxf(m, s[j]);
+    dst[((clip * dst_ctot + dst_coff + c) * H + y) * To + t] = m;
+}
+
+// ------------------------------------------------------------------------------------------
+// Masked temporal mean over the head maps + sigmoid on key (models.py:754-804).
+// maps: [B][rows][Tm]; one thread per (clip, row).
+// ------------------------------------------------------------------------------------------
+struct PoolHeadArgs {
+    const float* maps[3];     // key, tonic, genre (genre may be null)
+    float* outs[3];
+    int rows[3];              // 12, 12, 11
+    int Tm;                   // frames of the maps
+    const long long* seq;     // [B] or null
+    int n_pool_layers;        // num_layers - 1
+    int tp;                   // time_pool_size
+    int shrink;               // (kernel_size - 1) * head_layers
+    int max_pool;
+    int batch;
+    int clip0;                // global index of the first clip of this chunk (for the max_pool sample-0 quirk)
+};
+
+__global__ void head_pool_kernel(PoolHeadArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int which = blockIdx.y;
+    if (a.maps[which] == nullptr) return;
+    const int rows = a.rows[which];
+    if (i >= a.batch * rows) return;
+    const int clip = i / rows;
+    int L = a.Tm;
+    bool use_max = a.max_pool != 0;
+    if (a.seq) {
+        long long l = a.seq[clip];
+        for (int k = 0; k < a.n_pool_layers; ++k) l = l / a.tp;      // floor (models.py:759)
+        L = static_cast<int>(l) - a.shrink;                           // models.py:760
+        if (L > a.Tm) L = a.Tm;                                       // x[..., :L] clamps at the end ...
+        if (L < 0) L = a.Tm + L > 0 ? a.Tm + L : 0;                   // ... and counts from the end when negative
+        use_max = use_max && (a.clip0 + clip == 0);                   // models.py:764-785 quirk
+    }
+    const float* m = a.maps[which] + static_cast<long long>(i) * a.Tm;
+    float v;
+    if (use_max) {
+        v = -INFINITY;
+        for (int t = 0; t < L; ++t) v = fmaxf(v, m[t]);
+    } else {
+        float sum = 0.f;
+        for (int t = 0; t < L; ++t) sum += m[t];
+        v = sum / static_cast<float>(L > 0 ? L : 0);                  // empty slice -> NaN, as torch.mean
+    }
+    if (which == 0) v = 1.f / (1.f + expf(-v));                       // self.sig(key_out), models.py:802
+    a.outs[which][i] = v;
+}
+
+}  // namespace ake_k

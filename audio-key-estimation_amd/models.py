@@ -1,0 +1,360 @@
+"""Drop-in ``PitchClassNet`` whose forward pass runs on hand-written HIP kernels (gfx950).
+
+Same constructor, ``forward(mel, seq_length)`` contract, LightningModule hook names and
+``state_dict`` keys/shapes as the reference class (models.py:651-1116), so
+``train_model.py`` / ``eval.py`` style code and a reference ``best_model.pt`` load unchanged
+(``load_state_dict(strict=True)``, eval.py:115).
+
+The torch modules below are *parameter containers only* (they give the parameters their
+reference names and default initialisation); no torch op computes the network.  ``forward``
+hands the tensors to ``libake_hip.so`` (``ake_pcnet_forward_f32``); without that library, or on
+a CPU tensor, it raises -- there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+from .lightning_shim import LightningModule
+from .metrics import mirex_score as _mirex_score
+
+_VARIANT_FLAGS = ("resblock", "denseblock", "stay_sixth", "only_semitones", "p2pc_conv", "pc2p_mem", "local")
+
+
+class EquivariantPitchClassConvolutionSimple(nn.Module):
+    """Parameter container for models.py:22-33: ``conv2d`` = Conv2d(cin, cout, (12, kd))."""
+
+    def __init__(self, pitch_classes, in_channels, out_channels, kernel_depth, same_depth_padding=False):
+        super().__init__()
+        self.conv2d = nn.Conv2d(in_channels, out_channels, (pitch_classes, kernel_depth),
+                                padding=(0, kernel_depth // 2 if same_depth_padding else 0))
+
+
+class _ConvStack(nn.Module):
+    """Parameter container for PitchClass2PitchClass / Pitch2Pitch (models.py:190-199, 227-237): ``layer`` Sequential."""
+
+    def __init__(self, blocks):
+        super().__init__()
+        self.layer = nn.Sequential(*blocks)
+
+
+def _pc2pc(cin, cout, k, n):
+    blocks = []
+    for i in range(n):
+        blocks += [EquivariantPitchClassConvolutionSimple(12, cin if i == 0 else cout, cout, k, True), nn.BatchNorm2d(cout), nn.LeakyReLU()]
+    return _ConvStack(blocks)
+
+
+def _p2p(cin, cout, k, n):
+    blocks = []
+    for i in range(n):
+        blocks += [nn.Conv2d(cin if i == 0 else cout, cout, k, padding=k // 2, padding_mode="circular"), nn.BatchNorm2d(cout), nn.LeakyReLU()]
+    return _ConvStack(blocks)
+
+
+class PitchClassNetLayer(nn.Module):
+    """Parameter container for one layer (models.py:246-350); creation order matches the reference
+    so that the same torch seed gives the same initial weights."""
+
+    def __init__(self, layer_num, nf, k, conv_layers):
+        super().__init__()
+        if layer_num == 0:
+            self.pool_semi = nn.Conv2d(1, 1, 3, stride=(3, 1), padding=(0, 1), padding_mode="circular")
+            self.pool_semi_b = nn.BatchNorm2d(1)
+            self.pool_semi_a = nn.LeakyReLU()
+            self.pc2pc = _pc2pc(1, nf, k, conv_layers)
+            return
+        if layer_num == 1:
+            prev_p, prev_pc = 1, nf
+            out_p = 2 * nf
+            out_pc = 2 * out_p
+        else:
+            prev_p = 2 * nf if layer_num == 2 else 2 * nf * 4 ** (layer_num - 2)
+            prev_pc = 2 * prev_p
+            out_p, out_pc = 4 * prev_p, 4 * prev_pc
+        self.up_sixth = nn.ConvTranspose2d(prev_pc, prev_pc, kernel_size=(3, 1), stride=(3, 1))
+        self.up_sixth_b = nn.BatchNorm2d(prev_pc)
+        self.up_sixth_a = nn.LeakyReLU()
+        self.p2p = _p2p(prev_pc + prev_p, out_p, k, conv_layers)
+        self.pool_semi = nn.Conv2d(out_p, out_p, (3, 3), stride=(3, 1), padding=(0, 1), padding_mode="circular")
+        self.pool_semi_b = nn.BatchNorm2d(out_p)
+        self.pool_semi_a = nn.LeakyReLU()
+        self.pc2pc = _pc2pc(out_p + prev_pc, out_pc, k, conv_layers)
+        self.out_pc = out_pc
+
+
+def _opt_get(opt, name, default):
+    return getattr(opt, name, default) if opt is not None else default
+
+
+class PitchClassNet(LightningModule):
+
+    def __init__(self, pitches, pitch_classes, num_layers, kernel_size, opt=None, window_size=23, batch_size=4,
+                 train_set=None, val_set=None):
+        super().__init__()
+        self.pitches, self.pitch_classes = pitches, pitch_classes
+        self.num_layers, self.kernel_size = num_layers, kernel_size
+        self.batch_size, self.window_size, self.opt = batch_size, window_size, opt
+        self.conv_layers = _opt_get(opt, "conv_layers", 3)
+        self.n_filters = _opt_get(opt, "n_filters", 4)
+        self.best_mirex_score = 0
+        self.data = {"train": train_set, "val": val_set}
+        for flag in _VARIANT_FLAGS:
+            if _opt_get(opt, flag, False):
+                raise NotImplementedError(f"--{flag} selects a non-default architecture variant that the HIP path does not build "
+                                          "(SURVEY.md section 2.1); only the default PitchClassNet family is available")
+        nf, k = self.n_filters, kernel_size
+        self.model = nn.Sequential(*[PitchClassNetLayer(i, nf, k, self.conv_layers) for i in range(num_layers)])
+        final = nf if num_layers == 1 else self.model[num_layers - 1].out_pc          # models.py:694-710
+        self.head_layers = _opt_get(opt, "head_layers", 2)
+        self.genre = bool(_opt_get(opt, "genre", False))
+        t, kk, g = [], [], []
+        ch = final
+        for i in range(self.head_layers):                                              # models.py:716-737
+            if i == self.head_layers - 1:
+                t.append(EquivariantPitchClassConvolutionSimple(12, ch, 1, k))
+                kk.append(EquivariantPitchClassConvolutionSimple(12, ch, 1, k))
+                if self.genre:
+                    g.append(nn.Conv2d(ch, 1, kernel_size=(2, k)))
+            else:
+                co = 2 * ch if i == 0 else ch
+                t += [EquivariantPitchClassConvolutionSimple(12, ch, co, k), nn.BatchNorm2d(co), nn.LeakyReLU()]
+                kk += [EquivariantPitchClassConvolutionSimple(12, ch, co, k), nn.BatchNorm2d(co), nn.LeakyReLU()]
+                if self.genre:
+                    g += [nn.Conv2d(ch, co, kernel_size=(1, k)), nn.BatchNorm2d(co), nn.LeakyReLU()]
+                ch = co
+        self.tonic_classifier = nn.Sequential(*t)
+        self.key_classifier = nn.Sequential(*kk)
+        if self.genre:
+            self.genre_classifier = nn.Sequential(*g)
+        self.sig = nn.Sigmoid()
+        # device-side state (not part of the state_dict)
+        self._h = None
+        self._h_device = None
+        self._h_stamp = None
+        self._ws = None
+
+    # ------------------------------------------------------------------ device handle
+    def _float_state(self):
+        return [(k, v) for k, v in self.state_dict(keep_vars=True).items() if v.is_floating_point()]
+
+    def _config(self):
+        c = _lib.PcnetConfig()
+        c.pitches, c.pitch_classes, c.num_layers, c.kernel_size = self.pitches, self.pitch_classes, self.num_layers, self.kernel_size
+        c.conv_layers, c.n_filters, c.head_layers = self.conv_layers, self.n_filters, self.head_layers
+        c.time_pool_size = _opt_get(self.opt, "time_pool_size", 2)
+        c.genre = 1 if self.genre else 0
+        c.max_pool = 1 if _opt_get(self.opt, "max_pool", False) else 0
+        return c
+
+    def _sync_weights(self, device):
+        """(Re)build the device handle when parameters changed (optimizer step, load_state_dict, .to())."""
+        state = self._float_state()
+        stamp = (str(device),) + tuple((v._version, v.data_ptr()) for _, v in state)
+        if self._h is not None and stamp == self._h_stamp:
+            return
+        L = _lib.lib()
+        with torch.cuda.device(device):
+            if self._h is None or self._h_device != device:
+                self._release()
+                cfg = self._config()
+                h = C.c_void_p()
+                _lib.check(L.ake_pcnet_create(C.byref(cfg), C.byref(h)), "ake_pcnet_create")
+                self._h, self._h_device = h, device
+            expected = set()
+            for i in range(L.ake_pcnet_num_tensors(self._h)):
+                name, shape, ndim = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+                _lib.check(L.ake_pcnet_tensor_info(self._h, i, C.byref(name), shape, C.byref(ndim)), "ake_pcnet_tensor_info")
+                expected.add(name.value.decode())
+            have = {k for k, _ in state}
+            if expected != have:
+                raise _lib.AkeError(f"state_dict keys differ from the device layout: missing {sorted(expected - have)[:4]}, "
+                                    f"unexpected {sorted(have - expected)[:4]}")
+            for k, v in state:
+                host = v.detach().to(device="cpu", dtype=torch.float32).contiguous()
+                shape = (C.c_int64 * max(1, host.dim()))(*host.shape)
+                _lib.check(L.ake_pcnet_set_tensor(self._h, k.encode(), host.data_ptr(), shape, host.dim()), f"ake_pcnet_set_tensor({k})")
+            _lib.check(L.ake_pcnet_finalize(self._h), "ake_pcnet_finalize")
+        self._h_stamp = stamp
+
+    def _release(self):
+        d = self.__dict__                    # plain attributes; avoids nn.Module.__setattr__ at interpreter shutdown
+        h = d.get("_h")
+        if h is not None:
+            try:
+                _lib.lib().ake_pcnet_destroy(h)
+            except Exception:      # noqa: BLE001
+                pass
+        d["_h"] = None
+        d["_h_stamp"] = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:          # noqa: BLE001
+            pass
+
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        return self._ws
+
+    @property
+    def handle(self):
+        """Opaque ``ake_pcnet*`` (valid after a forward or ``prepare()``)."""
+        return self._h
+
+    def prepare(self):
+        """Upload the current weights to the device now (otherwise done lazily by ``forward``)."""
+        self._sync_weights(self._device())
+        return self
+
+    def _device(self):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.AkeError("PitchClassNet.forward runs on a HIP device only: move the module with .cuda() "
+                                "(the reference does so in its constructors, models.py:199,237,739). No CPU fallback.")
+        return dev
+
+    # ------------------------------------------------------------------ forward (models.py:747-817)
+    def forward(self, mel, seq_length):
+        if self.training:
+            raise NotImplementedError("train-mode forward (batch-statistics BatchNorm) and backward are not built yet: "
+                                      "call .eval(); see DESIGN.md 'Out of scope this round'")
+        device = self._device()
+        self._sync_weights(device)
+        assert mel.dim() == 4 and mel.shape[1] == 1 and mel.shape[2] == self.pitches, \
+            f"mel must be (B,1,{self.pitches},T), got {tuple(mel.shape)}"                     # models.py:357
+        out_dtype = mel.dtype if mel.is_floating_point() else torch.float32
+        x = mel.to(device=device, dtype=torch.float32).contiguous()
+        B, _, _, Tn = x.shape
+        seq = None
+        if seq_length is not None:
+            seq = torch.as_tensor(seq_length).to(device=device, dtype=torch.int64).reshape(-1)
+            if seq.numel() == 1 and B > 1:
+                seq = seq.expand(B)
+            seq = seq.contiguous()
+            assert seq.numel() == B
+        key = torch.empty((B, 12), dtype=torch.float32, device=device)
+        tonic = torch.empty((B, 12), dtype=torch.float32, device=device)
+        genre = torch.empty((B, 11), dtype=torch.float32, device=device) if self.genre else None
+        L = _lib.lib()
+        ws = self._workspace(L.ake_pcnet_workspace_bytes(self._h, B, Tn), device)
+        with torch.cuda.device(device):
+            _lib.check(L.ake_pcnet_forward_f32(self._h, x.data_ptr(), B, Tn, seq.data_ptr() if seq is not None else None,
+                                               key.data_ptr(), tonic.data_ptr(), genre.data_ptr() if genre is not None else None,
+                                               ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                       "ake_pcnet_forward_f32")
+        self._last_shape = (B, Tn)
+        if self.genre:
+            return key.to(out_dtype), tonic.to(out_dtype), genre.to(out_dtype)               # models.py:813
+        return key.to(out_dtype), tonic.to(out_dtype)                                         # models.py:815
+
+    def tap(self, name):
+        """Intermediate activation of the last forward (debug / bisecting): reference module path -> tensor."""
+        B, Tn = self._last_shape
+        L = _lib.lib()
+        shape = (C.c_int64 * 4)()
+        _lib.check(L.ake_pcnet_tap_info(self._h, name.encode(), B, Tn, shape), "ake_pcnet_tap_info")
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=self._h_device)
+        with torch.cuda.device(self._h_device):
+            _lib.check(L.ake_pcnet_tap_copy(self._h, name.encode(), B, Tn, self._ws.data_ptr(), out.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "ake_pcnet_tap_copy")
+        return out
+
+    # ------------------------------------------------------------------ steps (models.py:819-1027)
+    def general_step(self, batch, batch_idx, mode):
+        opt = self.opt
+        mel = batch["mel"]
+        key_signature_id = batch["key_signature_id"]
+        key_labels = batch["key_labels"].to(mel.dtype if mel.is_floating_point() else torch.float32)
+        tonic_labels = batch["tonic_labels"].long()
+        tonic_idx = torch.argmax(tonic_labels, dim=1)
+        if self.genre:
+            genre_labels = batch["genre"].long()
+            genre_idx = torch.argmax(genre_labels, dim=1)
+            genre_mask = genre_labels.sum(dim=1) == 1                                        # models.py:839
+        out = self.forward(mel, batch["seq_length"] if _opt_get(opt, "frames", 5) > 0 else None)
+        key_out, tonic_out = out[0], out[1]
+        dev = key_out.device
+        key_labels, tonic_idx = key_labels.to(dev), tonic_idx.to(dev)
+        loss = _opt_get(opt, "key_weight", 1.0) * F.binary_cross_entropy(key_out, key_labels.to(key_out.dtype)) \
+            + _opt_get(opt, "tonic_weight", 1.0) * F.cross_entropy(tonic_out, tonic_idx)      # models.py:878-889
+        accuracy_genre = torch.tensor(0.0)
+        if self.genre:
+            genre_mask, genre_idx = genre_mask.to(dev), genre_idx.to(dev)
+            if genre_mask.sum() != 0:                                                         # models.py:892-893
+                g = out[2][genre_mask]
+                loss = loss + _opt_get(opt, "genre_weight", 0.1) * F.cross_entropy(g, genre_idx[genre_mask])
+                accuracy_genre = (torch.argmax(g, dim=1) == genre_idx[genre_mask]).float().mean()
+        if _opt_get(opt, "use_cos", False):                                                   # models.py:885-896
+            loss = loss + (1 - F.cosine_similarity(key_out, key_labels.to(key_out.dtype), dim=1).sum() / key_out.shape[0])
+        mirex, correct, fifths, relative, parallel, other, accuracy = self.mirex_score(
+            key_labels, key_out, tonic_labels.to(dev), tonic_out, key_signature_id.to(dev))
+        accuracy_tonic = (torch.argmax(tonic_out, dim=1) == tonic_idx).float().mean()
+        return loss, accuracy, mirex, correct, fifths, relative, parallel, other, accuracy_tonic, accuracy_genre
+
+    def mirex_score(self, key_labels, key_preds, tonic_labels, tonic_preds, key_signature_id):
+        return _mirex_score(key_labels, key_preds, tonic_labels, tonic_preds, key_signature_id)
+
+    _NAMES = ("accuracy", "mirex_score", "correct", "fifths", "relative", "parallel", "other", "accuracy_tonic", "accuracy_genre")
+
+    def _step(self, batch, batch_idx, mode):
+        vals = self.general_step(batch, batch_idx, mode)
+        d = {(mode + "_loss") if mode != "train" else "loss": vals[0]}
+        d.update({f"{mode}_{n}": v for n, v in zip(self._NAMES, vals[1:])})
+        return d
+
+    def training_step(self, batch, batch_idx):
+        d = self._step(batch, batch_idx, "train")
+        d["log"] = {"loss": d["loss"]}
+        return d
+
+    def validation_step(self, batch, batch_idx):
+        return self._step(batch, batch_idx, "val")
+
+    def test_step(self, batch, batch_idx):
+        return self._step(batch, batch_idx, "test")
+
+    def general_end(self, outputs, mode):
+        names = ("loss",) + self._NAMES
+        return tuple(torch.stack([torch.as_tensor(x[f"{mode}_{n}"]).float().cpu() for x in outputs]).mean() for n in names)
+
+    def validation_epoch_end(self, outputs):
+        vals = self.general_end(outputs, "val")
+        names = ("val_loss", "val_accuracy", "val_mirex_score", "val_correct", "val_fifths", "val_relative", "val_parallel",
+                 "val_other", "val_accuracy_tonic", "val_accuracy_genre")
+        result = dict(zip(names, vals))
+        print("Val-Loss={}".format(result["val_loss"]))
+        print("Val-Acc={}".format(result["val_accuracy"]))
+        print("Val-Acc_Tonic={}".format(result["val_accuracy_tonic"]))
+        if self.genre:
+            print("Val-Acc_Genre={}".format(result["val_accuracy_genre"]))
+        print("Val-Mirex_Score={}".format(result["val_mirex_score"]))
+        for k, v in result.items():
+            self.log(k, v)
+        no_ckpt = _opt_get(self.opt, "no_ckpt", True)
+        if result["val_mirex_score"] > self.best_mirex_score and not no_ckpt:                 # models.py:991-993
+            self.best_mirex_score = result["val_mirex_score"]
+            import os
+            path = "Model_logs/lightning_logs/version_" + str(getattr(self.logger, "version", 0))
+            os.makedirs(path, exist_ok=True)
+            torch.save(self.state_dict(), path + "/best_model.pt")
+        result["log"] = dict(result)
+        return result
+
+    def train_dataloader(self):
+        return torch.utils.data.DataLoader(self.data["train"], shuffle=True, batch_size=self.batch_size)
+
+    def val_dataloader(self):
+        return torch.utils.data.DataLoader(self.data["val"], shuffle=False, batch_size=self.batch_size, drop_last=True)
+
+    def configure_optimizers(self):
+        optim = torch.optim.Adam(self.parameters(), betas=(0.9, 0.999), lr=_opt_get(self.opt, "lr", 3e-4),
+                                 weight_decay=_opt_get(self.opt, "reg", 0))
+        scheduler = torch.optim.lr_scheduler.ExponentialLR(optim, gamma=_opt_get(self.opt, "gamma", 0.96))
+        return [optim], [scheduler]

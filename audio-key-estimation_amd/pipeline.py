@@ -1,0 +1,44 @@
+"""Whole hot path in one call: waveforms on the GPU -> (key, tonic[, genre]).
+
+Host wrapper of ``ake_pipeline_forward_f32``: CQT, seq_length fill and the network run back
+to back on one stream with no host round trip (what ``DatasetLoader.get_all`` ->
+``KeyDataset.__getitem__`` -> ``PitchClassNet.forward`` do in the reference, KeyDataset.py:469-509,
+242-256, models.py:846).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .cqt import CQTPlan, hop_for
+from .models import PitchClassNet
+
+
+class KeyEstimator:
+    def __init__(self, net: PitchClassNet, sample_rate: int = 22050, frames: int = 5):
+        self.net = net.eval()
+        self.device = net._device()
+        self.plan = CQTPlan(sample_rate, hop_for(sample_rate, frames), net.pitches, 36, device=self.device)
+        self._ws = None
+
+    @torch.no_grad()
+    def __call__(self, audio: torch.Tensor):
+        """audio (B, n) float32 on the GPU -> tuple of (B,12), (B,12)[, (B,11)] float32 tensors."""
+        net, L = self.net, _lib.lib()
+        net._sync_weights(self.device)
+        audio = audio.to(device=self.device, dtype=torch.float32)
+        if audio.stride(-1) != 1:
+            audio = audio.contiguous()
+        B, n = audio.shape
+        nbytes = L.ake_pipeline_workspace_bytes(self.plan.handle, net.handle, B, n)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+        key = torch.empty((B, 12), dtype=torch.float32, device=self.device)
+        tonic = torch.empty((B, 12), dtype=torch.float32, device=self.device)
+        genre = torch.empty((B, 11), dtype=torch.float32, device=self.device) if net.genre else None
+        with torch.cuda.device(self.device):
+            _lib.check(L.ake_pipeline_forward_f32(self.plan.handle, net.handle, audio.data_ptr(), B, n, audio.stride(0),
+                                                  key.data_ptr(), tonic.data_ptr(), genre.data_ptr() if genre is not None else None,
+                                                  self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream),
+                       "ake_pipeline_forward_f32")
+        return (key, tonic, genre) if net.genre else (key, tonic)

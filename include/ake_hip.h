@@ -1,0 +1,158 @@
+/*
+ * ake_hip.h -- C ABI of libake_hip.so, the MI355X (gfx950) implementation of the
+ * key-estimation hot path:  waveform -> CQT log-magnitude -> PitchClassNet forward.
+ *
+ * The reference (flo-stilz/Audio-Key-Estimation) is pure Python and defines no FFI;
+ * each entry point below names the reference call it stands in for (file:line into
+ * the reference tree).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - every function returns AKE_OK (0) or a negative error code; no C++ exception
+ *     crosses the ABI; ake_last_error() returns a thread-local message;
+ *   - "dev" pointers are device (HIP) pointers, "host" pointers are host memory;
+ *   - compute entry points never allocate and never synchronise: the caller passes
+ *     a workspace (size from the matching *_workspace_bytes) and a hipStream_t;
+ *     they are safe to capture into a hipGraph;
+ *   - one handle may be used from one stream at a time (the workspace is the
+ *     per-call state; handles are immutable after creation / finalize);
+ *   - all tensors are dense row-major float32, NCHW as in the reference.
+ */
+#ifndef AKE_HIP_H
+#define AKE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AKE_OK 0
+#define AKE_ERR_INVALID (-1)     /* bad argument / shape */
+#define AKE_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define AKE_ERR_STATE (-3)       /* handle not finalized, tensor missing, ... */
+#define AKE_ERR_WORKSPACE (-4)   /* workspace too small */
+#define AKE_ERR_UNSUPPORTED (-5) /* architecture flag outside the default family */
+
+typedef void* ake_stream_t; /* hipStream_t */
+
+int ake_version(void);
+const char* ake_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * CQT front end.  Replaces
+ *     librosa.cqt(y, sr, hop_length=round(sr/frames), bins_per_octave=36, n_bins=36*octaves)
+ *     -> torch.abs -> torch.log(1 + .)                 KeyDataset.py:485, 490-499
+ * (also equivariance_test.py:161-169).  Definition: oracle/cqt_oracle.py (direct form);
+ * evaluated here octave-recursively (half-band decimators + per-phase filter banks).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ake_cqt_plan ake_cqt_plan;
+
+typedef struct ake_cqt_config {
+    int sample_rate;      /* Hz, e.g. 22050 */
+    int hop_length;       /* samples between frame centres; KeyDataset.py:485 */
+    int n_bins;           /* 36 * octaves; KeyDataset.py:491 */
+    int bins_per_octave;  /* 36 */
+    double fmin;          /* Hz of bin 0; <=0 selects librosa's default C1 = 32.7032 Hz */
+    int q_mode;           /* 0: Q = (r^2+1)/(r^2-1) (librosa >= 0.10); 1: Q = 1/(r-1) (<= 0.9) */
+    int decim_half_len;   /* half length of the half-band decimator; <=0 selects 23 (47 taps) */
+    double decim_beta;    /* Kaiser beta of the decimator; <=0 selects 8.0 */
+} ake_cqt_config;
+
+/* hop = round(sample_rate / frames_per_second) (KeyDataset.py:485), n_bins = 36 * octaves. */
+int ake_cqt_default_config(ake_cqt_config* cfg, int sample_rate, int frames_per_second, int octaves);
+/* Builds the filter tables in double precision on the host and uploads them to the current device. */
+int ake_cqt_plan_create(const ake_cqt_config* cfg, ake_cqt_plan** out);
+void ake_cqt_plan_destroy(ake_cqt_plan* plan);
+int ake_cqt_plan_n_bins(const ake_cqt_plan* plan);
+/* 1 + n_samples / hop  (librosa center=True framing). */
+int64_t ake_cqt_num_frames(const ake_cqt_plan* plan, int64_t n_samples);
+size_t ake_cqt_workspace_bytes(const ake_cqt_plan* plan, int batch, int64_t n_samples);
+/*
+ * audio_dev : [batch][audio_stride] float32, first n_samples of each row are the clip
+ * out_dev   : [batch][n_bins][out_frames] float32 = log(1 + |CQT|); frames >= num_frames are
+ *             written as 0 (the zero padding KeyDataset.__getitem__ appends, KeyDataset.py:245)
+ */
+int ake_cqt_logmag_f32(const ake_cqt_plan* plan, const float* audio_dev, int batch, int64_t n_samples,
+                       int64_t audio_stride, float* out_dev, int64_t out_frames, void* workspace,
+                       size_t workspace_bytes, ake_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PitchClassNet forward (inference: eval-mode BatchNorm folded into the convolutions).
+ * Replaces  PitchClassNet.forward(mel, seq_length)   models.py:747-817
+ * and everything it calls (models.py:22-106, 135-143, 168-243, 246-399).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ake_pcnet ake_pcnet;
+
+typedef struct ake_pcnet_config {
+    int pitches;        /* CQT bins = 36*octaves; models.py:653 */
+    int pitch_classes;  /* 12 */
+    int num_layers;     /* opt.num_layers, default 2 */
+    int kernel_size;    /* opt.kernel_size, default 7 */
+    int conv_layers;    /* opt.conv_layers, default 3 */
+    int n_filters;      /* opt.n_filters, default 4 */
+    int head_layers;    /* opt.head_layers, default 2 */
+    int time_pool_size; /* opt.time_pool_size, default 2 */
+    int genre;          /* opt.genre: 1 adds the 11-way genre head */
+    int max_pool;       /* opt.max_pool (models.py:766-797, sample-0 quirk kept) */
+    /* Non-default architecture variants (models.py:108-133,145-166,402-648): must be 0,
+     * ake_pcnet_create returns AKE_ERR_UNSUPPORTED otherwise. */
+    int resblock, denseblock, stay_sixth, only_semitones, p2pc_conv, pc2p_mem, local;
+} ake_pcnet_config;
+
+int ake_pcnet_default_config(ake_pcnet_config* cfg, int octaves, int genre);
+int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out);
+void ake_pcnet_destroy(ake_pcnet* net);
+
+int ake_pcnet_pitches(const ake_pcnet* net);
+
+/* The float entries of the reference state_dict this configuration expects
+ * (models.py:993 / eval.py:115 strict=True): names and shapes, for host-side validation. */
+int ake_pcnet_num_tensors(const ake_pcnet* net);
+int ake_pcnet_tensor_info(const ake_pcnet* net, int index, const char** name, int64_t shape[4], int* ndim);
+/* Hand one state_dict entry (host float32, reference layout) to the handle. */
+int ake_pcnet_set_tensor(ake_pcnet* net, const char* name, const float* host_data, const int64_t* shape, int ndim);
+/* All tensors set -> fold BatchNorm (running stats, eps 1e-5), repack for the kernels, upload. */
+int ake_pcnet_finalize(ake_pcnet* net);
+
+size_t ake_pcnet_workspace_bytes(const ake_pcnet* net, int batch, int frames);
+/*
+ * mel_dev        : [batch][1][pitches][frames] float32 (log-CQT, zero padded to `frames`)
+ * seq_length_dev : [batch] int64 valid frames per clip, or NULL (models.py:786-797 branch)
+ * key_out_dev    : [batch][12]  sigmoid pitch-class membership           (models.py:802)
+ * tonic_out_dev  : [batch][12]  tonic logits                             (models.py:800)
+ * genre_out_dev  : [batch][11]  genre logits, ignored unless cfg.genre   (models.py:804)
+ */
+int ake_pcnet_forward_f32(const ake_pcnet* net, const float* mel_dev, int batch, int frames,
+                          const int64_t* seq_length_dev, float* key_out_dev, float* tonic_out_dev,
+                          float* genre_out_dev, void* workspace, size_t workspace_bytes, ake_stream_t stream);
+
+/* Debug tap: copy an intermediate activation of the LAST forward call out of the workspace.
+ * name is the reference module path whose output it is (e.g. "model.1.p2p.layer.8"). */
+int ake_pcnet_tap_info(const ake_pcnet* net, const char* name, int batch, int frames, int64_t shape[4]);
+int ake_pcnet_tap_copy(const ake_pcnet* net, const char* name, int batch, int frames, const void* workspace,
+                       float* out_dev, ake_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole hot path for a batch of equal-length clips: CQT then forward
+ * (DatasetLoader.get_all -> __getitem__ -> general_step's forward; KeyDataset.py:469-509,
+ * 242-256, models.py:846).  seq_length of every clip = num_frames(n_samples).
+ * ---------------------------------------------------------------------------------------- */
+size_t ake_pipeline_workspace_bytes(const ake_cqt_plan* plan, const ake_pcnet* net, int batch, int64_t n_samples);
+int ake_pipeline_forward_f32(const ake_cqt_plan* plan, const ake_pcnet* net, const float* audio_dev, int batch,
+                             int64_t n_samples, int64_t audio_stride, float* key_out_dev, float* tonic_out_dev,
+                             float* genre_out_dev, void* workspace, size_t workspace_bytes, ake_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-kernel timing with hipEvents recorded on the launch stream (bench.py roofline leg).
+ * ---------------------------------------------------------------------------------------- */
+int ake_prof_enable(const char* name_filter /* substring, NULL or "" = all */, int on);
+int ake_prof_collect(void);                 /* synchronises the recorded events, accumulates */
+int ake_prof_reset(void);
+int ake_prof_num_entries(void);
+int ake_prof_entry(int index, const char** kernel_name, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AKE_HIP_H */

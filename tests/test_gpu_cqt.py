@@ -1,0 +1,86 @@
+"""PARITY (GPU): the HIP multirate CQT, through the C ABI, against the float64 direct-form oracle.
+
+The CQT oracle is the build's own specification (parity with librosa is UNPINNED, oracle/cqt_oracle.py).
+Tolerance: 1e-3 of the tensor's peak (north_star); the multirate evaluation's own error is ~1.5e-4
+(tools/cqt_multirate_proto.py), so we assert 5e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+import ake_amd
+from ake_amd import synthetic
+from conftest import rel_err
+from oracle import cqt_oracle as O
+
+pytestmark = pytest.mark.gpu
+SR, HOP, DEV = 22050, 4410, "cuda:0"
+TOL = 5e-4
+
+
+@pytest.fixture(scope="module")
+def plan():
+    return ake_amd.CQTPlan(SR, HOP, 288, 36, device=DEV)
+
+
+def test_short_clips_against_direct_form(plan):
+    ys, _ = synthetic.make_batch(range(3), SR * 3)
+    rng = np.random.default_rng(0)
+    ys = np.concatenate([ys, rng.normal(0, 0.3, (1, SR * 3)).astype(np.float32)])        # + white noise (aliasing stress)
+    got = plan.logmag(torch.from_numpy(ys).to(DEV)).cpu().numpy()
+    assert got.shape == (4, 288, 16)
+    for b in range(4):
+        ref = O.cqt_logmag(ys[b], SR, HOP)
+        assert rel_err(got[b], ref) < TOL, b
+
+
+def test_full_length_clip_against_direct_form(plan):
+    """One BASELINE-size clip: 15 s @ 22.05 kHz -> (288, 76)."""
+    y, _ = synthetic.make_clip(7)
+    got = plan.logmag(torch.from_numpy(y).to(DEV)).cpu().numpy()
+    assert got.shape == (288, 76)
+    ref = O.FastDirectCQT(SR, HOP, dtype=torch.float64)(y[None])[0].numpy()
+    assert rel_err(got, ref) < TOL
+
+
+@pytest.mark.parametrize("n", [4409, 4410, 4411, 30000, 70001])
+def test_ragged_lengths_and_padding(plan, n):
+    """Lengths around a hop boundary and clips shorter than the longest filter; frames past the clip are zero."""
+    y, _ = synthetic.make_clip(2, n)
+    T = O.n_frames(n, HOP)
+    got = plan.logmag(torch.from_numpy(y).to(DEV), out_frames=T + 3).cpu().numpy()
+    assert got.shape == (288, T + 3) and np.all(got[:, T:] == 0)
+    assert rel_err(got[:, :T], O.cqt_logmag(y, SR, HOP)) < TOL
+
+
+def test_other_rates_and_hops():
+    for sr, frames, octaves in ((44100, 5, 8), (22050, 10, 8), (22050, 5, 7)):
+        hop = ake_amd.hop_for(sr, frames)
+        p = ake_amd.CQTPlan(sr, hop, 36 * octaves, 36, device=DEV)
+        y, _ = synthetic.make_clip(4, sr * 2, sr)
+        got = p.logmag(torch.from_numpy(y).to(DEV)).cpu().numpy()
+        assert rel_err(got, O.cqt_logmag(y, sr, hop, n_bins=36 * octaves)) < TOL, (sr, frames, octaves)
+    with pytest.raises(ake_amd._lib.AkeError, match="Nyquist"):
+        ake_amd.CQTPlan(22050, 4410, 360, 36, device=DEV)                    # 10 octaves do not fit under 11 kHz
+
+
+def test_full_size_batch_properties(plan):
+    """B=64 full-length clips: scaling linearity of |C| and the hop-shift property (size-independent checks)."""
+    audio, _ = synthetic.make_batch_device(range(64), DEV)
+    out = plan.logmag(audio)
+    assert out.shape == (64, 288, 76) and torch.isfinite(out).all()
+    mag = torch.expm1(out)
+    half = torch.expm1(plan.logmag(0.5 * audio))
+    assert ((half - 0.5 * mag).abs().max() / mag.max()).item() < 1e-5
+    # delaying a clip by exactly k hops moves its frames by k (interior frames, away from both edges)
+    k = 3
+    shifted = torch.zeros_like(audio)
+    shifted[:, k * HOP:] = audio[:, :-k * HOP]
+    out_s = plan.logmag(shifted)
+    assert ((out_s[:, :, 12 + k:60] - out[:, :, 12:60 - k]).abs().max() / out.max()).item() < 1e-5
+    # batch independence: a clip's rows do not depend on its neighbours
+    solo = plan.logmag(audio[17:18])
+    assert torch.equal(solo[0], out[17])
+    # and 2 of the 64 against the oracle
+    ref = O.FastDirectCQT(SR, HOP, dtype=torch.float64)(audio[[5, 40]].cpu().numpy()).numpy()
+    assert rel_err(out[[5, 40]].cpu().numpy(), ref) < TOL

@@ -1,0 +1,185 @@
+"""PARITY (GPU): the HIP PitchClassNet forward, called through the C ABI, against the reference fixtures and the oracle.
+
+Tolerance: BASELINE.json states 1e-3 relative (fp32 path vs the reference's fp64 outputs); measured as
+max|a-b| / max|b| per tensor.  The kernels land around 1e-6, so we assert 1e-4 to catch
+regressions long before the stated budget.
+"""
+import json
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+import ake_amd
+from conftest import golden_state_dict, rel_err
+from oracle import mirex_oracle, pcnet_oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4          # asserted;  north_star budget is 1e-3
+DEV = "cuda:0"
+
+
+def make_net(gold, **opt_kw):
+    opt = Namespace(**json.loads(str(gold["opt"])))
+    for k, v in opt_kw.items():
+        setattr(opt, k, v)
+    net = ake_amd.PitchClassNet(opt.octaves * 36, 12, opt.num_layers, opt.kernel_size, opt)
+    net.load_state_dict(golden_state_dict(gold), strict=True)
+    return net.to(DEV).eval(), opt
+
+
+def test_native_library_is_the_compute_path():
+    assert torch.cuda.is_available()
+    import ctypes
+    assert isinstance(ake_amd._lib.lib(), ctypes.CDLL)
+
+
+def test_default_config_against_reference_fixture(gold_default):
+    net, _ = make_net(gold_default)
+    x = torch.from_numpy(gold_default["x"]).to(DEV)
+    seq = torch.from_numpy(gold_default["seq_length"]).to(DEV)
+    key, tonic, genre = net(x, seq)
+    assert key.shape == (4, 12) and tonic.shape == (4, 12) and genre.shape == (4, 11) and key.dtype == torch.float32
+    assert rel_err(key.cpu(), gold_default["key"]) < TOL
+    assert rel_err(tonic.cpu(), gold_default["tonic"]) < TOL
+    assert rel_err(genre.cpu(), gold_default["genre"]) < TOL
+    key, tonic, genre = net(x, None)                              # models.py:786-797 branch
+    assert rel_err(key.cpu(), gold_default["key_noseq"]) < TOL
+    assert rel_err(tonic.cpu(), gold_default["tonic_noseq"]) < TOL
+    assert rel_err(genre.cpu(), gold_default["genre_noseq"]) < TOL
+    # float64 in -> float64 out, as reference scripts expect (train_model.py:105 .double())
+    k64 = net(x.double(), seq)[0]
+    assert k64.dtype == torch.float64 and rel_err(k64.cpu(), gold_default["key"]) < TOL
+
+
+def test_every_layer_against_reference_taps(gold_default, gold_taps):
+    net, _ = make_net(gold_default)
+    x = torch.from_numpy(gold_taps["x"]).to(DEV)
+    outs = net(x, torch.from_numpy(gold_taps["seq_length"]).to(DEV))
+    for got, n in zip(outs, ("key", "tonic", "genre")):
+        assert rel_err(got.cpu(), gold_taps[n]) < TOL
+    direct = ["model.0.pool", "model.0.pc2pc.layer.2", "model.0.pc2pc.layer.5", "model.1.up_sixth_a",
+              "model.1.p2p.layer.2", "model.1.p2p.layer.5", "model.1.p2p.layer.8", "model.1.pc2pc.layer.2",
+              "model.1.pc2pc.layer.5", "model.1.pc2pc.layer.8", "model.1.time_pool_pc", "key_map", "tonic_map", "genre_map"]
+    for name in direct:
+        got = net.tap(name).cpu().numpy()
+        ref = gold_taps["tap/" + name]
+        assert got.shape == ref.shape, name
+        assert rel_err(got, ref) < TOL, name
+    cat = net.tap("model.1.cat").cpu().numpy()                    # [pc | pc2] concat, models.py:392
+    assert rel_err(cat[:, :4], gold_taps["tap/model.0.pc2pc.layer.8"]) < TOL
+    assert rel_err(cat[:, 4:], gold_taps["tap/model.1.pool"]) < TOL
+
+
+def test_guard_octave_equivariance_all_12_shifts(gold_guard):
+    """equivariance_test.py as an assertion: 360-bin net, +-1..12 semitone zero-fill shifts roll key and tonic."""
+    net, opt = make_net(gold_guard)
+    assert opt.octaves == 10 and not net.genre
+    mel = gold_guard["mel"].astype(np.float64)
+    mel_g = np.concatenate([np.zeros((36, 40)), mel, np.zeros((36, 40))])
+    seq = torch.tensor(40).reshape(1, 1)                          # equivariance_test.py:188
+    rows_k, rows_t = [], []
+    for i in range(0, 13):
+        k, t = net(torch.from_numpy(mirex_oracle.mel_shifting_up(mel_g, i)).reshape(1, 1, 360, 40).to(DEV), seq)
+        rows_k.insert(0, k[0].cpu().numpy()); rows_t.insert(0, t[0].cpu().numpy())
+    for i in range(1, 13):
+        k, t = net(torch.from_numpy(mirex_oracle.mel_shifting_down(mel_g, i)).reshape(1, 1, 360, 40).to(DEV), seq)
+        rows_k.append(k[0].cpu().numpy()); rows_t.append(t[0].cpu().numpy())
+    K, T = np.stack(rows_k), np.stack(rows_t)
+    assert K.shape == (25, 12)
+    assert rel_err(K, gold_guard["key_eval"]) < TOL and rel_err(T, gold_guard["tonic_eval"]) < TOL
+    for s in range(1, 13):                                        # <= 1e-5 abs on the fp32 path
+        assert np.abs(K[12 - s] - np.roll(K[12], s)).max() <= 1e-5
+        assert np.abs(K[12 + s] - np.roll(K[12], -s)).max() <= 1e-5
+        assert np.abs(T[12 - s] - np.roll(T[12], s)).max() <= 1e-5
+        assert np.abs(T[12 + s] - np.roll(T[12], -s)).max() <= 1e-5
+
+
+def test_circular_roll_on_training_geometry(gold_default):
+    net, _ = make_net(gold_default)
+    x = torch.from_numpy(gold_default["x"]).to(DEV)
+    k0, t0, g0 = net(x, None)
+    for s in (1, 5, 11):
+        k1, t1, _ = net(torch.roll(x, 3 * s, dims=2), None)
+        assert (k1 - torch.roll(k0, s, dims=1)).abs().max() <= 1e-5
+        assert (t1 - torch.roll(t0, s, dims=1)).abs().max() <= 1e-5
+
+
+@pytest.mark.parametrize("cfg", [dict(num_layers=1), dict(num_layers=3), dict(head_layers=1), dict(head_layers=3),
+                                 dict(conv_layers=2, n_filters=2), dict(n_filters=3), dict(max_pool=True), dict(time_pool_size=4)])
+def test_other_configurations_against_oracle(cfg):
+    """Non-default sizes of the default family: random weights, oracle as the checker."""
+    opt = Namespace(conv_layers=3, n_filters=4, head_layers=2, time_pool_size=2, genre=True, max_pool=False, frames=5)
+    num_layers = cfg.pop("num_layers", 2)
+    for k, v in cfg.items():
+        setattr(opt, k, v)
+    torch.manual_seed(11)
+    net = ake_amd.PitchClassNet(288, 12, num_layers, 7, opt)
+    g = torch.Generator().manual_seed(3)
+    for name, mod in net.named_modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.2)
+            mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+            mod.weight.data.copy_(torch.rand(mod.weight.shape, generator=g) + 0.5)
+            mod.bias.data.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
+    sd64 = pcnet_oracle.to_dtype(net.state_dict(), torch.float64)
+    T = 120 if (num_layers == 3 or opt.time_pool_size == 4 or opt.head_layers == 3) else 52
+    x = torch.rand((3, 1, 288, T), generator=g) * 2.5
+    seq = torch.tensor([T, T - 9, T - 20])
+    ref = pcnet_oracle.pcnet_forward(sd64, x.double(), seq, head_layers=opt.head_layers, time_pool_size=opt.time_pool_size,
+                                     max_pool=opt.max_pool)
+    got = net.to(DEV).eval()(x.to(DEV), seq.to(DEV))
+    for a, b in zip(got, ref):
+        assert rel_err(a.cpu(), b) < TOL
+
+
+def test_weights_follow_parameter_updates(gold_default):
+    """The device copy is refreshed when parameters change in place (optimizer step / load_state_dict)."""
+    net, _ = make_net(gold_default)
+    x = torch.from_numpy(gold_default["x"]).to(DEV)
+    k0 = net(x, None)[0].clone()
+    with torch.no_grad():
+        net.key_classifier[3].conv2d.bias.add_(0.5)
+    k1 = net(x, None)[0]
+    sd = pcnet_oracle.to_dtype({k: v.cpu() for k, v in net.state_dict().items()}, torch.float64)
+    ref = pcnet_oracle.pcnet_forward(sd, x.cpu().double(), None)[0]
+    assert (k1 - k0).abs().max() > 1e-3 and rel_err(k1.cpu(), ref) < TOL
+
+
+def test_full_size_batch_properties(gold_default):
+    """BASELINE config-2 size (B=256, T=76): clips are independent (chunking at 64 must not leak), the batch
+    is a permutation-equivariant map, and 8 of the clips are checked against the oracle."""
+    net, _ = make_net(gold_default)
+    g = torch.Generator().manual_seed(9)
+    x = (torch.rand((256, 1, 288, 76), generator=g) * 2.5).to(DEV)
+    seq = torch.randint(30, 77, (256,), generator=g).to(DEV)
+    key, tonic, genre = net(x, seq)
+    assert torch.isfinite(key).all() and torch.isfinite(tonic).all() and torch.isfinite(genre).all()
+    perm = torch.randperm(256, generator=g).to(DEV)
+    kp, tp, gp = net(x[perm], seq[perm])
+    assert torch.equal(kp, key[perm]) and torch.equal(tp, tonic[perm]) and torch.equal(gp, genre[perm])
+    idx = [0, 1, 63, 64, 65, 127, 128, 255]
+    ks, ts, gs = net(x[idx], seq[idx])
+    assert torch.equal(ks, key[idx]) and torch.equal(ts, tonic[idx])
+    sd = golden_state_dict(gold_default, torch.float64)
+    ref = pcnet_oracle.pcnet_forward(sd, x[idx].cpu().double(), seq[idx].cpu())
+    for a, b in zip((ks, ts, gs), ref):
+        assert rel_err(a.cpu(), b) < TOL
+
+
+def test_edge_shapes(gold_default):
+    net, _ = make_net(gold_default)
+    sd = golden_state_dict(gold_default, torch.float64)
+    g = torch.Generator().manual_seed(1)
+    for B, T in ((1, 26), (1, 27), (2, 33), (1, 151), (1, 300)):        # minimum length, odd lengths, long clips (time tiling)
+        x = torch.rand((B, 1, 288, T), generator=g) * 2.5
+        ref = pcnet_oracle.pcnet_forward(sd, x.double(), None)
+        got = net(x.to(DEV), None)
+        for a, b in zip(got, ref):
+            assert rel_err(a.cpu(), b) < TOL, (B, T)
+    with pytest.raises(ake_amd._lib.AkeError, match="too short"):
+        net(torch.zeros(1, 1, 288, 24, device=DEV), None)                 # T/2 - 12 <= 0 frames left for the heads
+    # seq_length shorter than the heads' receptive field -> mean over an empty slice = NaN, as torch.mean does
+    out = net(torch.rand(1, 1, 288, 76, device=DEV), torch.tensor([24], device=DEV))
+    assert torch.isnan(out[1]).all()

@@ -1,0 +1,93 @@
+"""GPU: the fused entry point, the KeyDataset drop-in and the validate loop."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+import ake_amd
+from ake_amd import synthetic
+from ake_amd.lightning_shim import Trainer
+from conftest import golden_state_dict, rel_err
+from oracle import cqt_oracle, mirex_oracle, pcnet_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def default_opt(**kw):
+    o = dict(conv_layers=3, n_filters=4, head_layers=2, time_pool_size=2, genre=True, max_pool=False, frames=5, octaves=8,
+             key_weight=1.0, tonic_weight=1.0, genre_weight=0.1, use_cos=False, no_ckpt=True, local=False,
+             only_semitones=False, multi_scale=False)
+    o.update(kw)
+    return Namespace(**o)
+
+
+@pytest.fixture(scope="module")
+def net(gold_default):
+    n = ake_amd.PitchClassNet(288, 12, 2, 7, default_opt())
+    n.load_state_dict(golden_state_dict(gold_default), strict=True)
+    return n.to(DEV).eval()
+
+
+def test_pipeline_equals_cqt_then_forward_and_oracle(net, gold_default):
+    est = ake_amd.KeyEstimator(net, 22050, 5)
+    audio, _ = synthetic.make_batch(range(3), synthetic.N_SAMPLES)
+    audio_d = torch.from_numpy(audio).to(DEV)
+    key, tonic, genre = est(audio_d)
+    mel = est.plan.logmag(audio_d)
+    k2, t2, g2 = net(mel[:, None], torch.full((3,), 76, device=DEV))
+    assert torch.equal(key, k2) and torch.equal(tonic, t2) and torch.equal(genre, g2)
+    # end to end against the CPU oracle chain (direct-form CQT -> fp64 net)
+    sd = golden_state_dict(gold_default, torch.float64)
+    mel_ref = cqt_oracle.FastDirectCQT(22050, 4410, dtype=torch.float64)(audio)
+    ref = pcnet_oracle.pcnet_forward(sd, mel_ref[:, None], torch.full((3,), 76))
+    for a, b in zip((key, tonic, genre), ref):
+        assert rel_err(a.cpu(), b) < 1e-3
+
+
+def test_keydataset_item_contract_and_validate(net):
+    opt = default_opt()
+    ds = ake_amd.KeyDataset(True, opt)
+    ds.import_data(ake_amd.SyntheticSineMixLoader(5, n_samples=22050 * 4),
+                   ake_amd.SyntheticSineMixLoader(3, first=100, n_samples=22050 * 6, name="Synthetic long"), shuffle=False)
+    assert len(ds) == 8 and ds.seq_length_max == 31
+    item = ds[0]
+    assert set(item) == {"mel", "key_labels", "tonic_labels", "key_signature_id", "genre", "seq_length"}   # KeyDataset.py:249-256
+    assert item["mel"].shape == (1, 288, 31) and item["mel"].dtype == torch.float64 and item["seq_length"] == 21
+    assert torch.all(item["mel"][:, :, 21:] == 0)
+    assert item["key_labels"].shape == (12,) and item["tonic_labels"].shape == (12,) and item["key_signature_id"].shape == (24,)
+    assert item["genre"].shape == (11,)
+    ref = cqt_oracle.cqt_logmag(synthetic.make_clip(0, 22050 * 4)[0], 22050, 4410)
+    assert rel_err(item["mel"][0, :, :21].numpy(), ref) < 5e-4
+    # --genre off: zeros(8) label (KeyDataset.py:476)
+    ds2 = ake_amd.KeyDataset(False, opt)
+    ds2.import_data(ake_amd.SyntheticSineMixLoader(2, n_samples=22050 * 3), shuffle=False)
+    assert ds2[1]["genre"].shape == (8,)
+    # validate loop with the Lightning hook order; metrics equal the oracle's on the same outputs
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False)
+    res = Trainer().validate(net, dataloaders=loader)[0]
+    assert set(res) >= {"val_loss", "val_mirex_score", "val_accuracy", "val_accuracy_tonic", "val_accuracy_genre"}
+    batch = next(iter(loader))
+    out = net(batch["mel"].to(DEV), batch["seq_length"].to(DEV))
+    m = mirex_oracle.mirex_score(batch["key_labels"].numpy(), out[0].cpu().numpy(), batch["tonic_labels"].numpy(),
+                                 out[1].cpu().numpy(), batch["key_signature_id"].numpy())
+    step = net.validation_step({k: v.to(DEV) if torch.is_tensor(v) else v for k, v in batch.items()}, 0)
+    assert abs(float(step["val_mirex_score"]) - float(m[0])) < 1e-6
+    from oracle import loss_oracle
+    loss = loss_oracle.general_step_loss(out[0].cpu().numpy(), out[1].cpu().numpy(), out[2].cpu().numpy(), batch["key_labels"].numpy(),
+                                         batch["tonic_labels"].numpy(), batch["genre"].numpy())
+    assert abs(float(step["val_loss"]) - loss) < 1e-5
+
+
+def test_kernel_timer_reports_the_launched_kernels(net):
+    est = ake_amd.KeyEstimator(net, 22050, 5)
+    audio = torch.from_numpy(synthetic.make_batch(range(2), 22050 * 3)[0]).to(DEV)
+    est(audio)
+    ake_amd._lib.prof_enable("", True)
+    est(audio)
+    res = ake_amd._lib.prof_results()
+    ake_amd._lib.prof_enable("", False)
+    assert {"cqt_bank_kernel", "cqt_decimate_kernel", "conv_rows_kernel/p2p", "conv_rows_kernel/pc2pc", "head_pool_kernel"} <= set(res)
+    assert res["conv_rows_kernel/p2p"][1] == 3 and res["cqt_decimate_kernel"][1] == 7
+    assert all(ms > 0 for ms, _ in res.values())

@@ -1,0 +1,95 @@
+"""The CPU oracle (oracle/pcnet_oracle.py) against the fixtures generated from the real reference."""
+import json
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+from conftest import golden_state_dict
+from oracle import mirex_oracle, pcnet_oracle
+
+
+def test_default_outputs_fp64(gold_default):
+    sd = golden_state_dict(gold_default, torch.float64)
+    x = torch.from_numpy(gold_default["x"]).double()
+    seq = torch.from_numpy(gold_default["seq_length"])
+    k, t, g = pcnet_oracle.pcnet_forward(sd, x, seq)
+    assert np.abs(k.numpy() - gold_default["key"]).max() <= 1e-12
+    assert np.abs(t.numpy() - gold_default["tonic"]).max() <= 1e-12
+    assert np.abs(g.numpy() - gold_default["genre"]).max() <= 1e-12
+    k, t, g = pcnet_oracle.pcnet_forward(sd, x, None)
+    assert np.abs(k.numpy() - gold_default["key_noseq"]).max() <= 1e-12
+    assert np.abs(t.numpy() - gold_default["tonic_noseq"]).max() <= 1e-12
+    assert np.abs(g.numpy() - gold_default["genre_noseq"]).max() <= 1e-12
+
+
+def test_default_outputs_fp32_within_budget(gold_default):
+    """fp32 arithmetic alone stays far inside the 1e-3 budget (sets expectations for the HIP path)."""
+    sd = golden_state_dict(gold_default, torch.float32)
+    k, t, g = pcnet_oracle.pcnet_forward(sd, torch.from_numpy(gold_default["x"]), torch.from_numpy(gold_default["seq_length"]))
+    for got, name in ((k, "key"), (t, "tonic"), (g, "genre")):
+        ref = gold_default[name]
+        assert np.abs(got.numpy() - ref).max() / np.abs(ref).max() < 1e-4
+
+
+def test_layer_taps(gold_default, gold_taps):
+    sd = golden_state_dict(gold_default, torch.float64)
+    taps = {}
+    outs = pcnet_oracle.pcnet_forward(sd, torch.from_numpy(gold_taps["x"]).double(), torch.from_numpy(gold_taps["seq_length"]), taps=taps)
+    names = [n[4:] for n in gold_taps.files if n.startswith("tap/")]
+    assert len(names) == 16
+    for n in names:
+        ref = gold_taps["tap/" + n]            # stored as float32
+        assert taps[n].shape == ref.shape
+        assert np.abs(taps[n].numpy() - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), n
+    for got, n in zip(outs, ("key", "tonic", "genre")):
+        assert np.abs(got.numpy() - gold_taps[n]).max() <= 1e-12
+
+
+def test_guard_octave_table_and_equivariance(gold_guard):
+    """Rows of the (25,12) stack of equivariance_test.py:172-205, eval and train mode, and the roll identity."""
+    sd = golden_state_dict(gold_guard, torch.float64)
+    opt = Namespace(**json.loads(str(gold_guard["opt"])))
+    assert opt.octaves == 10 and not opt.genre
+    mel = gold_guard["mel"].astype(np.float64)
+    mel_g = np.concatenate([np.zeros((36, 40)), mel, np.zeros((36, 40))])
+    seq = torch.tensor(40).reshape(1, 1)
+
+    def run(m, training):
+        return pcnet_oracle.pcnet_forward(sd, torch.from_numpy(m).reshape(1, 1, 360, 40), seq, training=training)
+
+    for training, kk, tt in ((False, "key_eval", "tonic_eval"), (True, "key_train", "tonic_train")):
+        for s in (0, 1, 5, 12):
+            k, t = run(mirex_oracle.mel_shifting_up(mel_g, s), training)
+            assert np.abs(k[0].numpy() - gold_guard[kk][12 - s]).max() < 1e-11
+            assert np.abs(t[0].numpy() - gold_guard[tt][12 - s]).max() < 1e-11
+            k, t = run(mirex_oracle.mel_shifting_down(mel_g, s), training)
+            assert np.abs(k[0].numpy() - gold_guard[kk][12 + s]).max() < 1e-11
+    # transposition equivariance of the reference outputs themselves
+    base_k, base_t = gold_guard["key_eval"][12], gold_guard["tonic_eval"][12]
+    for s in range(1, 13):
+        assert np.abs(gold_guard["key_eval"][12 - s] - np.roll(base_k, s)).max() < 1e-13
+        assert np.abs(gold_guard["key_eval"][12 + s] - np.roll(base_k, -s)).max() < 1e-13
+        assert np.abs(gold_guard["tonic_eval"][12 - s] - np.roll(base_t, s)).max() < 1e-13
+
+
+def test_circular_roll_on_training_geometry(gold_default):
+    """288-bin geometry: a circular roll by 3 bins (one semitone) rolls key/tonic exactly; genre is NOT invariant."""
+    sd = golden_state_dict(gold_default, torch.float64)
+    x = torch.from_numpy(gold_default["x"][:1]).double()
+    k0, t0, g0 = pcnet_oracle.pcnet_forward(sd, x, None)
+    k1, t1, g1 = pcnet_oracle.pcnet_forward(sd, torch.roll(x, 3, dims=2), None)
+    assert (k1 - torch.roll(k0, 1, dims=1)).abs().max() < 1e-13
+    assert (t1 - torch.roll(t0, 1, dims=1)).abs().max() < 1e-13
+    assert (g1 - g0).abs().max() > 1e-9
+
+
+def test_max_pool_quirk(gold_default):
+    """--max_pool with seq_length: only sample 0 takes the max (models.py:764-785)."""
+    sd = golden_state_dict(gold_default, torch.float64)
+    x = torch.from_numpy(gold_default["x"]).double()
+    seq = torch.from_numpy(gold_default["seq_length"])
+    km, tm, _ = pcnet_oracle.pcnet_forward(sd, x, seq, max_pool=True)
+    ka, ta, _ = pcnet_oracle.pcnet_forward(sd, x, seq)
+    assert np.abs(tm[1:].numpy() - ta[1:].numpy()).max() == 0
+    assert np.abs(tm[0].numpy() - ta[0].numpy()).max() > 1e-6
