@@ -685,11 +685,17 @@ static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frame
         const int Ti = b.Tl[i];
         const int last_j = c.conv_layers - 1;
         for (int j = 0; j < c.conv_layers; ++j) {
+            // ping-pong buffers: only the last two outputs of a stack are still in memory after the forward
             if (nm == m + "pc2pc.layer." + std::to_string(3 * j + 2)) {
-                if (i == 0 && j == last_j && L > 1) break;   // lives inside the concat buffer (strided)
+                const bool to_cat = i == 0 && L > 1;             // layer 0's last conv writes into cat[1]
+                if (to_cat && j == last_j) break;                // strided inside the concat buffer: use "model.1.cat"
+                if (j < last_j - (to_cat ? 2 : 1)) break;
                 return set((j & 1) ? b.pcb[i] : b.pca[i], i == 0 ? c.n_filters : d.out_pc, 12, Ti);
             }
-            if (i >= 1 && nm == m + "p2p.layer." + std::to_string(3 * j + 2)) return set((j & 1) ? b.pb[i] : b.pa[i], d.out_p, P, Ti);
+            if (i >= 1 && nm == m + "p2p.layer." + std::to_string(3 * j + 2)) {
+                if (j < last_j - 1) break;
+                return set((j & 1) ? b.pb[i] : b.pa[i], d.out_p, P, Ti);
+            }
         }
         if (i >= 1 && nm == m + "up_sixth_a") return set(b.psix[i], d.prev_pc, 36, Ti);
         if (i >= 1 && nm == m + "cat") return set(b.cat[i], d.prev_pc + d.out_p, 12, Ti);

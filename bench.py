@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/s (15 s @ 22.05 kHz) through HIP CQT + PitchClassNet forward.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+One "step" = one pass of the hot path (``ake_pipeline_forward_f32``: CQT -> seq_length fill ->
+network) over B = 256 synthetic sine-mix clips that are already resident in HBM (BASELINE.json
+configs[1]).  For N > 1 the driver launches this file under ``torch.distributed.run``; every rank
+owns 256 clips of its own (weak scaling, clips are independent, no data-path collective) and the
+step time is the max over ranks.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line (tier contract):
+  roofline      dominant kernel (the 7x7 circular pitch convolutions, 65 % of the MACs):
+                algorithmic FLOPs of its launches / their hipEvent-measured duration, vs the
+                157.3 TFLOP/s fp32 peak of MI355X.
+  roofline_cqt  the CQT stage against the 8 TB/s HBM peak (1 410 552 algorithmic bytes per clip).
+  cpu_baseline  the CPU oracle (direct-form CQT as BLAS matmuls + the float64 network, the
+                reference's dtype) timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+SR, FRAMES, OCTAVES = 22050, 5, 8
+N_SAMPLES = SR * 15                       # 330 750
+HOP = 4410
+T_FRAMES = 1 + N_SAMPLES // HOP           # 76
+P = 36 * OCTAVES
+# SURVEY.md section 8d / DESIGN.md "Measurement"
+CQT_BYTES_PER_CLIP = N_SAMPLES * 4 + P * T_FRAMES * 4                  # 1 410 552
+P2P_MACS_PER_CLIP = (5 * 8 + 8 * 8 + 8 * 8) * 49 * P * T_FRAMES        # 180 166 656 (three 7x7 convs: 5->8, 8->8, 8->8)
+NET_MACS_PER_CLIP = 277_395_712
+PEAK_FP32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def load_fixture_weights():
+    gold = np.load(os.path.join(REPO, "tests", "golden", "pcnet_default.npz"))
+    return {k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("sd/")}
+
+
+def cpu_baseline(sd, n_clips=24, batch=8):
+    """Oracle ("port") on the host cores: same synthetic clips, CQT then network (float64, the reference dtype)."""
+    from ake_amd import synthetic
+    from oracle import cqt_oracle, pcnet_oracle
+    threads = torch.get_num_threads()
+    audio, _ = synthetic.make_batch(range(n_clips))
+    cqt = cqt_oracle.FastDirectCQT(SR, HOP, dtype=torch.float32)
+    sd64 = pcnet_oracle.to_dtype(sd, torch.float64)
+    seq = torch.full((batch,), T_FRAMES)
+    with torch.no_grad():
+        pcnet_oracle.pcnet_forward(sd64, cqt(audio[:1])[:, None].double(), seq[:1])       # warm-up
+        t0 = time.perf_counter()
+        t_cqt = 0.0
+        for s in range(0, n_clips, batch):
+            c0 = time.perf_counter()
+            mel = cqt(audio[s:s + batch])
+            t_cqt += time.perf_counter() - c0
+            pcnet_oracle.pcnet_forward(sd64, mel[:, None].double(), seq[: mel.shape[0]])
+        dt = time.perf_counter() - t0
+    return {"value": round(n_clips / dt, 2), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"{n_clips} synthetic 15 s clips, batches of {batch}: oracle direct-form CQT (fp32 BLAS matmuls, "
+                      f"{t_cqt / dt:.0%} of the time) + oracle PitchClassNet forward in float64 (reference dtype), "
+                      f"torch CPU ops on {threads} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import ake_amd
+    from ake_amd import distributed as D, synthetic
+
+    rank, world, local_rank = D.init_from_env()
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    sd = load_fixture_weights()
+    net = ake_amd.PitchClassNet(P, 12, 2, 7, Namespace(genre=True))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    est = ake_amd.KeyEstimator(net, SR, FRAMES)
+    B = args.batch
+    lo = rank * B                                                       # each rank synthesises its own clips
+    audio, _ = synthetic.make_batch_device(range(lo, lo + B), dev)
+    assert audio.shape == (B, N_SAMPLES)
+
+    for _ in range(max(args.warmup, 1)):
+        out = est(audio)
+    torch.cuda.synchronize()
+    # timed region: hipEvents (on the launch stream) bracket only the dominant kernel -- 12 launches per step
+    ake_amd._lib.lib().ake_prof_reset()
+    ake_amd._lib.prof_enable("conv_rows_kernel/p2p", True)
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = est(audio)
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = time.perf_counter() - t0
+    prof = ake_amd._lib.prof_results()
+    # second, untimed pass with every kernel bracketed: per-kernel breakdown and the CQT stage's roofline
+    ake_amd._lib.prof_enable("", True)
+    for _ in range(args.steps):
+        est(audio)
+    torch.cuda.synchronize()
+    prof_all = ake_amd._lib.prof_results()
+    ake_amd._lib.prof_enable("", False)
+    dt = D.max_over_ranks(dt, dev)
+
+    # result collection (outside the timed region): 35 floats per clip, rank order
+    rows = D.gather_rows(torch.cat(out, 1), B * world)
+    if rank != 0:
+        return
+    assert rows.shape == (B * world, 35) and bool(torch.isfinite(rows).all())
+
+    clips = B * world * args.steps
+    value = clips / dt
+    p2p_ms, p2p_n = prof.get("conv_rows_kernel/p2p", (0.0, 0))
+    launches_per_step = p2p_n / args.steps if args.steps else 0
+    p2p_flops = 2.0 * P2P_MACS_PER_CLIP * B * args.steps              # all p2p launches of this rank
+    achieved = p2p_flops / (p2p_ms * 1e-3) / 1e12 if p2p_ms > 0 else None
+    cqt_ms = sum(prof_all.get(k, (0.0, 0))[0] for k in ("cqt_decimate_kernel", "cqt_bank_kernel"))
+    cqt_gbs = CQT_BYTES_PER_CLIP * B * args.steps / (cqt_ms * 1e-3) / 1e9 if cqt_ms > 0 else None
+    kernel_ms = {k: round(v[0] / args.steps, 4) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}
+    line = {
+        "metric": "clips/s (15 s @ 22.05 kHz), HIP CQT + PitchClassNet forward",
+        "value": round(value, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: batch={B} synthetic 15 s sine-mix clips per GPU, HIP CQT (288 bins, hop 4410) "
+                               f"+ default PitchClassNet inference (genre head on), audio resident in HBM",
+                   "clips_per_gpu": B, "n_samples": N_SAMPLES, "frames": T_FRAMES, "weights": "tests/golden/pcnet_default.npz (seeded)",
+                   "parallelism": f"clip-sharded x{world}, no data-path collective"},
+        "roofline": {"bound": "mfma", "kernel": "conv_rows_kernel<7,7,8> (pitch conv 7x7 circular, x3 per chunk)",
+                     "achieved": round(achieved, 3) if achieved else None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_FP32_TFLOPS, 4) if achieved else None, "traffic": None,
+                     "avg_launch_ms": round(p2p_ms / p2p_n, 4) if p2p_n else None, "launches_per_step": launches_per_step,
+                     "algorithmic_flops_per_clip": 2 * P2P_MACS_PER_CLIP},
+        "roofline_cqt": {"bound": "hbm", "kernels": "cqt_decimate_kernel x7 + cqt_bank_kernel", "achieved": round(cqt_gbs, 1) if cqt_gbs else None,
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(cqt_gbs / PEAK_HBM_GBS, 4) if cqt_gbs else None,
+                         "traffic": None, "algorithmic_bytes_per_clip": CQT_BYTES_PER_CLIP,
+                         "stage_ms_per_step": round(cqt_ms / args.steps, 4)},
+        "kernel_ms_per_step": kernel_ms,
+        "net_fp32_frac_of_peak": round(2.0 * NET_MACS_PER_CLIP * value / world / (PEAK_FP32_TFLOPS * 1e12), 4),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(sd)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -72,12 +72,13 @@ def test_full_size_batch_properties(plan):
     mag = torch.expm1(out)
     half = torch.expm1(plan.logmag(0.5 * audio))
     assert ((half - 0.5 * mag).abs().max() / mag.max()).item() < 1e-5
-    # delaying a clip by exactly k hops moves its frames by k (interior frames, away from both edges)
+    # delaying a clip by exactly k hops moves its frames by k (interior frames, away from both edges).  Frame t and
+    # frame t+k use different fractional-phase filter banks, so this holds to twice the multirate error, not to rounding.
     k = 3
     shifted = torch.zeros_like(audio)
     shifted[:, k * HOP:] = audio[:, :-k * HOP]
     out_s = plan.logmag(shifted)
-    assert ((out_s[:, :, 12 + k:60] - out[:, :, 12:60 - k]).abs().max() / out.max()).item() < 1e-5
+    assert ((out_s[:, :, 12 + k:60] - out[:, :, 12:60 - k]).abs().max() / out.max()).item() < 2 * TOL
     # batch independence: a clip's rows do not depend on its neighbours
     solo = plan.logmag(audio[17:18])
     assert torch.equal(solo[0], out[17])

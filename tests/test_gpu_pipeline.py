@@ -82,7 +82,7 @@ def test_keydataset_item_contract_and_validate(net):
 
 def test_kernel_timer_reports_the_launched_kernels(net):
     est = ake_amd.KeyEstimator(net, 22050, 5)
-    audio = torch.from_numpy(synthetic.make_batch(range(2), 22050 * 3)[0]).to(DEV)
+    audio = torch.from_numpy(synthetic.make_batch(range(2), 22050 * 6)[0]).to(DEV)
     est(audio)
     ake_amd._lib.prof_enable("", True)
     est(audio)
