@@ -44,7 +44,10 @@ struct HostTensor {
 
 struct PackedConv {          // device-resident folded + packed convolution
     int cin = 0, cout = 0, kh = 0, kw = 0, co = 1, groups = 1;
-    size_t w_off = 0, b_off = 0;   // float offsets into the blob
+    size_t w_off = 0, b_off = 0;   // float offsets into the blob (VALU layout [group][ci][dy][dx][CO])
+    // f32-MFMA fragment layout [ci][dy][s][ntile][64 lanes] (Toeplitz over TB frames), see pcnet_kernels.h
+    int tb = 0, ku = 0, ntiles = 0, nt = 1;
+    size_t f_off = 0;
 };
 
 struct LayerDims {
@@ -150,6 +153,30 @@ PackedConv pack_conv(ake_pcnet* n, const std::vector<double>& w, const std::vect
     p.b_off = blob.size();
     blob.resize(blob.size() + static_cast<size_t>(p.groups) * p.co, 0.f);
     for (int co = 0; co < cout; ++co) blob[p.b_off + co] = static_cast<float>(b[co]);
+    if (kw == 7) {   // MFMA fragments
+        p.tb = cout >= 9 ? 1 : (cout >= 5 ? 2 : (cout >= 2 ? 4 : 16));
+        p.ku = (p.tb + kw - 1 + 3) / 4 * 4;
+        p.ntiles = (cout * p.tb + 15) / 16;
+        p.nt = (p.tb == 1 && p.ntiles % 2 == 0) ? 2 : 1;
+        const int ks = p.ku / 4;
+        blob.resize(ake::align_up(blob.size(), 64));
+        p.f_off = blob.size();
+        const size_t frag = static_cast<size_t>(cin) * kh * ks * p.ntiles * 64;
+        blob.resize(blob.size() + frag + static_cast<size_t>(ks) * p.ntiles * 64, 0.f);   // + one (ci,dy) of zero padding (prefetch)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int dy = 0; dy < kh; ++dy)
+                for (int s = 0; s < ks; ++s)
+                    for (int nt = 0; nt < p.ntiles; ++nt)
+                        for (int l = 0; l < 64; ++l) {
+                            const int u = 4 * s + (l >> 4);
+                            const int nn = nt * 16 + (l & 15);
+                            const int co = nn / p.tb, tau = nn % p.tb;
+                            const int dx = u - tau;
+                            double v = 0.0;
+                            if (co < cout && dx >= 0 && dx < kw) v = w[((static_cast<size_t>(co) * cin + ci) * kh + dy) * kw + dx];
+                            blob[p.f_off + ((((static_cast<size_t>(ci) * kh + dy) * ks + s) * p.ntiles + nt) * 64) + l] = static_cast<float>(v);
+                        }
+    }
     return p;
 }
 
@@ -166,53 +193,59 @@ struct Tile {
     size_t lds;
 };
 
-// Choose (rows, frames) per workgroup for the generic conv under the LDS budget.
-bool choose_tile(bool fullrows, int cin, int H, int KH, int T_out, Tile* t) {
+// Workgroup shape of the MFMA conv: every wave owns MT M-tiles (16 positions each), so a workgroup of W <= 8
+// waves covers up to W*MT*16 positions = R rows x J frame groups; input channels are staged in chunks that fit
+// the LDS budget.  Score = useful tile slots / issued, times the row-tile fill.
+struct MTile { int W, cin_chunk; };
+bool choose_tile(bool fullrows, int cin, int H, int KH, int T_out, int TB, int KU, int MT, Tile* t, MTile* mt_out) {
+    const int cap = 8 * MT * 16;
     const int T4 = (T_out + TW - 1) / TW * TW;
-    int n_tt = 1;
-    for (;; ++n_tt) {
-        int TT = ((T4 / TW + n_tt - 1) / n_tt) * TW;
-        if (TT > 128 && TT > TW) continue;
-        const int Tp = TT + 8;
-        const int strips = TT / TW;
-        if (fullrows) {
-            const size_t lds = static_cast<size_t>(cin) * H * Tp * sizeof(float);
-            if ((lds > kLdsBudget || H * strips > 1024) && TT > TW) continue;
-            if (lds > 160 * 1024) return false;
-            *t = Tile{H, TT, Tp, 1, n_tt, (H * strips + 63) / 64 * 64, lds};
-            return true;
+    double best = -1;
+    Tile bt{};
+    MTile bm{};
+    for (int n_tt = 1; n_tt <= T4 / TW; ++n_tt) {
+        const int TT = ((T4 / TW + n_tt - 1) / n_tt) * TW;
+        const int n_tt_eff = (T_out + TT - 1) / TT;
+        const int J = (TT + TB - 1) / TB;
+        const int Tp = (TB * J - TB + KU + 3) / 4 * 4;
+        for (int R = fullrows ? H : 1; R <= (fullrows ? H : std::min(H, 64)); ++R) {
+            if (R * J > cap) break;
+            const int R_in = fullrows ? H : R + KH - 1;
+            const size_t per_ch = static_cast<size_t>(R_in) * Tp * sizeof(float);
+            if (per_ch > kLdsBudget) break;
+            const int max_chunk = static_cast<int>(std::min<size_t>(cin, std::min<size_t>(kLdsBudget, 48 * 1024) / per_ch));
+            if (max_chunk < 1) continue;
+            const int n_chunks = (cin + max_chunk - 1) / max_chunk;
+            const int chunk = (cin + n_chunks - 1) / n_chunks;           // even split, no 7+1
+            const int tiles = (R * J + 15) / 16;
+            const int W = (tiles + MT - 1) / MT;
+            const int row_tiles = (H + R - 1) / R;
+            // useful positions / issued slots; mild preferences: fewer staged halo bytes, fuller workgroups
+            const double useful = static_cast<double>(H) * T_out / TB;
+            const double issued = static_cast<double>(row_tiles) * n_tt_eff * W * MT * 16;
+            const double halo = static_cast<double>(R) / R_in * TT / (TT + KU);
+            const double eff = useful / issued * (0.85 + 0.15 * halo) * (0.9 + 0.1 * W / 8.0);
+            if (eff > best + 1e-9) {
+                best = eff;
+                bt = Tile{R, TT, Tp, fullrows ? 1 : row_tiles, n_tt_eff, W * 64, per_ch * chunk};
+                bm = MTile{W, chunk};
+            }
         }
-        int bestR = 0;
-        double best = -1;
-        for (int R = 1; R <= std::min(H, 64); ++R) {
-            const size_t lds = static_cast<size_t>(cin) * (R + KH - 1) * Tp * sizeof(float);
-            const int thr = R * strips;
-            if (lds > kLdsBudget || thr > 1024) break;
-            const int padded = (thr + 63) / 64 * 64;
-            const int tiles = (H + R - 1) / R;
-            const double eff = (static_cast<double>(thr) / padded) * (static_cast<double>(R) / (R + KH - 1)) *
-                               (static_cast<double>(H) / (tiles * R));
-            if (eff > best) { best = eff; bestR = R; }
-        }
-        if (bestR == 0) {
-            if (TT > TW) continue;
-            return false;
-        }
-        const int strips_ = TT / TW;
-        *t = Tile{bestR, TT, Tp, (H + bestR - 1) / bestR, n_tt, (bestR * strips_ + 63) / 64 * 64,
-                  static_cast<size_t>(cin) * (bestR + KH - 1) * Tp * sizeof(float)};
-        return true;
     }
+    if (best < 0) return false;
+    *t = bt; *mt_out = bm;
+    return true;
 }
 
 template <int KH, bool FULLROWS>
-int launch_conv_co(int co, const ConvArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-    switch (co) {
-        case 8: hipLaunchKernelGGL((conv_rows_kernel<KH, 7, 8, FULLROWS>), grid, block, lds, s, a); return AKE_OK;
-        case 4: hipLaunchKernelGGL((conv_rows_kernel<KH, 7, 4, FULLROWS>), grid, block, lds, s, a); return AKE_OK;
-        case 1: hipLaunchKernelGGL((conv_rows_kernel<KH, 7, 1, FULLROWS>), grid, block, lds, s, a); return AKE_OK;
-    }
-    ake::set_error("conv: no kernel for CO=%d", co);
+int launch_mfma(const PackedConv& pc, const MfmaArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+#define AKE_MFMA(KU_, NT_) hipLaunchKernelGGL((conv_mfma_kernel<KH, KU_, NT_, 3, FULLROWS>), grid, block, lds, s, a); return AKE_OK
+    if (pc.ku == 8 && pc.nt == 1) { AKE_MFMA(8, 1); }
+    if (pc.ku == 8 && pc.nt == 2) { AKE_MFMA(8, 2); }
+    if (pc.ku == 12 && pc.nt == 1) { AKE_MFMA(12, 1); }
+    if (pc.ku == 24 && pc.nt == 1) { AKE_MFMA(24, 1); }
+#undef AKE_MFMA
+    ake::set_error("conv: no MFMA kernel for KU=%d NT=%d", pc.ku, pc.nt);
     return AKE_ERR_UNSUPPORTED;
 }
 
@@ -245,15 +278,31 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
     a.dst = dst; a.dst_coff = dst_coff; a.dst_clip_stride = static_cast<long long>(dst_ctot) * a.H_out * a.T_out;
     a.lrelu = lrelu ? 1 : 0;
     Tile t;
-    AKE_REQUIRE(choose_tile(fullrows, pc.cin, H, pc.kh, a.T_out, &t), AKE_ERR_UNSUPPORTED,
+    MTile mtile;
+    AKE_REQUIRE(choose_tile(fullrows, pc.cin, H, pc.kh, a.T_out, pc.tb, pc.ku, 3, &t, &mtile), AKE_ERR_UNSUPPORTED,
                 "conv %s: no tile fits LDS (cin=%d H=%d)", name, pc.cin, H);
     a.R = t.R; a.TT = t.TT; a.Tp = t.Tp; a.n_row_tiles = t.n_row_tiles; a.n_time_tiles = t.n_time_tiles;
-    dim3 grid(t.n_row_tiles * t.n_time_tiles, pc.groups, batch), block(t.threads);
+    a.w = n->blob_dev + pc.f_off;
+    MfmaArgs ma;
+    ma.c = a; ma.TB = pc.tb; ma.ntiles_total = pc.ntiles; ma.cin_chunk = mtile.cin_chunk;
+    ma.ksplit = 0;
+    if (mtile.W == 1 && pc.cin >= 8) {      // tiny M (1-channel head convs): split the input channels over 8 waves instead
+        ma.ksplit = 1;
+        mtile.W = 8;
+        t.threads = 8 * 64;
+        t.lds = std::max<size_t>(t.lds, static_cast<size_t>(8) * 3 * pc.nt * 64 * sizeof(float) * 4);
+    }
+    static const bool debug = std::getenv("AKE_DEBUG") != nullptr;
+    if (debug)
+        fprintf(stderr, "[ake] %-28s cin=%3d cout=%3d kh=%2d TB=%2d KU=%2d NT=%d | R=%2d TT=%3d Tp=%3d tiles=%dx%d waves=%d chunk=%d lds=%zu grid=(%d,%d,%d)\n",
+                name, pc.cin, pc.cout, pc.kh, pc.tb, pc.ku, pc.nt, t.R, t.TT, t.Tp, t.n_row_tiles, t.n_time_tiles, mtile.W,
+                mtile.cin_chunk, t.lds, t.n_row_tiles * t.n_time_tiles, pc.ntiles / pc.nt, batch);
+    dim3 grid(t.n_row_tiles * t.n_time_tiles, pc.ntiles / pc.nt, batch), block(t.threads);
     ake::ProfScope ps(name, s);
-    if (kind == 0 && pc.kh == 7) return launch_conv_co<7, false>(pc.co, a, grid, block, t.lds, s);
-    if (kind == 1 && pc.kh == 12) return launch_conv_co<12, true>(pc.co, a, grid, block, t.lds, s);
-    if (kind == 2 && pc.kh == 1) return launch_conv_co<1, true>(pc.co, a, grid, block, t.lds, s);
-    if (kind == 2 && pc.kh == 2) return launch_conv_co<2, true>(pc.co, a, grid, block, t.lds, s);
+    if (kind == 0 && pc.kh == 7) return launch_mfma<7, false>(pc, ma, grid, block, t.lds, s);
+    if (kind == 1 && pc.kh == 12) return launch_mfma<12, true>(pc, ma, grid, block, t.lds, s);
+    if (kind == 2 && pc.kh == 1) return launch_mfma<1, true>(pc, ma, grid, block, t.lds, s);
+    if (kind == 2 && pc.kh == 2) return launch_mfma<2, true>(pc, ma, grid, block, t.lds, s);
     ake::set_error("conv %s: kernel height %d not built", name, pc.kh);
     return AKE_ERR_UNSUPPORTED;
 }
@@ -279,51 +328,51 @@ int run_semi(const ake_pcnet* n, const PackedConv& pc, const float* src, int bat
     return AKE_OK;
 }
 
-struct Buffers {           // workspace carve for one chunk; also the tap table
-    struct Tap { float* p; int64_t shape[4]; };
-    std::map<std::string, Tap> taps;
-    float *fold0 = nullptr, *pcf = nullptr, *hid_k = nullptr, *hid_t = nullptr, *hid_g = nullptr;
-    float *map_k = nullptr, *map_t = nullptr, *map_g = nullptr;
+struct Buffers {           // workspace carve
+    // per chunk (pitch stream): everything up to the last layer's semitone fold
+    float* fold0 = nullptr;
     std::vector<float*> cat, psix, pa, pb, pca, pcb, ppool;
+    // whole batch (pitch-class tail): last layer's concat buffer, its pc stack, pooled features, heads
+    float *pcf = nullptr, *hid_k = nullptr, *hid_t = nullptr, *hid_g = nullptr;
+    float *map_k = nullptr, *map_t = nullptr, *map_g = nullptr;
     std::vector<int> Tl;    // frames at layer i
     int Tf = 0;             // frames after the last layer
     size_t bytes = 0;
 };
 
-int plan_buffers(const ake_pcnet* n, int chunk, int frames, void* ws, Buffers* b) {
+// chunk = clips per pitch-stream pass, batch = clips of the call (tail buffers)
+int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws, Buffers* b) {
     const auto& c = n->cfg;
     const int L = c.num_layers, P = c.pitches;
     ake::Carver cv(ws, 0);
     b->Tl.assign(L, frames);
     for (int i = 2; i < L; ++i) b->Tl[i] = b->Tl[i - 1] / c.time_pool_size;
-    if (L > 1) b->Tl[1] = frames;
     b->Tf = L > 1 ? b->Tl[L - 1] / c.time_pool_size : frames;
     AKE_REQUIRE(b->Tf >= 1, AKE_ERR_INVALID, "pcnet: %d frames vanish under the time pooling", frames);
     b->cat.assign(L + 1, nullptr); b->psix.assign(L, nullptr); b->pa.assign(L, nullptr); b->pb.assign(L, nullptr);
     b->pca.assign(L, nullptr); b->pcb.assign(L, nullptr); b->ppool.assign(L, nullptr);
-    const size_t B = chunk;
+    const size_t C = chunk, B = batch;
     b->fold0 = cv.take<float>(B * 12 * frames);
     for (int i = 0; i < L; ++i) {
         const int Ti = b->Tl[i];
         const auto& d = n->dims[i];
+        const bool last = i == L - 1;
         const int pc_out = i == 0 ? c.n_filters : d.out_pc;
         if (i >= 1) {
-            b->cat[i] = cv.take<float>(B * (d.prev_pc + d.out_p) * 12 * Ti);
-            b->psix[i] = cv.take<float>(B * d.prev_pc * 36 * Ti);
-            b->pa[i] = cv.take<float>(B * d.out_p * P * Ti);
-            b->pb[i] = cv.take<float>(B * d.out_p * P * Ti);
-            if (i + 1 < L) b->ppool[i] = cv.take<float>(B * d.out_p * P * (Ti / c.time_pool_size));
+            b->cat[i] = cv.take<float>((last || i == 1 ? B : C) * (d.prev_pc + d.out_p) * 12 * Ti);
+            b->psix[i] = cv.take<float>((i == 1 ? B : C) * d.prev_pc * 36 * Ti);
+            b->pa[i] = cv.take<float>(C * d.out_p * P * Ti);
+            b->pb[i] = cv.take<float>(C * d.out_p * P * Ti);
+            if (!last) b->ppool[i] = cv.take<float>(C * d.out_p * P * (Ti / c.time_pool_size));
         }
-        b->pca[i] = cv.take<float>(B * pc_out * 12 * Ti);
-        b->pcb[i] = cv.take<float>(B * pc_out * 12 * Ti);
+        b->pca[i] = cv.take<float>((last || i == 0 ? B : C) * pc_out * 12 * Ti);
+        b->pcb[i] = cv.take<float>((last || i == 0 ? B : C) * pc_out * 12 * Ti);
     }
     b->pcf = cv.take<float>(B * n->final_ch * 12 * b->Tf);
-    const int k = c.kernel_size;
     const size_t hid = B * 2 * n->final_ch * 12 * b->Tf;
     b->hid_k = cv.take<float>(2 * hid); b->hid_t = cv.take<float>(2 * hid);
     b->map_k = cv.take<float>(B * 12 * b->Tf); b->map_t = cv.take<float>(B * 12 * b->Tf);
     if (c.genre) { b->hid_g = cv.take<float>(2 * hid); b->map_g = cv.take<float>(B * 12 * b->Tf); }
-    (void)k;
     b->bytes = ake::align_up(cv.off, 256);
     return AKE_OK;
 }
@@ -514,116 +563,150 @@ int ake_pcnet_finalize(ake_pcnet* n) {
 size_t ake_pcnet_workspace_bytes(const ake_pcnet* n, int batch, int frames) {
     if (!n || batch <= 0 || frames <= 0) return 0;
     Buffers b;
-    if (plan_buffers(n, std::min(batch, n->chunk_clips), frames, nullptr, &b) != AKE_OK) return 0;
+    if (plan_buffers(n, batch, std::min(batch, n->chunk_clips), frames, nullptr, &b) != AKE_OK) return 0;
     return b.bytes;
 }
 
-static int forward_chunk(const ake_pcnet* n, Buffers& b, const float* mel, int clip0, int B, int frames,
-                         const int64_t* seq, float* key_out, float* tonic_out, float* genre_out, hipStream_t s) {
+// Phase A, whole batch: layer 0 (semitone conv + octave fold + pc2pc, models.py:361-369) and layer 1's up_sixth
+// (models.py:372-374).  These are pitch-class sized (12 or 36 rows), so they are launched once for all clips.
+static int forward_entry(const ake_pcnet* n, Buffers& b, const float* mel, int B, hipStream_t s) {
+    const auto& c = n->cfg;
+    const int L = c.num_layers, P = c.pitches;
+    const int T0 = b.Tl[0];
+    int rc;
+    if ((rc = run_semi(n, n->semi[0], mel, B, P, T0, b.fold0, 1, 0, s, "semi_fold_kernel/L0"))) return rc;
+    if (L == 1) return AKE_OK;                               // its pc2pc runs in the tail
+    const LayerDims& d1 = n->dims[1];
+    const int ctot1 = d1.prev_pc + d1.out_p;
+    const float* src = b.fold0;
+    int cin = 1;
+    for (int j = 0; j < c.conv_layers; ++j) {
+        const bool lastj = j == c.conv_layers - 1;           // the last conv writes channels [0, nf) of layer 1's concat buffer
+        float* dst = lastj ? b.cat[1] : ((j & 1) ? b.pcb[0] : b.pca[0]);
+        if ((rc = run_conv(n, n->pc2pc[0][j], 1, Src{src, cin, nullptr, 0, 0}, B, 12, T0, true, true, dst,
+                           lastj ? ctot1 : c.n_filters, 0, s, "conv_mfma_kernel/pc2pc0")))
+            return rc;
+        src = dst; cin = c.n_filters;
+    }
+    const long long total = static_cast<long long>(B) * d1.prev_pc * 36 * T0;
+    ake::ProfScope ps("up_sixth_kernel", s);
+    hipLaunchKernelGGL(up_sixth_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.cat[1],
+                       static_cast<long long>(ctot1) * 12 * T0, n->blob_dev + n->up[1].w_off, n->blob_dev + n->up[1].b_off,
+                       b.psix[1], d1.prev_pc, T0, total);
+    return AKE_OK;
+}
+
+// Phase B, per chunk of clips [c0, c0+B): the pitch stream -- pitch convs -> semitone fold for every layer >= 1
+// (plus pc2pc / pooling / the next up_sixth for the inner layers of deeper nets).  Leaves the last layer's concat
+// buffer filled for these clips.
+static int forward_pitch_chunk(const ake_pcnet* n, Buffers& b, const float* mel, int c0, int B, hipStream_t s) {
     const auto& c = n->cfg;
     const int L = c.num_layers, P = c.pitches, tp = c.time_pool_size;
     int rc;
-    const float* p_cur = mel;     // pitch stream: [B][cp][P][Tcur]
+    const float* p_cur = mel;     // pitch stream [B][cp][P][T]
     int cp = 1;
-    float* pc_cur = nullptr;      // pitch-class stream
-    int cpc = 0;
-    for (int i = 0; i < L; ++i) {
+    const float* pc_cur = nullptr;   // pitch-class stream of the previous layer (first channels of cat[i])
+    for (int i = 1; i < L; ++i) {
         const int Ti = b.Tl[i];
         const LayerDims& d = n->dims[i];
-        if (i == 0) {
-            // models.py:361-369  pool_semi -> fold -> pc2pc
-            if ((rc = run_semi(n, n->semi[0], mel, B, P, Ti, b.fold0, 1, 0, s, "semi_fold_kernel/L0"))) return rc;
-            const float* src = b.fold0;
-            int cin = 1;
-            for (int j = 0; j < c.conv_layers; ++j) {
-                const bool last = j == c.conv_layers - 1;
-                float* dst; int ctot, coff = 0;
-                if (last && L > 1) { dst = b.cat[1]; ctot = n->dims[1].prev_pc + n->dims[1].out_p; }
-                else { dst = (j & 1) ? b.pcb[0] : b.pca[0]; ctot = c.n_filters; }
-                if ((rc = run_conv(n, n->pc2pc[0][j], 1, Src{src, cin, nullptr, 0, 0}, B, 12, Ti, true, true, dst, ctot, coff, s,
-                                   "conv_rows_kernel/pc2pc0")))
-                    return rc;
-                src = dst; cin = c.n_filters;
-                if (last) { pc_cur = dst; cpc = c.n_filters; }
-            }
-            if (L > 1) {
-                // pc_cur lives in cat[1] channels [0, nf); layer 1 reads it through the concat buffer
-            }
-        } else {
-            const int ctot = d.prev_pc + d.out_p;
-            // models.py:372-374  up_sixth (+BN+LReLU).  Input = first prev_pc channels of cat[i].
-            {
-                const long long total = static_cast<long long>(B) * d.prev_pc * 36 * Ti;
-                // the pitch-class features are the first prev_pc channels of this layer's concat buffer
-                ake::ProfScope ps("up_sixth_kernel", s);
-                hipLaunchKernelGGL(up_sixth_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, pc_cur,
-                                   static_cast<long long>(ctot) * 12 * Ti, n->blob_dev + n->up[i].w_off,
-                                   n->blob_dev + n->up[i].b_off, b.psix[i], d.prev_pc, Ti, total);
-            }
-            // models.py:378-384  repeat + concat (never materialised) + pitch convs
-            const float* src = p_cur;
-            Src sdesc{src, cp, b.psix[i], d.prev_pc, 36};
-            float* out = nullptr;
-            for (int j = 0; j < c.conv_layers; ++j) {
-                out = (j & 1) ? b.pb[i] : b.pa[i];
-                if ((rc = run_conv(n, n->p2p[i][j], 0, sdesc, B, P, Ti, true, true, out, d.out_p, 0, s, "conv_rows_kernel/p2p")))
-                    return rc;
-                sdesc = Src{out, d.out_p, nullptr, 0, 0};
-            }
-            // models.py:386-392  pool_semi -> fold, written next to pc in the concat buffer
-            if ((rc = run_semi(n, n->semi[i], out, B, P, Ti, b.cat[i], ctot, d.prev_pc, s, "semi_fold_kernel/L1+"))) return rc;
-            // models.py:393  pc2pc
-            const float* psrc = b.cat[i];
-            int cin = ctot;
-            float* pdst = nullptr;
-            for (int j = 0; j < c.conv_layers; ++j) {
-                pdst = (j & 1) ? b.pcb[i] : b.pca[i];
-                if ((rc = run_conv(n, n->pc2pc[i][j], 1, Src{psrc, cin, nullptr, 0, 0}, B, 12, Ti, true, true, pdst, d.out_pc, 0, s,
-                                   "conv_rows_kernel/pc2pc")))
-                    return rc;
-                psrc = pdst; cin = d.out_pc;
-            }
-            // models.py:395-396  time pooling (the pitch stream of the last layer feeds nothing: skipped)
-            const bool last_layer = i == L - 1;
-            {
-                float* dstp = last_layer ? b.pcf : b.cat[i + 1];
-                const int dct = last_layer ? d.out_pc : n->dims[i + 1].prev_pc + n->dims[i + 1].out_p;
-                const long long total = static_cast<long long>(B) * d.out_pc * 12 * (Ti / tp);
-                ake::ProfScope ps("time_pool_kernel", s);
-                hipLaunchKernelGGL(time_pool_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, pdst, dstp,
-                                   d.out_pc, 12, Ti, tp, dct, 0, total);
-                pc_cur = dstp; cpc = d.out_pc;
-            }
-            if (!last_layer) {
-                const long long total = static_cast<long long>(B) * d.out_p * P * (Ti / tp);
-                ake::ProfScope ps("time_pool_kernel", s);
-                hipLaunchKernelGGL(time_pool_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, out, b.ppool[i],
-                                   d.out_p, P, Ti, tp, d.out_p, 0, total);
-                p_cur = b.ppool[i]; cp = d.out_p;
-            }
+        const bool last = i == L - 1;
+        const int ctot = d.prev_pc + d.out_p;
+        float* cat = b.cat[i] + (last || i == 1 ? static_cast<size_t>(c0) * ctot * 12 * Ti : 0);
+        float* psix = b.psix[i] + (i == 1 ? static_cast<size_t>(c0) * d.prev_pc * 36 * Ti : 0);
+        if (i > 1) {   // models.py:372-374  up_sixth (+BN+LReLU); layer 1's ran batch-wide in forward_entry
+            const long long total = static_cast<long long>(B) * d.prev_pc * 36 * Ti;
+            ake::ProfScope ps("up_sixth_kernel", s);
+            hipLaunchKernelGGL(up_sixth_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, pc_cur,
+                               static_cast<long long>(ctot) * 12 * Ti, n->blob_dev + n->up[i].w_off,
+                               n->blob_dev + n->up[i].b_off, psix, d.prev_pc, Ti, total);
         }
+        // models.py:378-384  repeat + concat (never materialised) + pitch convs
+        Src sdesc{p_cur, cp, psix, d.prev_pc, 36};
+        float* out = nullptr;
+        for (int j = 0; j < c.conv_layers; ++j) {
+            out = (j & 1) ? b.pb[i] : b.pa[i];
+            if ((rc = run_conv(n, n->p2p[i][j], 0, sdesc, B, P, Ti, true, true, out, d.out_p, 0, s, "conv_mfma_kernel/p2p"))) return rc;
+            sdesc = Src{out, d.out_p, nullptr, 0, 0};
+        }
+        // models.py:386-392  pool_semi -> fold, written next to pc in the concat buffer
+        if ((rc = run_semi(n, n->semi[i], out, B, P, Ti, cat, ctot, d.prev_pc, s, "semi_fold_kernel/L1+"))) return rc;
+        if (last) return AKE_OK;                             // pc2pc + pooling + heads run batch-wide
+        // inner layers of deeper nets: pc2pc, then both time pools (models.py:393-396)
+        const float* psrc = cat;
+        int cin = ctot;
+        float* pdst = nullptr;
+        for (int j = 0; j < c.conv_layers; ++j) {
+            pdst = (j & 1) ? b.pcb[i] : b.pca[i];
+            if ((rc = run_conv(n, n->pc2pc[i][j], 1, Src{psrc, cin, nullptr, 0, 0}, B, 12, Ti, true, true, pdst, d.out_pc, 0, s,
+                               "conv_mfma_kernel/pc2pc")))
+                return rc;
+            psrc = pdst; cin = d.out_pc;
+        }
+        const LayerDims& dn = n->dims[i + 1];
+        const int ctn = dn.prev_pc + dn.out_p;
+        const int Tn = Ti / tp;
+        float* catn = b.cat[i + 1] + (i + 1 == L - 1 ? static_cast<size_t>(c0) * ctn * 12 * Tn : 0);   // (i+1 >= 2 here)
+        {
+            const long long total = static_cast<long long>(B) * d.out_pc * 12 * Tn;
+            ake::ProfScope ps("time_pool_kernel", s);
+            hipLaunchKernelGGL(time_pool_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, pdst, catn,
+                               d.out_pc, 12, Ti, tp, ctn, 0, total);
+        }
+        {
+            const long long total = static_cast<long long>(B) * d.out_p * P * Tn;
+            ake::ProfScope ps("time_pool_kernel", s);
+            hipLaunchKernelGGL(time_pool_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, out, b.ppool[i],
+                               d.out_p, P, Ti, tp, d.out_p, 0, total);
+        }
+        pc_cur = catn; p_cur = b.ppool[i]; cp = d.out_p;
     }
-    if (L == 1) {   // single layer: no pooling, features are the layer-0 pc stack output
-        AKE_HIP_CHECK(hipMemcpyAsync(b.pcf, pc_cur, sizeof(float) * B * cpc * 12 * b.Tf, hipMemcpyDeviceToDevice, s));
+    return AKE_OK;
+}
+
+// Pitch-class tail over the whole batch: last layer's pc2pc, time pool, heads, masked mean.
+static int forward_tail(const ake_pcnet* n, Buffers& b, int B, const int64_t* seq, float* key_out, float* tonic_out,
+                        float* genre_out, hipStream_t s) {
+    const auto& c = n->cfg;
+    const int L = c.num_layers, tp = c.time_pool_size;
+    const int i = L - 1;
+    const int Ti = b.Tl[i];
+    const LayerDims& d = n->dims[i];
+    int rc;
+    const float* psrc = L == 1 ? b.fold0 : b.cat[i];
+    int cin = L == 1 ? 1 : d.prev_pc + d.out_p;
+    const int cout = L == 1 ? c.n_filters : d.out_pc;
+    float* pdst = nullptr;
+    for (int j = 0; j < c.conv_layers; ++j) {
+        const bool lastj = j == c.conv_layers - 1;
+        pdst = (L == 1 && lastj) ? b.pcf : ((j & 1) ? b.pcb[i] : b.pca[i]);
+        if ((rc = run_conv(n, n->pc2pc[i][j], 1, Src{psrc, cin, nullptr, 0, 0}, B, 12, Ti, true, true, pdst, cout, 0, s,
+                           L == 1 ? "conv_mfma_kernel/pc2pc0" : "conv_mfma_kernel/pc2pc")))
+            return rc;
+        psrc = pdst; cin = cout;
+    }
+    if (L > 1) {   // models.py:396  time pooling of the pitch-class stream (the pitch stream of the last layer feeds nothing)
+        const long long total = static_cast<long long>(B) * cout * 12 * (Ti / tp);
+        ake::ProfScope ps("time_pool_kernel", s);
+        hipLaunchKernelGGL(time_pool_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, pdst, b.pcf, cout, 12,
+                           Ti, tp, cout, 0, total);
     }
     // ---- heads (models.py:750-753) ----
     const int Tf = b.Tf;
-    struct HeadRun { const std::vector<PackedConv>* convs; float* hid; float* map; int kind; int rows; };
-    HeadRun heads[3] = {{&n->head_key, b.hid_k, b.map_k, 1, 12}, {&n->head_tonic, b.hid_t, b.map_t, 1, 12},
-                        {&n->head_genre, b.hid_g, b.map_g, 2, 11}};
+    struct HeadRun { const std::vector<PackedConv>* convs; float* hid; float* map; int kind; };
+    HeadRun heads[3] = {{&n->head_key, b.hid_k, b.map_k, 1}, {&n->head_tonic, b.hid_t, b.map_t, 1}, {&n->head_genre, b.hid_g, b.map_g, 2}};
     int Tm = Tf;
     for (int h = 0; h < (c.genre ? 3 : 2); ++h) {
         const float* src = b.pcf;
-        int cin = n->final_ch, Tcur = Tf;
+        int hc = n->final_ch, Tcur = Tf;
         const size_t hid_half = static_cast<size_t>(B) * 2 * n->final_ch * 12 * Tf;
         for (int j = 0; j < c.head_layers; ++j) {
             const PackedConv& pcv = (*heads[h].convs)[j];
-            const bool last = j == c.head_layers - 1;
-            float* dst = last ? heads[h].map : heads[h].hid + (j & 1) * hid_half;
-            if ((rc = run_conv(n, pcv, heads[h].kind, Src{src, cin, nullptr, 0, 0}, B, 12, Tcur, false, !last, dst, pcv.cout, 0, s,
-                               h == 2 ? "conv_rows_kernel/genre_head" : "conv_rows_kernel/head")))
+            const bool lastj = j == c.head_layers - 1;
+            float* dst = lastj ? heads[h].map : heads[h].hid + (j & 1) * hid_half;
+            if ((rc = run_conv(n, pcv, heads[h].kind, Src{src, hc, nullptr, 0, 0}, B, 12, Tcur, false, !lastj, dst, pcv.cout, 0, s,
+                               h == 2 ? "conv_mfma_kernel/genre_head" : "conv_mfma_kernel/head")))
                 return rc;
-            src = dst; cin = pcv.cout; Tcur -= c.kernel_size - 1;
+            src = dst; hc = pcv.cout; Tcur -= c.kernel_size - 1;
         }
         Tm = Tcur;
     }
@@ -635,7 +718,7 @@ static int forward_chunk(const ake_pcnet* n, Buffers& b, const float* mel, int c
     pa.rows[0] = 12; pa.rows[1] = 12; pa.rows[2] = 11;
     pa.Tm = Tm; pa.seq = reinterpret_cast<const long long*>(seq);
     pa.n_pool_layers = L - 1; pa.tp = tp; pa.shrink = (c.kernel_size - 1) * c.head_layers;
-    pa.max_pool = c.max_pool; pa.batch = B; pa.clip0 = clip0;
+    pa.max_pool = c.max_pool; pa.batch = B; pa.clip0 = 0;
     {
         ake::ProfScope ps("head_pool_kernel", s);
         hipLaunchKernelGGL(head_pool_kernel, dim3((B * 12 + 63) / 64, 3), dim3(64), 0, s, pa);
@@ -653,18 +736,17 @@ int ake_pcnet_forward_f32(const ake_pcnet* n, const float* mel, int batch, int f
     AKE_REQUIRE(!n->cfg.genre || genre_out, AKE_ERR_INVALID, "pcnet: genre head enabled but genre_out is null");
     const int chunk = std::min(batch, n->chunk_clips);
     Buffers b;
-    int rc = plan_buffers(n, chunk, frames, workspace, &b);
+    int rc = plan_buffers(n, batch, chunk, frames, workspace, &b);
     if (rc) return rc;
     AKE_REQUIRE(workspace && ws_bytes >= b.bytes, AKE_ERR_WORKSPACE, "pcnet: workspace %zu < %zu bytes", ws_bytes, b.bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    for (int c0 = 0; c0 < batch; c0 += chunk) {
+    if ((rc = forward_entry(n, b, mel, batch, s))) return rc;
+    for (int c0 = 0; c0 < batch && n->cfg.num_layers > 1; c0 += chunk) {
         const int B = std::min(chunk, batch - c0);
-        rc = forward_chunk(n, b, mel + static_cast<size_t>(c0) * n->cfg.pitches * frames, c0, B, frames,
-                           seq_length ? seq_length + c0 : nullptr, key_out + static_cast<size_t>(c0) * 12,
-                           tonic_out + static_cast<size_t>(c0) * 12, genre_out ? genre_out + static_cast<size_t>(c0) * 11 : nullptr, s);
+        rc = forward_pitch_chunk(n, b, mel + static_cast<size_t>(c0) * n->cfg.pitches * frames, c0, B, s);
         if (rc) return rc;
     }
-    return AKE_OK;
+    return forward_tail(n, b, batch, seq_length, key_out, tonic_out, genre_out, s);
 }
 
 // ---- debug taps ---------------------------------------------------------------------------
@@ -672,7 +754,7 @@ static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frame
     AKE_REQUIRE(n && name, AKE_ERR_INVALID, "tap: null argument");
     AKE_REQUIRE(batch <= n->chunk_clips, AKE_ERR_INVALID, "tap: batch %d exceeds the chunk size %d", batch, n->chunk_clips);
     Buffers b;
-    int rc = plan_buffers(n, batch, frames, const_cast<void*>(ws), &b);
+    int rc = plan_buffers(n, batch, batch, frames, const_cast<void*>(ws), &b);
     if (rc) return rc;
     const auto& c = n->cfg;
     const int L = c.num_layers, P = c.pitches;

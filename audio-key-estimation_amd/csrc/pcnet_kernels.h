@@ -334,4 +334,206 @@ __global__ void head_pool_kernel(PoolHeadArgs a) {
     a.outs[which][i] = v;
 }
 
+
+// ==========================================================================================
+// f32-MFMA implicit-GEMM form of the same "rows circular, time local" convolution.
+//
+//   D[m][n] = sum_k A[m][k] * B[k][n]          v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fmaf chain)
+//
+//   m = output position (row y, frame group j)         16 positions per MFMA tile
+//   n = (output channel co, frame offset tau < TB)     N' = Cout*TB columns, 16 per N-tile
+//   k = (ci, dy, u < KU)                               A[m][k] = in[ci][y+dy-py][TB*j + u - pad]
+//   B[k][n] = w[co][ci][dy][u - tau]  if 0 <= u - tau < 7 else 0      (Toeplitz in time)
+//
+// The Toeplitz expansion lets narrow layers fill the 16-wide N dimension: the 7x7 pitch conv has only
+// 8 output channels, so TB = 2 gives 8 x 2 = 16 columns and KU = 8 taps per (ci,dy) -- 7/8 of every MFMA is
+// useful work and nothing is padded.  TB = 1 for 16/32 channels, 4 for 4, 16 for the 1-channel head convs.
+//
+// A comes from the same LDS patch as the VALU kernel (one f32 per lane per MFMA: lane (r,q) reads
+// patch[row_m + dy][TB*j_m + 4*s + q], conflict-free), B is pre-packed on the host in fragment order
+// [ci][dy][s][ntile][lane] and streamed from L2 with coalesced 256-byte loads, one k-step ahead.
+// ==========================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MfmaArgs {
+    ConvArgs c;           // geometry, sources, destination (c.w = packed B fragments, c.bias = per-channel bias)
+    int TB;               // frames per column group
+    int ntiles_total;     // N-tiles of the whole layer (fragment stride)
+    int cin_chunk;        // input channels staged in LDS at a time
+    int ksplit;           // 1: the layer has <= MT M-tiles per workgroup (1-channel head convs): all waves share them and
+                          //    split the input channels (ci = wave, wave + W, ...); partial sums are reduced through LDS
+};
+
+template <int KH, int KU, int NT, int MT, bool FULLROWS>
+__global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ConvArgs& a = ma.c;
+    const int TB = ma.TB;
+    const int cin = a.c0 + a.c1;
+    const int tile = blockIdx.x;
+    const int row_tile = tile / a.n_time_tiles;
+    const int time_tile = tile - row_tile * a.n_time_tiles;
+    const int ngrp = blockIdx.y;                 // group of NT N-tiles
+    const int clip = blockIdx.z;
+    const int y0 = FULLROWS ? 0 : row_tile * a.R;
+    const int t0 = time_tile * a.TT;
+    const int R_in = FULLROWS ? a.H : a.R + KH - 1;
+    const int Tp = a.Tp;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int rows_here = FULLROWS ? a.H : (a.H - y0 < a.R ? a.H - y0 : a.R);
+    const int tt_here = a.T_out - t0 < a.TT ? a.T_out - t0 : a.TT;   // frames of this time tile
+    const int J = (tt_here + TB - 1) / TB;                             // frame groups per row
+    const int Mblk = rows_here * J;
+    const int mtiles = (Mblk + 15) / 16;
+    const int nw = blockDim.x >> 6;
+    const int grp = ma.ksplit ? 0 : wave;                              // M-tile group of this wave
+    const bool active = grp * MT < mtiles;
+    const int cstride = R_in * Tp;
+    const int wrap_at = a.H * Tp;
+    constexpr int KS = KU / 4;                                          // k-steps per (ci,dy)
+
+    int rstart[MT], tcol[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = (grp * MT + mt) * 16 + r16;
+        if (m >= Mblk) m = Mblk - 1;
+        const int r = m / J, j = m - r * J;
+        rstart[mt] = (FULLROWS ? wrap(r - a.py, a.H) : r) * Tp;
+        tcol[mt] = TB * j + q;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // B fragments: [ci][dy][s][ntile][64 lanes]; fetched one (ci,dy) ahead
+    const float* __restrict__ bbase = a.w + (static_cast<long long>(ngrp) * NT) * 64 + lane;
+    const long long bstep = static_cast<long long>(ma.ntiles_total) * 64;   // floats per k-step
+    const long long bci = static_cast<long long>(KH) * KS * bstep;           // floats per input channel
+    const int cstep = ma.ksplit ? nw : 1;
+    int ci = ma.ksplit ? wave : 0;
+    float bcur[KS][NT];
+    {
+        const float* bp = bbase + (ci < cin ? ci : 0) * bci;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bcur[s][nt] = bp[s * bstep + nt * 64];
+    }
+
+    const float* s0 = a.src0 + clip * a.src0_clip_stride;
+    const float* s1 = a.src1 ? a.src1 + clip * a.src1_clip_stride : nullptr;
+    for (int c_lo = 0; c_lo < cin; c_lo += ma.cin_chunk) {
+        const int cc = cin - c_lo < ma.cin_chunk ? cin - c_lo : ma.cin_chunk;
+        if (c_lo) __syncthreads();
+        // ---- stage channels [c_lo, c_lo+cc): rows and frames with both halos resolved.  One wave per patch row:
+        //      the row arithmetic is wave-uniform (SALU), lanes walk consecutive frames (coalesced), no div/mod per element.
+        {
+            const int nrows = cc * R_in;
+            for (int rr = __builtin_amdgcn_readfirstlane(wave); rr < nrows; rr += nw) {
+                const int cl = rr / R_in;
+                const int rj = rr - cl * R_in;
+                const int cs = c_lo + cl;
+                const int row = FULLROWS ? rj : wrap(y0 - a.py + rj, a.H);
+                const float* srow = cs < a.c0 ? s0 + (static_cast<long long>(cs) * a.H + row) * a.T_in
+                                              : s1 + (static_cast<long long>(cs - a.c0) * a.h1 + (row % a.h1)) * a.T_in;
+                float* drow = lds + rr * Tp;
+                for (int tj = lane; tj < Tp; tj += 64) {
+                    int ti = t0 - a.pad_l + tj;
+                    float v = 0.f;
+                    if (a.time_circ) {
+                        while (ti < 0) ti += a.T_in;
+                        while (ti >= a.T_in) ti -= a.T_in;
+                        v = srow[ti];
+                    } else if (ti >= 0 && ti < a.T_in) {
+                        v = srow[ti];
+                    }
+                    drow[tj] = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (!active) continue;
+        for (; ci < c_lo + cc; ci += cstep) {
+            const int cl = ci - c_lo;
+            const int nci = ci + cstep < cin ? ci + cstep : ci;          // channel whose first fragments are prefetched last
+            const float* bp = bbase + ci * bci;
+            int roff[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) roff[mt] = rstart[mt] + cl * cstride;
+            for (int dy = 0; dy < KH; ++dy) {
+                const float* bn = dy + 1 < KH ? bp + (dy + 1) * KS * bstep : bbase + nci * bci;
+                float bnext[KS][NT];
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bnext[s][nt] = bn[s * bstep + nt * 64];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    float av[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) av[mt] = lds[roff[mt] + tcol[mt] + 4 * s];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bcur[s][nt], acc[mt][nt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bcur[s][nt] = bnext[s][nt];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    roff[mt] += Tp;
+                    if (FULLROWS && roff[mt] - cl * cstride == wrap_at) roff[mt] -= wrap_at;
+                }
+            }
+        }
+    }
+    if (ma.ksplit) {   // sum the waves' partial accumulators through LDS (the patch is dead now); wave 0 stores
+        __syncthreads();
+        f32x4* red = reinterpret_cast<f32x4*>(lds);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) red[((wave * MT + mt) * NT + nt) * 64 + lane] = acc[mt][nt];
+        __syncthreads();
+        if (wave != 0) return;
+        for (int w = 1; w < nw; ++w)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] += red[((w * MT + mt) * NT + nt) * 64 + lane];
+    }
+    if (!active) return;
+
+    // ---- epilogue: D[row = 4*(lane>>4) + reg][col = lane&15]; bias (BN folded), LeakyReLU ----
+    float* d = a.dst + clip * a.dst_clip_stride;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = (ngrp * NT + nt) * 16 + r16;
+        const int co = n / TB, tau = n - co * TB;
+        if (co >= a.cout) continue;
+        const float b = a.bias[co];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int m = (grp * MT + mt) * 16 + 4 * q + reg;
+                if (m >= Mblk) continue;
+                const int r = m / J, j = m - r * J;
+                const int y = y0 + r, t = t0 + TB * j + tau;
+                if (y >= a.H_out || TB * j + tau >= tt_here) continue;
+                float v = acc[mt][nt][reg] + b;
+                if (a.lrelu) v = v > 0.f ? v : v * kSlope;
+                d[(static_cast<long long>(a.dst_coff + co) * a.H_out + y) * a.T_out + t] = v;
+            }
+    }
+}
+
 }  // namespace ake_k

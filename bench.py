@@ -109,7 +109,7 @@ def main():
     torch.cuda.synchronize()
     # timed region: hipEvents (on the launch stream) bracket only the dominant kernel -- 12 launches per step
     ake_amd._lib.lib().ake_prof_reset()
-    ake_amd._lib.prof_enable("conv_rows_kernel/p2p", True)
+    ake_amd._lib.prof_enable("conv_mfma_kernel/p2p", True)
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -136,7 +136,7 @@ def main():
 
     clips = B * world * args.steps
     value = clips / dt
-    p2p_ms, p2p_n = prof.get("conv_rows_kernel/p2p", (0.0, 0))
+    p2p_ms, p2p_n = prof.get("conv_mfma_kernel/p2p", (0.0, 0))
     launches_per_step = p2p_n / args.steps if args.steps else 0
     p2p_flops = 2.0 * P2P_MACS_PER_CLIP * B * args.steps              # all p2p launches of this rank
     achieved = p2p_flops / (p2p_ms * 1e-3) / 1e12 if p2p_ms > 0 else None
@@ -152,7 +152,7 @@ def main():
                                f"+ default PitchClassNet inference (genre head on), audio resident in HBM",
                    "clips_per_gpu": B, "n_samples": N_SAMPLES, "frames": T_FRAMES, "weights": "tests/golden/pcnet_default.npz (seeded)",
                    "parallelism": f"clip-sharded x{world}, no data-path collective"},
-        "roofline": {"bound": "mfma", "kernel": "conv_rows_kernel<7,7,8> (pitch conv 7x7 circular, x3 per chunk)",
+        "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel<7,8,1,3> (pitch conv 7x7 circular as f32-MFMA implicit GEMM, x3 per chunk)",
                      "achieved": round(achieved, 3) if achieved else None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_FP32_TFLOPS, 4) if achieved else None, "traffic": None,
                      "avg_launch_ms": round(p2p_ms / p2p_n, 4) if p2p_n else None, "launches_per_step": launches_per_step,
