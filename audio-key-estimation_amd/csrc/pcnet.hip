@@ -197,7 +197,7 @@ struct Tile {
 // waves covers up to W*MT*16 positions = R rows x J frame groups; input channels are staged in chunks that fit
 // the LDS budget.  Score = useful tile slots / issued, times the row-tile fill.
 struct MTile { int W, cin_chunk; };
-bool choose_tile(bool fullrows, int cin, int H, int KH, int T_out, int TB, int KU, int MT, Tile* t, MTile* mt_out) {
+bool choose_tile(bool fullrows, int cin, int H, int KH, int T_out, int TB, int KU, int NT, int MT, Tile* t, MTile* mt_out) {
     const int cap = 8 * MT * 16;
     const int T4 = (T_out + TW - 1) / TW * TW;
     double best = -1;
@@ -210,8 +210,8 @@ bool choose_tile(bool fullrows, int cin, int H, int KH, int T_out, int TB, int K
         const int Tp = (TB * J - TB + KU + 3) / 4 * 4;
         for (int R = fullrows ? H : 1; R <= (fullrows ? H : std::min(H, 64)); ++R) {
             if (R * J > cap) break;
-            const int R_in = fullrows ? H : R + KH - 1;
-            const size_t per_ch = static_cast<size_t>(R_in) * Tp * sizeof(float);
+            const int R_in = R + KH - 1;                                 // the row halo is always materialised
+            const size_t per_ch = (static_cast<size_t>(R_in) * Tp + static_cast<size_t>(KH) * (KU / 4) * NT * 64) * sizeof(float);   // A rows + B fragments
             if (per_ch > kLdsBudget) break;
             const int max_chunk = static_cast<int>(std::min<size_t>(cin, std::min<size_t>(kLdsBudget, 48 * 1024) / per_ch));
             if (max_chunk < 1) continue;
@@ -237,9 +237,8 @@ bool choose_tile(bool fullrows, int cin, int H, int KH, int T_out, int TB, int K
     return true;
 }
 
-template <int KH, bool FULLROWS>
 int launch_mfma(const PackedConv& pc, const MfmaArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-#define AKE_MFMA(KU_, NT_) hipLaunchKernelGGL((conv_mfma_kernel<KH, KU_, NT_, 3, FULLROWS>), grid, block, lds, s, a); return AKE_OK
+#define AKE_MFMA(KU_, NT_) hipLaunchKernelGGL((conv_mfma_kernel<KU_, NT_, 3>), grid, block, lds, s, a); return AKE_OK
     if (pc.ku == 8 && pc.nt == 1) { AKE_MFMA(8, 1); }
     if (pc.ku == 8 && pc.nt == 2) { AKE_MFMA(8, 2); }
     if (pc.ku == 12 && pc.nt == 1) { AKE_MFMA(12, 1); }
@@ -279,13 +278,16 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
     a.lrelu = lrelu ? 1 : 0;
     Tile t;
     MTile mtile;
-    AKE_REQUIRE(choose_tile(fullrows, pc.cin, H, pc.kh, a.T_out, pc.tb, pc.ku, 3, &t, &mtile), AKE_ERR_UNSUPPORTED,
+    AKE_REQUIRE(choose_tile(fullrows, pc.cin, H, pc.kh, a.T_out, pc.tb, pc.ku, pc.nt, 3, &t, &mtile), AKE_ERR_UNSUPPORTED,
                 "conv %s: no tile fits LDS (cin=%d H=%d)", name, pc.cin, H);
     a.R = t.R; a.TT = t.TT; a.Tp = t.Tp; a.n_row_tiles = t.n_row_tiles; a.n_time_tiles = t.n_time_tiles;
     a.w = n->blob_dev + pc.f_off;
     MfmaArgs ma;
-    ma.c = a; ma.TB = pc.tb; ma.ntiles_total = pc.ntiles; ma.cin_chunk = mtile.cin_chunk;
+    ma.c = a; ma.TB = pc.tb; ma.KH = pc.kh; ma.ntiles_total = pc.ntiles; ma.cin_chunk = mtile.cin_chunk;
     ma.ksplit = 0;
+    ma.h1_magic = (65536 + a.h1 - 1) / a.h1;
+    static const int ablate = std::getenv("AKE_ABLATE") ? std::atoi(std::getenv("AKE_ABLATE")) : 0;
+    ma.dbg = ablate;
     if (mtile.W == 1 && pc.cin >= 8) {      // tiny M (1-channel head convs): split the input channels over 8 waves instead
         ma.ksplit = 1;
         mtile.W = 8;
@@ -299,12 +301,7 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
                 mtile.cin_chunk, t.lds, t.n_row_tiles * t.n_time_tiles, pc.ntiles / pc.nt, batch);
     dim3 grid(t.n_row_tiles * t.n_time_tiles, pc.ntiles / pc.nt, batch), block(t.threads);
     ake::ProfScope ps(name, s);
-    if (kind == 0 && pc.kh == 7) return launch_mfma<7, false>(pc, ma, grid, block, t.lds, s);
-    if (kind == 1 && pc.kh == 12) return launch_mfma<12, true>(pc, ma, grid, block, t.lds, s);
-    if (kind == 2 && pc.kh == 1) return launch_mfma<1, true>(pc, ma, grid, block, t.lds, s);
-    if (kind == 2 && pc.kh == 2) return launch_mfma<2, true>(pc, ma, grid, block, t.lds, s);
-    ake::set_error("conv %s: kernel height %d not built", name, pc.kh);
-    return AKE_ERR_UNSUPPORTED;
+    return launch_mfma(pc, ma, grid, block, t.lds, s);
 }
 
 int run_semi(const ake_pcnet* n, const PackedConv& pc, const float* src, int batch, int H, int Tn, float* dst,

@@ -358,143 +358,203 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct MfmaArgs {
     ConvArgs c;           // geometry, sources, destination (c.w = packed B fragments, c.bias = per-channel bias)
     int TB;               // frames per column group
+    int KH;               // kernel rows
     int ntiles_total;     // N-tiles of the whole layer (fragment stride)
     int cin_chunk;        // input channels staged in LDS at a time
+    int h1_magic;         // ceil(2^16 / h1): (row * h1_magic) >> 16 == row / h1 for the row counts used here
+    int dbg;              // ablation (AKE_ABLATE): 1 = skip the MFMA steps, 2 = skip the staging loads (results wrong, timing only)
     int ksplit;           // 1: the layer has <= MT M-tiles per workgroup (1-channel head convs): all waves share them and
                           //    split the input channels (ci = wave, wave + W, ...); partial sums are reduced through LDS
 };
 
-template <int KH, int KU, int NT, int MT, bool FULLROWS>
+template <int KU, int NT, int MT>
 __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ConvArgs& a = ma.c;
-    const int TB = ma.TB;
+    const int TB = ma.TB, KH = ma.KH;
     const int cin = a.c0 + a.c1;
     const int tile = blockIdx.x;
     const int row_tile = tile / a.n_time_tiles;
     const int time_tile = tile - row_tile * a.n_time_tiles;
     const int ngrp = blockIdx.y;                 // group of NT N-tiles
     const int clip = blockIdx.z;
-    const int y0 = FULLROWS ? 0 : row_tile * a.R;
+    const int y0 = row_tile * a.R;
     const int t0 = time_tile * a.TT;
-    const int R_in = FULLROWS ? a.H : a.R + KH - 1;
+    const int R_in = a.R + KH - 1;               // patch rows: the row halo is always materialised (wrapped rows are copied)
     const int Tp = a.Tp;
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
     const int r16 = lane & 15, q = lane >> 4;
-    const int rows_here = FULLROWS ? a.H : (a.H - y0 < a.R ? a.H - y0 : a.R);
+    const int rows_here = a.H - y0 < a.R ? a.H - y0 : a.R;
     const int tt_here = a.T_out - t0 < a.TT ? a.T_out - t0 : a.TT;   // frames of this time tile
     const int J = (tt_here + TB - 1) / TB;                             // frame groups per row
     const int Mblk = rows_here * J;
     const int mtiles = (Mblk + 15) / 16;
-    const int nw = blockDim.x >> 6;
     const int grp = ma.ksplit ? 0 : wave;                              // M-tile group of this wave
     const bool active = grp * MT < mtiles;
     const int cstride = R_in * Tp;
-    const int wrap_at = a.H * Tp;
     constexpr int KS = KU / 4;                                          // k-steps per (ci,dy)
 
-    int rstart[MT], tcol[MT];
+    // per-lane LDS float index of A[m][u = q] at (ci = 0, dy = 0) for each of the wave's MT tiles
+    int abase[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int m = (grp * MT + mt) * 16 + r16;
         if (m >= Mblk) m = Mblk - 1;
         const int r = m / J, j = m - r * J;
-        rstart[mt] = (FULLROWS ? wrap(r - a.py, a.H) : r) * Tp;
-        tcol[mt] = TB * j + q;
+        abase[mt] = r * Tp + TB * j + q;
     }
-    f32x4 acc[MT][NT];
+    // two independent accumulator chains per tile (even / odd k-steps): back-to-back MFMAs never depend on each other
+    f32x4 acc[MT][NT], acc2[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) { acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    // B fragments: [ci][dy][s][ntile][64 lanes]; fetched one (ci,dy) ahead
-    const float* __restrict__ bbase = a.w + (static_cast<long long>(ngrp) * NT) * 64 + lane;
-    const long long bstep = static_cast<long long>(ma.ntiles_total) * 64;   // floats per k-step
-    const long long bci = static_cast<long long>(KH) * KS * bstep;           // floats per input channel
+    // B fragments in global memory: [ci][dy][s][ntile][64 lanes]; the block's NT tiles of a chunk are staged in LDS
+    // behind the A patch as [cl][dy][s][nt][64] so that no wave ever waits on an L2 round trip inside the MFMA loop
+    const float* __restrict__ bglob = a.w + (static_cast<long long>(ngrp) * NT) * 64;
+    const int bstep = ma.ntiles_total * 64;                              // floats per k-step in global memory
+    float* const ldsB = lds + ma.cin_chunk * cstride;
     const int cstep = ma.ksplit ? nw : 1;
-    int ci = ma.ksplit ? wave : 0;
-    float bcur[KS][NT];
-    {
-        const float* bp = bbase + (ci < cin ? ci : 0) * bci;
+    int ci = ma.ksplit ? wave : 0;                                       // next input channel of this wave
+
+    auto load_a = [&](float (&A)[KS][MT], int soff) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) A[s][mt] = lds[abase[mt] + soff + 4 * s];
+    };
+    auto load_b = [&](float (&B)[KS][NT], int boff) {
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bcur[s][nt] = bp[s * bstep + nt * 64];
-    }
+            for (int nt = 0; nt < NT; ++nt) B[s][nt] = ldsB[boff + (s * NT + nt) * 64 + lane];
+    };
+    auto mma = [&](const float (&A)[KS][MT], const float (&B)[KS][NT]) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (s & 1) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][mt], B[s][nt], acc2[mt][nt], 0, 0, 0);
+                    else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][mt], B[s][nt], acc[mt][nt], 0, 0, 0);
+                }
+    };
 
     const float* s0 = a.src0 + clip * a.src0_clip_stride;
     const float* s1 = a.src1 ? a.src1 + clip * a.src1_clip_stride : nullptr;
+    const int ncb = (Tp + 63) >> 6;                                     // 64-lane column blocks per patch row (<= 3)
+    const bool fast_wrap = a.T_in >= Tp;                                // one conditional add/sub resolves the circular frame index
     for (int c_lo = 0; c_lo < cin; c_lo += ma.cin_chunk) {
         const int cc = cin - c_lo < ma.cin_chunk ? cin - c_lo : ma.cin_chunk;
         if (c_lo) __syncthreads();
-        // ---- stage channels [c_lo, c_lo+cc): rows and frames with both halos resolved.  One wave per patch row:
-        //      the row arithmetic is wave-uniform (SALU), lanes walk consecutive frames (coalesced), no div/mod per element.
-        {
+        // ---- stage channels [c_lo, c_lo+cc): rows and frames with both halos resolved.  One wave per patch row (row
+        //      arithmetic is wave-uniform), lanes walk consecutive frames (coalesced); 4 rows x <=3 column blocks of
+        //      loads are in flight before the first LDS write.
+        if (ma.dbg != 2) {
             const int nrows = cc * R_in;
-            for (int rr = __builtin_amdgcn_readfirstlane(wave); rr < nrows; rr += nw) {
-                const int cl = rr / R_in;
-                const int rj = rr - cl * R_in;
-                const int cs = c_lo + cl;
-                const int row = FULLROWS ? rj : wrap(y0 - a.py + rj, a.H);
-                const float* srow = cs < a.c0 ? s0 + (static_cast<long long>(cs) * a.H + row) * a.T_in
-                                              : s1 + (static_cast<long long>(cs - a.c0) * a.h1 + (row % a.h1)) * a.T_in;
-                float* drow = lds + rr * Tp;
-                for (int tj = lane; tj < Tp; tj += 64) {
-                    int ti = t0 - a.pad_l + tj;
-                    float v = 0.f;
-                    if (a.time_circ) {
-                        while (ti < 0) ti += a.T_in;
-                        while (ti >= a.T_in) ti -= a.T_in;
-                        v = srow[ti];
-                    } else if (ti >= 0 && ti < a.T_in) {
-                        v = srow[ti];
+            constexpr int UR = 4;
+            // (cl, rj) of patch row `wave`, advanced by nw rows per step without any division
+            int cl_it = 0, rj_it = wave;
+            while (rj_it >= R_in) { rj_it -= R_in; ++cl_it; }
+            for (int base = wave; base < nrows; base += UR * nw) {
+                float v[UR][3];
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    const bool live = base + u * nw < nrows;
+                    const int cl = live ? cl_it : 0, rj = live ? rj_it : 0;
+                    rj_it += nw;
+                    while (rj_it >= R_in) { rj_it -= R_in; ++cl_it; }
+                    const int cs = c_lo + cl;
+                    int row = y0 - a.py + rj;                            // in (-H, 2H): one conditional wrap each way
+                    row += row < 0 ? a.H : 0;
+                    row -= row >= a.H ? a.H : 0;
+                    const float* srow;
+                    if (cs < a.c0) srow = s0 + (static_cast<long long>(cs) * a.H + row) * a.T_in;
+                    else {
+                        const int r1 = row - ((row * ma.h1_magic) >> 16) * a.h1;     // row % h1 (PitchClass2Pitch repeat)
+                        srow = s1 + (static_cast<long long>(cs - a.c0) * a.h1 + r1) * a.T_in;
                     }
-                    drow[tj] = v;
+#pragma unroll
+                    for (int h = 0; h < 3; ++h) {
+                        v[u][h] = 0.f;
+                        const int tj = lane + 64 * h;
+                        if (h < ncb && tj < Tp) {
+                            int ti = t0 - a.pad_l + tj;
+                            bool ok = true;
+                            if (a.time_circ) {
+                                if (fast_wrap) { ti += ti < 0 ? a.T_in : 0; ti -= ti >= a.T_in ? a.T_in : 0; }
+                                else ti = wrap(ti, a.T_in);
+                            } else {
+                                ok = ti >= 0 && ti < a.T_in;
+                            }
+                            if (ok) v[u][h] = srow[ti];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    const int rr = base + u * nw;
+                    if (rr < nrows) {
+#pragma unroll
+                        for (int h = 0; h < 3; ++h) {
+                            const int tj = lane + 64 * h;
+                            if (h < ncb && tj < Tp) lds[rr * Tp + tj] = v[u][h];
+                        }
+                    }
+                }
+            }
+            // B fragments of the chunk: cc*KH k-step groups of KS*NT*64 floats (contiguous in LDS, strided in global)
+            constexpr int GF = KS * NT * 64;
+            const int ngroups = cc * KH;
+            const float* bsrc = bglob + static_cast<long long>(c_lo) * KH * KS * bstep;
+            for (int g = wave; g < ngroups; g += nw) {
+#pragma unroll
+                for (int e = 0; e < KS * NT; ++e) {
+                    const int sidx = e / NT, nt = e - sidx * NT;
+                    ldsB[g * GF + e * 64 + lane] = bsrc[(static_cast<long long>(g) * KS + sidx) * bstep + nt * 64 + lane];
                 }
             }
         }
         __syncthreads();
-        if (!active) continue;
-        for (; ci < c_lo + cc; ci += cstep) {
-            const int cl = ci - c_lo;
-            const int nci = ci + cstep < cin ? ci + cstep : ci;          // channel whose first fragments are prefetched last
-            const float* bp = bbase + ci * bci;
-            int roff[MT];
+        if (!active || ci >= c_lo + cc || ma.dbg == 1) continue;
+        // ---- this wave's steps of the chunk: (channel, dy) pairs, fragments fetched one step ahead into a ping-pong pair ----
+        const int nsteps = ((c_lo + cc - ci + cstep - 1) / cstep) * KH;
+        int pf_ci = ci, pf_dy = 0;                                       // prefetch cursor (wave-uniform)
+        float Ac[KS][MT], Bc[KS][NT];
+        load_a(Ac, ((pf_ci - c_lo) * R_in + pf_dy) * Tp);
+        load_b(Bc, ((pf_ci - c_lo) * KH + pf_dy) * (KS * NT * 64));
+        for (int st = 0; st < nsteps; ++st) {
+            // branch-free software pipeline: fetch step st+1 (the last iteration re-fetches its own step), then the
+            // MFMAs of step st; the fragment hand-over (register moves) waits for the loads after the MFMAs are issued
+            const int adv = st + 1 < nsteps ? 1 : 0;
+            pf_dy += adv;
+            if (pf_dy == KH) { pf_dy = 0; pf_ci += cstep; }
+            float An[KS][MT], Bn[KS][NT];
+            load_a(An, ((pf_ci - c_lo) * R_in + pf_dy) * Tp);
+            load_b(Bn, ((pf_ci - c_lo) * KH + pf_dy) * (KS * NT * 64));
+            mma(Ac, Bc);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) roff[mt] = rstart[mt] + cl * cstride;
-            for (int dy = 0; dy < KH; ++dy) {
-                const float* bn = dy + 1 < KH ? bp + (dy + 1) * KS * bstep : bbase + nci * bci;
-                float bnext[KS][NT];
+            for (int s = 0; s < KS; ++s) {
 #pragma unroll
-                for (int s = 0; s < KS; ++s)
+                for (int mt = 0; mt < MT; ++mt) Ac[s][mt] = An[s][mt];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bnext[s][nt] = bn[s * bstep + nt * 64];
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    float av[MT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) av[mt] = lds[roff[mt] + tcol[mt] + 4 * s];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bcur[s][nt], acc[mt][nt], 0, 0, 0);
-                }
-#pragma unroll
-                for (int s = 0; s < KS; ++s)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bcur[s][nt] = bnext[s][nt];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    roff[mt] += Tp;
-                    if (FULLROWS && roff[mt] - cl * cstride == wrap_at) roff[mt] -= wrap_at;
-                }
+                for (int nt = 0; nt < NT; ++nt) Bc[s][nt] = Bn[s][nt];
             }
         }
+        // the cursor stopped on this chunk's last step; the wave's next channel is one stride further
+        pf_ci += cstep;
+        ci = pf_ci;
     }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] += acc2[mt][nt];
+
     if (ma.ksplit) {   // sum the waves' partial accumulators through LDS (the patch is dead now); wave 0 stores
         __syncthreads();
         f32x4* red = reinterpret_cast<f32x4*>(lds);
@@ -527,11 +587,11 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
                 const int m = (grp * MT + mt) * 16 + 4 * q + reg;
                 if (m >= Mblk) continue;
                 const int r = m / J, j = m - r * J;
-                const int y = y0 + r, t = t0 + TB * j + tau;
+                const int y = y0 + r;
                 if (y >= a.H_out || TB * j + tau >= tt_here) continue;
                 float v = acc[mt][nt][reg] + b;
                 if (a.lrelu) v = v > 0.f ? v : v * kSlope;
-                d[(static_cast<long long>(a.dst_coff + co) * a.H_out + y) * a.T_out + t] = v;
+                d[(static_cast<long long>(a.dst_coff + co) * a.H_out + y) * a.T_out + t0 + TB * j + tau] = v;
             }
     }
 }
