@@ -3,8 +3,8 @@
 // Replaces PitchClassNet.forward (models.py:747-817) for the default architecture family
 // (models.py:190-197, 227-234, 311-350).  Channel algebra follows models.py:279-308 / 693-710.
 //
-// HBM layout (all fp32, NCHW, per chunk of <= chunk_clips clips so that the pitch-stream
-// activations [chunk][8][288][T] stay inside the 256 MiB Infinity Cache between layers):
+// HBM layout (all fp32, NCHW; the pitch stream runs in chunks of <= chunk_clips clips (AKE_PCNET_CHUNK, default
+// 256): measured on MI355X a larger launch beats Infinity-Cache residency of the 700 KB/clip activations):
 //   mel      [B][1][P][T]                    caller's
 //   fold0    [c][1][12][T]                   semitone conv + octave fold of layer 0
 //   cat_i    [c][prev_pc + out_p][12][T_i]   concat buffer of layer i: producers write their channel slice
@@ -66,7 +66,7 @@ struct ake_pcnet {
     std::map<std::string, int> spec_index;
     std::vector<HostTensor> host;
     bool finalized = false;
-    int chunk_clips = 64;
+    int chunk_clips = 256;
 
     // packed parameters
     std::vector<float> blob;
@@ -237,8 +237,10 @@ bool choose_tile(bool fullrows, int cin, int H, int KH, int T_out, int TB, int K
     return true;
 }
 
-int launch_mfma(const PackedConv& pc, const MfmaArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+int launch_mfma(const PackedConv& pc, const MfmaArgs& a, int MT, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
 #define AKE_MFMA(KU_, NT_) hipLaunchKernelGGL((conv_mfma_kernel<KU_, NT_, 3>), grid, block, lds, s, a); return AKE_OK
+    if (pc.ku == 8 && pc.nt == 1 && MT == 6) { hipLaunchKernelGGL((conv_mfma_kernel<8, 1, 6>), grid, block, lds, s, a); return AKE_OK; }
+    if (pc.ku == 8 && pc.nt == 1 && MT == 4) { hipLaunchKernelGGL((conv_mfma_kernel<8, 1, 4>), grid, block, lds, s, a); return AKE_OK; }
     if (pc.ku == 8 && pc.nt == 1) { AKE_MFMA(8, 1); }
     if (pc.ku == 8 && pc.nt == 2) { AKE_MFMA(8, 2); }
     if (pc.ku == 12 && pc.nt == 1) { AKE_MFMA(12, 1); }
@@ -278,7 +280,9 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
     a.lrelu = lrelu ? 1 : 0;
     Tile t;
     MTile mtile;
-    AKE_REQUIRE(choose_tile(fullrows, pc.cin, H, pc.kh, a.T_out, pc.tb, pc.ku, pc.nt, 3, &t, &mtile), AKE_ERR_UNSUPPORTED,
+    static const int mt_env = std::getenv("AKE_MT") ? std::atoi(std::getenv("AKE_MT")) : 3;
+    const int MT = (pc.ku == 8 && pc.nt == 1 && kind == 0) ? mt_env : 3;
+    AKE_REQUIRE(choose_tile(fullrows, pc.cin, H, pc.kh, a.T_out, pc.tb, pc.ku, pc.nt, MT, &t, &mtile), AKE_ERR_UNSUPPORTED,
                 "conv %s: no tile fits LDS (cin=%d H=%d)", name, pc.cin, H);
     a.R = t.R; a.TT = t.TT; a.Tp = t.Tp; a.n_row_tiles = t.n_row_tiles; a.n_time_tiles = t.n_time_tiles;
     a.w = n->blob_dev + pc.f_off;
@@ -292,7 +296,7 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
         ma.ksplit = 1;
         mtile.W = 8;
         t.threads = 8 * 64;
-        t.lds = std::max<size_t>(t.lds, static_cast<size_t>(8) * 3 * pc.nt * 64 * sizeof(float) * 4);
+        t.lds = std::max<size_t>(t.lds, static_cast<size_t>(8) * MT * pc.nt * 64 * sizeof(float) * 4);
     }
     static const bool debug = std::getenv("AKE_DEBUG") != nullptr;
     if (debug)
@@ -301,7 +305,7 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
                 mtile.cin_chunk, t.lds, t.n_row_tiles * t.n_time_tiles, pc.ntiles / pc.nt, batch);
     dim3 grid(t.n_row_tiles * t.n_time_tiles, pc.ntiles / pc.nt, batch), block(t.threads);
     ake::ProfScope ps(name, s);
-    return launch_mfma(pc, ma, grid, block, t.lds, s);
+    return launch_mfma(pc, ma, MT, grid, block, t.lds, s);
 }
 
 int run_semi(const ake_pcnet* n, const PackedConv& pc, const float* src, int batch, int H, int Tn, float* dst,

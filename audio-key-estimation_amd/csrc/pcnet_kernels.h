@@ -524,19 +524,24 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
         if (!active || ci >= c_lo + cc || ma.dbg == 1) continue;
         // ---- this wave's steps of the chunk: (channel, dy) pairs, fragments fetched one step ahead into a ping-pong pair ----
         const int nsteps = ((c_lo + cc - ci + cstep - 1) / cstep) * KH;
-        int pf_ci = ci, pf_dy = 0;                                       // prefetch cursor (wave-uniform)
+        // prefetch cursor (wave-uniform), advanced with adds only: a_off / b_off are LDS float offsets of the step
+        constexpr int GF = KS * NT * 64;
+        int pf_ci = ci, pf_dy = 0;
+        int a_off = (ci - c_lo) * cstride, b_off = (ci - c_lo) * KH * GF;
+        const int a_jump = cstep * cstride - (KH - 1) * Tp, b_jump = ((cstep - 1) * KH + 1) * GF;
         float Ac[KS][MT], Bc[KS][NT];
-        load_a(Ac, ((pf_ci - c_lo) * R_in + pf_dy) * Tp);
-        load_b(Bc, ((pf_ci - c_lo) * KH + pf_dy) * (KS * NT * 64));
+        load_a(Ac, a_off);
+        load_b(Bc, b_off);
         for (int st = 0; st < nsteps; ++st) {
             // branch-free software pipeline: fetch step st+1 (the last iteration re-fetches its own step), then the
-            // MFMAs of step st; the fragment hand-over (register moves) waits for the loads after the MFMAs are issued
-            const int adv = st + 1 < nsteps ? 1 : 0;
-            pf_dy += adv;
-            if (pf_dy == KH) { pf_dy = 0; pf_ci += cstep; }
+            // MFMAs of step st
+            if (st + 1 < nsteps) {
+                if (++pf_dy == KH) { pf_dy = 0; pf_ci += cstep; a_off += a_jump; b_off += b_jump; }
+                else { a_off += Tp; b_off += GF; }
+            }
             float An[KS][MT], Bn[KS][NT];
-            load_a(An, ((pf_ci - c_lo) * R_in + pf_dy) * Tp);
-            load_b(Bn, ((pf_ci - c_lo) * KH + pf_dy) * (KS * NT * 64));
+            load_a(An, a_off);
+            load_b(Bn, b_off);
             mma(Ac, Bc);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -572,27 +577,31 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
     }
     if (!active) return;
 
-    // ---- epilogue: D[row = 4*(lane>>4) + reg][col = lane&15]; bias (BN folded), LeakyReLU ----
-    float* d = a.dst + clip * a.dst_clip_stride;
+    // ---- epilogue: D[row = 4*(lane>>4) + reg][col = lane&15]; bias (BN folded), LeakyReLU.
+    //      One division per M-tile: positions 4q..4q+3 of a tile are consecutive frame groups (j, j+1, ..) of row r,
+    //      carried into the next row when j reaches J. ----
+    float* d = a.dst + clip * a.dst_clip_stride + t0;
+    const int row_elems = a.T_out;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = (ngrp * NT + nt) * 16 + r16;
-        const int co = n / TB, tau = n - co * TB;
-        if (co >= a.cout) continue;
-        const float b = a.bias[co];
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m0 = (grp * MT + mt) * 16 + 4 * q;
+        int r = m0 / J, j = m0 - r * J;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int reg = 0; reg < 4; ++reg) {
+            const bool ok_m = m0 + reg < Mblk && y0 + r < a.H_out;
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int m = (grp * MT + mt) * 16 + 4 * q + reg;
-                if (m >= Mblk) continue;
-                const int r = m / J, j = m - r * J;
-                const int y = y0 + r;
-                if (y >= a.H_out || TB * j + tau >= tt_here) continue;
-                float v = acc[mt][nt][reg] + b;
-                if (a.lrelu) v = v > 0.f ? v : v * kSlope;
-                d[(static_cast<long long>(a.dst_coff + co) * a.H_out + y) * a.T_out + t0 + TB * j + tau] = v;
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = (ngrp * NT + nt) * 16 + r16;
+                const int co = n / TB, tau = n - co * TB;        // TB is a power of two in practice; wave-invariant per lane
+                const int tl = TB * j + tau;
+                if (ok_m && co < a.cout && tl < tt_here) {
+                    float v = acc[mt][nt][reg] + a.bias[co];
+                    if (a.lrelu) v = v > 0.f ? v : v * kSlope;
+                    d[((a.dst_coff + co) * a.H_out + (y0 + r)) * row_elems + tl] = v;
+                }
             }
+            if (++j == J) { j = 0; ++r; }
+        }
     }
 }
 

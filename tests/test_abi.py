@@ -96,8 +96,8 @@ def test_variant_flags_are_refused(flag):
 def test_workspace_queries_need_no_gpu():
     lib = _lib.lib()
     rc, h = _create()
-    small, big = lib.ake_pcnet_workspace_bytes(h, 1, 76), lib.ake_pcnet_workspace_bytes(h, 64, 76)
+    small, big = lib.ake_pcnet_workspace_bytes(h, 1, 76), lib.ake_pcnet_workspace_bytes(h, 256, 76)
     assert 0 < small < big
-    huge = lib.ake_pcnet_workspace_bytes(h, 256, 76)           # pitch stream chunked at 64 clips; only the small
+    huge = lib.ake_pcnet_workspace_bytes(h, 1024, 76)          # pitch stream chunked at 256 clips; only the small
     assert big < huge < 2 * big                                 # pitch-class tail buffers grow with the batch
     lib.ake_pcnet_destroy(h)
