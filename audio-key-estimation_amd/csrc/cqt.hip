@@ -8,11 +8,13 @@
 //   2. cqt_bank_kernel       for every (octave o, frame t): the 36 bins of the octave are
 //                            <=277-tap complex FIRs on the 2^o-decimated signal.  A frame centre
 //                            t*hop is not a multiple of 2^o in general, so the plan holds one
-//                            filter bank per fractional phase (t*hop mod 2^o).  Lane = clip:
-//                            filter taps are wave-uniform and come in through SGPRs
-//                            (s_load), each lane streams its own clip's window with 16-byte
-//                            loads, and every v_fma has one scalar operand.  |.| and log1p are
-//                            fused into the epilogue.
+//                            filter bank per fractional phase (t*hop mod 2^o).  The bank apply is a
+//                            GEMM  out[clip][72 re/im columns] = X[clip][taps] * W[taps][72]  on
+//                            v_mfma_f32_16x16x4_f32 (exact fp32): M = 16 clips per wave, 5 N-tiles
+//                            of 8 bins each with its own tap window (shorter filters skip their zero
+//                            taps), W fragments staged through LDS per 64-tap chunk, each lane
+//                            streams its clip's window with one 16-byte load per 4 k-steps.
+//                            |.| (re/im pair via one lane shuffle) and log1p are the epilogue.
 //
 // HBM layout: audio [B][stride] f32 (caller's), y_o [B][len_o] f32 in the workspace
 // (len_o = ceil(n/2^o) + 2*Hh, sample m stored at m + Hh), out [B][n_bins][out_frames] f32.
@@ -26,17 +28,22 @@
 namespace {
 
 constexpr int kMaxOct = 12;
-constexpr int kNBW = 12;        // bins per wave in the bank kernel
+constexpr int kTileBins = 8;    // CQT bins per MFMA N-tile (16 columns = 8 bins x re/im)
+constexpr int kMaxTiles = 5;    // N-tiles per octave (36 bins -> 4.5 tiles)
+constexpr int kChunkBlocks = 4; // 16-tap blocks staged in LDS at a time
 constexpr int kMaxOddTaps = 32; // decimator: odd taps 1,3,..,2*32-1
 constexpr double kC1 = 32.70319566257483;
 constexpr int kDecimOutPerBlock = 512;
 constexpr int kDecimThreads = 256;
 
-struct GroupDesc {       // one (octave, bin-group): 12 bins sharing a tap window
-    int octave;          // 0 = top octave (full rate)
-    int k0;              // first CQT bin of the group
-    int uh;              // taps u = -uh .. +uh on the decimated grid
-    int table_off;       // float offset of phase 0 in the table
+struct OctDesc {         // one octave of the filter bank in MFMA fragment order
+    int k0;              // first CQT bin of the octave
+    int n_bins;          // bins in the octave (36)
+    int n_tiles;         // N-tiles (ceil(n_bins / 8))
+    int uh;              // taps u = -uh .. +uh on the decimated grid (window of the longest filter)
+    int n_blocks;        // 16-tap blocks covering the window
+    int blk_lo[kMaxTiles], blk_hi[kMaxTiles];   // active tap blocks of each N-tile (shorter filters skip the rest)
+    int table_off;       // float offset of phase 0: [phase][block][e][tile][64 lanes]
     int phase_stride;    // floats between consecutive phases
 };
 
@@ -59,12 +66,12 @@ struct BankCall {
 struct ake_cqt_plan {
     ake_cqt_config cfg;
     int n_oct;
-    int n_groups;       // n_oct * groups_per_oct
+
     int hop_twos;       // trailing zero bits of hop
     int half_len;
     DecimTaps taps;
-    std::vector<GroupDesc> groups;
-    GroupDesc* groups_dev = nullptr;
+    std::vector<OctDesc> octs;
+    OctDesc* octs_dev = nullptr;
     float* table_dev = nullptr;
     size_t table_floats = 0;
 };
@@ -106,63 +113,85 @@ __global__ __launch_bounds__(kDecimThreads) void cqt_decimate_kernel(
 }
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// One wave = 64 clips x 12 bins of one (octave, frame).
-__global__ __launch_bounds__(64) void cqt_bank_kernel(
-    BankCall call, const GroupDesc* __restrict__ groups, const float* __restrict__ table,
-    int batch, int n_frames, int hop, int hop_twos, float* __restrict__ out, long long out_clip_stride,
-    int out_frames) {
+// Workgroup = (frame t, octave o, 64 clips): 4 waves x one 16-clip M-tile, all N-tiles of the octave.
+// A[m = clip][k]: lane (r = lane&15, q = lane>>4) loads X[clip r][16*blk + 4q .. +3] (one dwordx4 per 16 taps);
+// component e of that vector is the A operand of k-step e, i.e. MFMA k index q <-> tap 16*blk + 4q + e, and the
+// W fragments are packed on the host with the same tap permutation.
+__global__ __launch_bounds__(256) void cqt_bank_kernel(
+    BankCall call, const OctDesc* __restrict__ octs, const float* __restrict__ table,
+    int batch, int hop, int hop_twos, float* __restrict__ out, long long out_clip_stride, int out_frames) {
+    __shared__ __attribute__((aligned(16))) float ldsB[kChunkBlocks * 4 * kMaxTiles * 64];
     const int t = blockIdx.x;
-    const GroupDesc g = groups[blockIdx.y];
-    const int lane_clip = blockIdx.z * 64 + threadIdx.x;
-    const int clip = lane_clip < batch ? lane_clip : batch - 1;   // clamp: idle lanes redo the last clip
-    const int o = g.octave;
+    const int o = blockIdx.y;
+    const OctDesc g = octs[o];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int clip_raw = blockIdx.z * 64 + wave * 16 + r16;
+    const int clip = clip_raw < batch ? clip_raw : batch - 1;       // idle rows redo the last clip (never stored)
     const long long c = static_cast<long long>(t) * hop;
     const int c_int = static_cast<int>(c >> o);
     const int ph = static_cast<int>(c & ((1ll << o) - 1));
     const int sh = hop_twos < o ? hop_twos : o;
     const float* __restrict__ w = table + g.table_off + static_cast<long long>(ph >> sh) * g.phase_stride;
-
-    const int lo = call.lo[o];
-    const int cnt = call.count[o];
+    const int lo = call.lo[o], cnt = call.count[o];
     const float* __restrict__ x = call.x[o] + clip * call.stride[o];
+    const int s_first = c_int - g.uh - lo;                           // array index of tap 0 of the window
 
-    // uniform tap range inside the stored signal: sample index s = c_int + u, array index s - lo
-    int u_beg = -g.uh, u_end = g.uh + 1;
-    if (c_int + u_beg < lo) u_beg = lo - c_int;
-    if (c_int + u_end > lo + cnt) u_end = lo + cnt - c_int;
+    f32x4 acc[kMaxTiles];
+#pragma unroll
+    for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float acc[2 * kNBW];
-#pragma unroll
-    for (int i = 0; i < 2 * kNBW; ++i) acc[i] = 0.f;
-
-    int u = u_beg;
-    const float* xp = x + (c_int + u - lo);
-    const float* wp = w + (u + g.uh) * (2 * kNBW);
-    for (; u + 4 <= u_end; u += 4) {
-        const f4u xv = *reinterpret_cast<const f4u*>(xp);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float xs = xv[q];
-#pragma unroll
-            for (int i = 0; i < 2 * kNBW; ++i) acc[i] = fmaf(xs, wp[q * 2 * kNBW + i], acc[i]);
+    auto load_x = [&](int blk) -> f32x4 {
+        const int i0 = s_first + 16 * blk + 4 * q;
+        if (i0 >= 0 && i0 + 4 <= cnt) {
+            const f4u v = *reinterpret_cast<const f4u*>(x + i0);
+            return f32x4{v[0], v[1], v[2], v[3]};
         }
-        xp += 4;
-        wp += 4 * 2 * kNBW;
-    }
-    for (; u < u_end; ++u) {
-        const float xs = *xp;
+        f32x4 v;
 #pragma unroll
-        for (int i = 0; i < 2 * kNBW; ++i) acc[i] = fmaf(xs, wp[i], acc[i]);
-        xp += 1;
-        wp += 2 * kNBW;
-    }
-    if (lane_clip < batch) {
-        float* dst = out + lane_clip * out_clip_stride + static_cast<long long>(g.k0) * out_frames + t;
+        for (int e = 0; e < 4; ++e) v[e] = (i0 + e >= 0 && i0 + e < cnt) ? x[i0 + e] : 0.f;   // zero padding outside the clip
+        return v;
+    };
+
+    constexpr int BF = 4 * kMaxTiles * 64;                           // floats per tap block
+    f32x4 xv = load_x(0);
+    for (int b0 = 0; b0 < g.n_blocks; b0 += kChunkBlocks) {
+        const int nb = g.n_blocks - b0 < kChunkBlocks ? g.n_blocks - b0 : kChunkBlocks;
+        if (b0) __syncthreads();
+        {   // stage the W fragments of this chunk (contiguous in global memory)
+            const float4* src = reinterpret_cast<const float4*>(w + static_cast<long long>(b0) * BF);
+            float4* dst = reinterpret_cast<float4*>(ldsB);
+            for (int i = threadIdx.x; i < nb * BF / 4; i += 256) dst[i] = src[i];
+        }
+        __syncthreads();
+        for (int bi = 0; bi < nb; ++bi) {
+            const int blk = b0 + bi;
+            const f32x4 xc = xv;
+            xv = load_x(blk + 1 < g.n_blocks ? blk + 1 : blk);       // next block's window, in flight during the MFMAs
 #pragma unroll
-        for (int b = 0; b < kNBW; ++b) {
-            const float re = acc[2 * b], im = acc[2 * b + 1];
-            dst[static_cast<long long>(b) * out_frames] = log1pf(sqrtf(re * re + im * im));
+            for (int j = 0; j < kMaxTiles; ++j) {
+                if (j < g.n_tiles && blk >= g.blk_lo[j] && blk <= g.blk_hi[j]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[e], ldsB[((bi * 4 + e) * kMaxTiles + j) * 64 + lane], acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // epilogue: D[row = clip 4q+reg][col r16]: col = 2*(bin within tile) + (re|im); |C| needs the neighbouring lane
+#pragma unroll
+    for (int j = 0; j < kMaxTiles; ++j) {
+        const int b = kTileBins * j + (r16 >> 1);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float v2 = acc[j][reg] * acc[j][reg];
+            const float m2 = v2 + __shfl_xor(v2, 1);
+            const int cl = blockIdx.z * 64 + wave * 16 + 4 * q + reg;
+            if ((r16 & 1) == 0 && j < g.n_tiles && b < g.n_bins && cl < batch)
+                out[cl * out_clip_stride + static_cast<long long>(g.k0 + b) * out_frames + t] = log1pf(sqrtf(m2));
         }
     }
 }
@@ -231,8 +260,8 @@ int ake_cqt_plan_create(const ake_cqt_config* cfg_in, ake_cqt_plan** out) {
     if (cfg.decim_half_len <= 0) cfg.decim_half_len = 23;
     if (cfg.decim_beta <= 0) cfg.decim_beta = 8.0;
     AKE_REQUIRE(cfg.sample_rate > 0 && cfg.hop_length > 0 && cfg.n_bins > 0, AKE_ERR_INVALID, "cqt: bad rate/hop/bins");
-    AKE_REQUIRE(cfg.bins_per_octave % kNBW == 0 && cfg.n_bins % cfg.bins_per_octave == 0, AKE_ERR_UNSUPPORTED,
-                "cqt: bins_per_octave must be a multiple of %d and divide n_bins", kNBW);
+    AKE_REQUIRE(cfg.n_bins % cfg.bins_per_octave == 0 && cfg.bins_per_octave <= kTileBins * kMaxTiles, AKE_ERR_UNSUPPORTED,
+                "cqt: bins_per_octave must divide n_bins and be <= %d", kTileBins * kMaxTiles);
     AKE_REQUIRE(cfg.decim_half_len % 2 == 1 && (cfg.decim_half_len + 1) / 2 <= kMaxOddTaps, AKE_ERR_INVALID,
                 "cqt: decim_half_len must be odd and <= %d", 2 * kMaxOddTaps - 1);
     const int bpo = cfg.bins_per_octave;
@@ -276,55 +305,58 @@ int ake_cqt_plan_create(const ake_cqt_config* cfg_in, ake_cqt_plan** out) {
         return gain;
     };
 
-    const int gpo = bpo / kNBW;
     std::vector<float> table;
     for (int o = 0; o < n_oct; ++o) {
         const int dec = 1 << o;
         const int sh = std::min(p->hop_twos, o);
         const int nph = dec >> sh;
-        const int k_hi = cfg.n_bins - bpo * o;
-        for (int gi = 0; gi < gpo; ++gi) {
-            GroupDesc g;
-            g.octave = o;
-            g.k0 = k_hi - bpo + gi * kNBW;
-            double lo_min = 0;
-            for (int b = 0; b < kNBW; ++b) lo_min = std::min(lo_min, std::floor(-len[g.k0 + b] / 2.0));
-            g.uh = static_cast<int>(std::ceil(-lo_min / dec)) + 1;
-            const int ntap = 2 * g.uh + 1;
-            g.phase_stride = ntap * 2 * kNBW;
-            g.table_off = static_cast<int>(table.size());
-            table.resize(table.size() + static_cast<size_t>(nph) * g.phase_stride);
-            for (int pi = 0; pi < nph; ++pi) {
-                const double ph = static_cast<double>(pi << sh);
-                float* dst = table.data() + g.table_off + static_cast<size_t>(pi) * g.phase_stride;
-                for (int b = 0; b < kNBW; ++b) {
-                    const int k = g.k0 + b;
-                    const double lo = std::floor(-len[k] / 2.0);
-                    const double L = std::floor(len[k] / 2.0) - lo;
-                    const double scale = dec * std::sqrt(len[k]) / (L / 2.0) / cascade_gain(freq[k], o);
-                    for (int u = -g.uh; u <= g.uh; ++u) {
-                        const double pos = static_cast<double>(dec) * u - ph;   // full-rate offset from the frame centre
-                        double re = 0, im = 0;
-                        if (pos >= lo && pos <= lo + L) {
-                            const double win = 0.5 - 0.5 * std::cos(2.0 * M_PI * (pos - lo) / L);
-                            const double arg = 2.0 * M_PI * freq[k] * pos / sr;
-                            re = scale * win * std::cos(arg);
-                            im = -scale * win * std::sin(arg);
-                        }
-                        dst[(u + g.uh) * 2 * kNBW + 2 * b] = static_cast<float>(re);
-                        dst[(u + g.uh) * 2 * kNBW + 2 * b + 1] = static_cast<float>(im);
-                    }
+        OctDesc g;
+        std::memset(&g, 0, sizeof(g));
+        g.k0 = cfg.n_bins - bpo * (o + 1);
+        g.n_bins = bpo;
+        g.n_tiles = (bpo + kTileBins - 1) / kTileBins;
+        auto uh_of = [&](int k) { return static_cast<int>(std::ceil(-std::floor(-len[k] / 2.0) / dec)) + 1; };
+        g.uh = uh_of(g.k0);                                    // lowest bin of the octave = longest filter
+        g.n_blocks = (2 * g.uh + 1 + 15) / 16;
+        for (int j = 0; j < g.n_tiles; ++j) {
+            const int uh_j = uh_of(g.k0 + kTileBins * j);       // longest filter of the tile
+            g.blk_lo[j] = (g.uh - uh_j) / 16;
+            g.blk_hi[j] = std::min(g.n_blocks - 1, (g.uh + uh_j) / 16);
+        }
+        constexpr int BF = 4 * kMaxTiles * 64;
+        g.phase_stride = g.n_blocks * BF;
+        g.table_off = static_cast<int>(table.size());
+        table.resize(table.size() + static_cast<size_t>(nph) * g.phase_stride, 0.f);
+        for (int pi = 0; pi < nph; ++pi) {
+            const double ph = static_cast<double>(pi << sh);
+            float* dst = table.data() + g.table_off + static_cast<size_t>(pi) * g.phase_stride;
+            for (int b = 0; b < bpo; ++b) {
+                const int k = g.k0 + b;
+                const int j = b / kTileBins;
+                const double lo = std::floor(-len[k] / 2.0);
+                const double L = std::floor(len[k] / 2.0) - lo;
+                const double scale = dec * std::sqrt(len[k]) / (L / 2.0) / cascade_gain(freq[k], o);
+                for (int tap = 0; tap < 16 * g.n_blocks; ++tap) {
+                    const int u = tap - g.uh;
+                    const double pos = static_cast<double>(dec) * u - ph;   // full-rate offset from the frame centre
+                    if (!(pos >= lo && pos <= lo + L)) continue;
+                    const double win = 0.5 - 0.5 * std::cos(2.0 * M_PI * (pos - lo) / L);
+                    const double arg = 2.0 * M_PI * freq[k] * pos / sr;
+                    const int blk = tap / 16, qq = (tap % 16) / 4, e = tap % 4;   // MFMA k index qq <-> tap 16*blk + 4*qq + e
+                    const int col = 2 * (b % kTileBins);
+                    float* f = dst + ((static_cast<size_t>(blk) * 4 + e) * kMaxTiles + j) * 64 + qq * 16;
+                    f[col] = static_cast<float>(scale * win * std::cos(arg));
+                    f[col + 1] = static_cast<float>(-scale * win * std::sin(arg));
                 }
             }
-            p->groups.push_back(g);
         }
+        p->octs.push_back(g);
     }
-    p->n_groups = static_cast<int>(p->groups.size());
     p->table_floats = table.size();
     hipError_t e = hipMalloc(&p->table_dev, table.size() * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&p->groups_dev, p->groups.size() * sizeof(GroupDesc));
+    if (e == hipSuccess) e = hipMalloc(&p->octs_dev, p->octs.size() * sizeof(OctDesc));
     if (e == hipSuccess) e = hipMemcpy(p->table_dev, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(p->groups_dev, p->groups.data(), p->groups.size() * sizeof(GroupDesc), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->octs_dev, p->octs.data(), p->octs.size() * sizeof(OctDesc), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         ake::set_error("cqt plan upload failed: %s", hipGetErrorString(e));
         ake_cqt_plan_destroy(p);
@@ -337,7 +369,7 @@ int ake_cqt_plan_create(const ake_cqt_config* cfg_in, ake_cqt_plan** out) {
 void ake_cqt_plan_destroy(ake_cqt_plan* p) {
     if (!p) return;
     if (p->table_dev) (void)hipFree(p->table_dev);
-    if (p->groups_dev) (void)hipFree(p->groups_dev);
+    if (p->octs_dev) (void)hipFree(p->octs_dev);
     delete p;
 }
 
@@ -387,10 +419,10 @@ int ake_cqt_logmag_f32(const ake_cqt_plan* p, const float* audio, int batch, int
     if (out_frames > T)
         AKE_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float) * batch * p->cfg.n_bins * out_frames, stream));
     {
-        dim3 grid(static_cast<unsigned>(T), p->n_groups, (batch + 63) / 64);
+        dim3 grid(static_cast<unsigned>(T), p->n_oct, (batch + 63) / 64);
         ake::ProfScope ps("cqt_bank_kernel", stream);
-        hipLaunchKernelGGL(cqt_bank_kernel, grid, dim3(64), 0, stream, call, p->groups_dev, p->table_dev, batch,
-                           static_cast<int>(T), p->cfg.hop_length, p->hop_twos, out,
+        hipLaunchKernelGGL(cqt_bank_kernel, grid, dim3(256), 0, stream, call, p->octs_dev, p->table_dev, batch,
+                           p->cfg.hop_length, p->hop_twos, out,
                            static_cast<long long>(p->cfg.n_bins) * out_frames, static_cast<int>(out_frames));
     }
     AKE_HIP_CHECK(hipGetLastError());

@@ -157,7 +157,7 @@ PackedConv pack_conv(ake_pcnet* n, const std::vector<double>& w, const std::vect
         p.tb = cout >= 9 ? 1 : (cout >= 5 ? 2 : (cout >= 2 ? 4 : 16));
         p.ku = (p.tb + kw - 1 + 3) / 4 * 4;
         p.ntiles = (cout * p.tb + 15) / 16;
-        p.nt = (p.tb == 1 && p.ntiles % 2 == 0) ? 2 : 1;
+        p.nt = (p.tb == 1 && p.ntiles % 2 == 0 && kh <= 2) ? 2 : 1;   // tall kernels: B fragments dominate LDS, keep one N-tile
         const int ks = p.ku / 4;
         blob.resize(ake::align_up(blob.size(), 64));
         p.f_off = blob.size();
@@ -292,7 +292,7 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
     ma.h1_magic = (65536 + a.h1 - 1) / a.h1;
     static const int ablate = std::getenv("AKE_ABLATE") ? std::atoi(std::getenv("AKE_ABLATE")) : 0;
     ma.dbg = ablate;
-    if (mtile.W == 1 && pc.cin >= 8) {      // tiny M (1-channel head convs): split the input channels over 8 waves instead
+    if (mtile.W == 1 && pc.cin * pc.kh >= 16) {   // tiny M (1-channel head convs): split the (channel, dy) steps over 8 waves instead
         ma.ksplit = 1;
         mtile.W = 8;
         t.threads = 8 * 64;

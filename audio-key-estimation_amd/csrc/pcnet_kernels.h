@@ -364,7 +364,8 @@ struct MfmaArgs {
     int h1_magic;         // ceil(2^16 / h1): (row * h1_magic) >> 16 == row / h1 for the row counts used here
     int dbg;              // ablation (AKE_ABLATE): 1 = skip the MFMA steps, 2 = skip the staging loads (results wrong, timing only)
     int ksplit;           // 1: the layer has <= MT M-tiles per workgroup (1-channel head convs): all waves share them and
-                          //    split the input channels (ci = wave, wave + W, ...); partial sums are reduced through LDS
+                          //    split the (channel, dy) steps of every chunk (step = wave, wave + W, ...); partial sums are
+                          //    reduced through LDS
 };
 
 template <int KU, int NT, int MT>
@@ -418,8 +419,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
     const float* __restrict__ bglob = a.w + (static_cast<long long>(ngrp) * NT) * 64;
     const int bstep = ma.ntiles_total * 64;                              // floats per k-step in global memory
     float* const ldsB = lds + ma.cin_chunk * cstride;
-    const int cstep = ma.ksplit ? nw : 1;
-    int ci = ma.ksplit ? wave : 0;                                       // next input channel of this wave
+    const int sstride = ma.ksplit ? nw : 1;                              // this wave takes every sstride-th step of a chunk
 
     auto load_a = [&](float (&A)[KS][MT], int soff) {
 #pragma unroll
@@ -521,23 +521,26 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
             }
         }
         __syncthreads();
-        if (!active || ci >= c_lo + cc || ma.dbg == 1) continue;
-        // ---- this wave's steps of the chunk: (channel, dy) pairs, fragments fetched one step ahead into a ping-pong pair ----
-        const int nsteps = ((c_lo + cc - ci + cstep - 1) / cstep) * KH;
-        // prefetch cursor (wave-uniform), advanced with adds only: a_off / b_off are LDS float offsets of the step
+        if (!active || ma.dbg == 1) continue;
+        // ---- this wave's steps of the chunk: step index -> (channel cl, row dy); fragments are fetched one step ahead.
+        //      The cursor is wave-uniform and advanced with adds only: a_off / b_off are LDS float offsets. ----
         constexpr int GF = KS * NT * 64;
-        int pf_ci = ci, pf_dy = 0;
-        int a_off = (ci - c_lo) * cstride, b_off = (ci - c_lo) * KH * GF;
-        const int a_jump = cstep * cstride - (KH - 1) * Tp, b_jump = ((cstep - 1) * KH + 1) * GF;
+        const int steps_total = cc * KH;
+        const int first = ma.ksplit ? wave : 0;
+        if (first >= steps_total) continue;
+        const int nsteps = (steps_total - first + sstride - 1) / sstride;
+        int pf_dy = first, pf_cl = 0;
+        while (pf_dy >= KH) { pf_dy -= KH; ++pf_cl; }
+        int a_off = pf_cl * cstride + pf_dy * Tp, b_off = first * GF;
         float Ac[KS][MT], Bc[KS][NT];
         load_a(Ac, a_off);
         load_b(Bc, b_off);
         for (int st = 0; st < nsteps; ++st) {
-            // branch-free software pipeline: fetch step st+1 (the last iteration re-fetches its own step), then the
-            // MFMAs of step st
-            if (st + 1 < nsteps) {
-                if (++pf_dy == KH) { pf_dy = 0; pf_ci += cstep; a_off += a_jump; b_off += b_jump; }
-                else { a_off += Tp; b_off += GF; }
+            if (st + 1 < nsteps) {                                       // (the last iteration re-fetches its own step)
+                pf_dy += sstride;
+                a_off += sstride * Tp;
+                b_off += sstride * GF;
+                while (pf_dy >= KH) { pf_dy -= KH; a_off += cstride - KH * Tp; }
             }
             float An[KS][MT], Bn[KS][NT];
             load_a(An, a_off);
@@ -551,9 +554,6 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
                 for (int nt = 0; nt < NT; ++nt) Bc[s][nt] = Bn[s][nt];
             }
         }
-        // the cursor stopped on this chunk's last step; the wave's next channel is one stride further
-        pf_ci += cstep;
-        ci = pf_ci;
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
