@@ -3,8 +3,11 @@
 // Replaces librosa.cqt + abs + log1p (KeyDataset.py:485,490-499).  Specification: the
 // direct-form transform of oracle/cqt_oracle.py.  Evaluation (MI355X-first):
 //
-//   1. cqt_decimate_kernel   y_{o+1}[m] = sum_j h[j] y_o[2m+j]   (Kaiser half-band, LDS-staged,
-//                            coalesced streaming; one launch per octave step)
+//   1. cqt_decimate_kernel   y_{o+1}[m] = sum_j h[j] y_o[2m+j]   (Kaiser half-band; one launch per octave
+//                            step).  HBM-bound streaming: 16-byte loads, the tile is de-interleaved into
+//                            even / odd samples in LDS (a half-band filter touches the centre sample and
+//                            odd offsets only), each thread produces 4 outputs from 8 ds_read_b128 and
+//                            stores them with one 16-byte store.
 //   2. cqt_bank_kernel       for every (octave o, frame t): the 36 bins of the octave are
 //                            <=277-tap complex FIRs on the 2^o-decimated signal.  A frame centre
 //                            t*hop is not a multiple of 2^o in general, so the plan holds one
@@ -17,7 +20,8 @@
 //                            |.| (re/im pair via one lane shuffle) and log1p are the epilogue.
 //
 // HBM layout: audio [B][stride] f32 (caller's), y_o [B][len_o] f32 in the workspace
-// (len_o = ceil(n/2^o) + 2*Hh, sample m stored at m + Hh), out [B][n_bins][out_frames] f32.
+// (sample m stored at m + pad, pad = Hh rounded up to 4; len_o = ceil(n/2^o) + 2*pad rounded up to 4, so every
+// row and every 512-output tile starts 16-byte aligned), out [B][n_bins][out_frames] f32.
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -34,7 +38,7 @@ constexpr int kChunkBlocks = 4; // 16-tap blocks staged in LDS at a time
 constexpr int kMaxOddTaps = 32; // decimator: odd taps 1,3,..,2*32-1
 constexpr double kC1 = 32.70319566257483;
 constexpr int kDecimOutPerBlock = 512;
-constexpr int kDecimThreads = 256;
+constexpr int kDecimThreads = 128;   // x 4 outputs per thread
 
 struct OctDesc {         // one octave of the filter bank in MFMA fragment order
     int k0;              // first CQT bin of the octave
@@ -80,39 +84,68 @@ struct ake_cqt_plan {
 // device code
 // ------------------------------------------------------------------------------------------
 
-// y_out[m] = h0*y[2m] + sum_{j odd} h[j]*(y[2m-j] + y[2m+j]);  in: sample s at in[s - in_lo].
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// y_out[m] = h0*y[2m] + sum_{j odd} h[j]*(y[2m-j] + y[2m+j]);  input sample s lives at in[s + in_pad], output sample m
+// at out[m + out_pad].  One workgroup = 512 consecutive output indices of one clip.  Requires Hh % 4 == 3 and
+// out_pad = Hh + 1 (checked by the host): then the first input the tile needs sits at local position 1 of a 16-byte
+// aligned window, centres are the even local positions and all filter taps the odd ones.
+template <int NODD>
 __global__ __launch_bounds__(kDecimThreads) void cqt_decimate_kernel(
-    const float* __restrict__ in, long long in_stride, int in_lo, int in_count,
-    float* __restrict__ out, long long out_stride, int out_lo, int out_count, DecimTaps taps) {
-    __shared__ float tile[2 * kDecimOutPerBlock + 2 * (2 * kMaxOddTaps) + 8];
+    const float* __restrict__ in, long long in_stride, int in_pad, int in_count,
+    float* __restrict__ out, long long out_stride, int out_pad, int out_count, DecimTaps taps) {
+    constexpr int H = 2 * NODD - 1;
+    constexpr int NLOC = 2 * kDecimOutPerBlock + 2 * H + 2;         // local positions 0 .. NLOC-1 (position 1 = first needed)
+    constexpr int NV4 = (NLOC + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float ev[NV4 * 2 + 4];   // even local positions (centres)
+    __shared__ __attribute__((aligned(16))) float od[NV4 * 2 + 4];   // odd local positions (taps)
     const int clip = blockIdx.y;
-    const int m0 = out_lo + blockIdx.x * kDecimOutPerBlock;     // first output sample of the block
-    const int H = taps.half_len;
-    const int s0 = 2 * m0 - H;                                   // first input sample needed
-    const int need = 2 * kDecimOutPerBlock + 2 * H;
+    const int o0 = blockIdx.x * kDecimOutPerBlock;                   // first output index of the tile
+    const int m0 = o0 - out_pad;                                     // ... and its sample number
+    const int i_al = 2 * m0 - H + in_pad - 1;                        // input index of local position 0 (multiple of 4)
     const float* src = in + clip * in_stride;
-    for (int i = threadIdx.x; i < need; i += kDecimThreads) {
-        const int idx = s0 + i - in_lo;
-        tile[i] = (idx >= 0 && idx < in_count) ? src[idx] : 0.f;
+    for (int v = threadIdx.x; v < NV4; v += kDecimThreads) {
+        const int i0 = i_al + 4 * v;
+        float x0, x1, x2, x3;
+        if (i0 >= 0 && i0 + 4 <= in_count) {
+            const f4u t = *reinterpret_cast<const f4u*>(src + i0);
+            x0 = t[0]; x1 = t[1]; x2 = t[2]; x3 = t[3];
+        } else {
+            x0 = (i0 >= 0 && i0 < in_count) ? src[i0] : 0.f;
+            x1 = (i0 + 1 >= 0 && i0 + 1 < in_count) ? src[i0 + 1] : 0.f;
+            x2 = (i0 + 2 >= 0 && i0 + 2 < in_count) ? src[i0 + 2] : 0.f;
+            x3 = (i0 + 3 >= 0 && i0 + 3 < in_count) ? src[i0 + 3] : 0.f;
+        }
+        *reinterpret_cast<float2*>(ev + 2 * v) = make_float2(x0, x2);
+        *reinterpret_cast<float2*>(od + 2 * v) = make_float2(x1, x3);
     }
     __syncthreads();
-    float* dst = out + clip * out_stride;
+    // outputs 4*tid .. 4*tid+3 of the tile: centre of output r at even slot 4*tid + r + NODD, taps at odd slots 4*tid + r + i
+    const int tid = threadIdx.x;
+    if (o0 + 4 * tid >= out_count) return;
+    float O[2 * NODD + 4], C[4];
+    {
+        const float4* po = reinterpret_cast<const float4*>(od + 4 * tid);
 #pragma unroll
-    for (int r = 0; r < kDecimOutPerBlock / kDecimThreads; ++r) {
-        const int mi = threadIdx.x + r * kDecimThreads;
-        const int o_idx = m0 + mi - out_lo;
-        if (o_idx >= out_count) continue;
-        const int c = 2 * mi + H;                                // tile index of sample 2m
-        float acc = taps.h0 * tile[c];
-        for (int q = 0; q < taps.n_odd; ++q) {
-            const int j = 2 * q + 1;
-            acc = fmaf(taps.hodd[q], tile[c - j] + tile[c + j], acc);
+        for (int i = 0; i < (2 * NODD + 4) / 4; ++i) {
+            const float4 t = po[i];
+            O[4 * i] = t.x; O[4 * i + 1] = t.y; O[4 * i + 2] = t.z; O[4 * i + 3] = t.w;
         }
-        dst[o_idx] = acc;
+        const float4 c = *reinterpret_cast<const float4*>(ev + 4 * tid + NODD);
+        C[0] = c.x; C[1] = c.y; C[2] = c.z; C[3] = c.w;
     }
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float acc = taps.h0 * C[k];
+#pragma unroll
+        for (int q = 0; q < NODD; ++q) acc = fmaf(taps.hodd[q], O[k + NODD - 1 - q] + O[k + NODD + q], acc);
+        r[k] = acc;
+    }
+    *reinterpret_cast<float4*>(out + clip * out_stride + o0 + 4 * tid) = make_float4(r[0], r[1], r[2], r[3]);
 }
 
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Workgroup = (frame t, octave o, 64 clips): 4 waves x one 16-clip M-tile, all N-tiles of the octave.
@@ -227,9 +260,11 @@ std::vector<double> kaiser_halfband(int half_len, double beta) {
     return h;
 }
 
-int len_store(const ake_cqt_plan* p, int o, int64_t n) {   // samples stored for octave o >= 1
+int pad_of(const ake_cqt_plan* p) { return p->half_len + 1; }   // Hh % 4 == 3  ->  multiple of 4
+
+int len_store(const ake_cqt_plan* p, int o, int64_t n) {   // floats stored per clip for octave o >= 1 (multiple of 4)
     const int64_t l = (n + (1ll << o) - 1) >> o;
-    return static_cast<int>(l) + 2 * p->half_len;
+    return (static_cast<int>(l) + 2 * pad_of(p) + 3) / 4 * 4;
 }
 
 }  // namespace
@@ -262,8 +297,8 @@ int ake_cqt_plan_create(const ake_cqt_config* cfg_in, ake_cqt_plan** out) {
     AKE_REQUIRE(cfg.sample_rate > 0 && cfg.hop_length > 0 && cfg.n_bins > 0, AKE_ERR_INVALID, "cqt: bad rate/hop/bins");
     AKE_REQUIRE(cfg.n_bins % cfg.bins_per_octave == 0 && cfg.bins_per_octave <= kTileBins * kMaxTiles, AKE_ERR_UNSUPPORTED,
                 "cqt: bins_per_octave must divide n_bins and be <= %d", kTileBins * kMaxTiles);
-    AKE_REQUIRE(cfg.decim_half_len % 2 == 1 && (cfg.decim_half_len + 1) / 2 <= kMaxOddTaps, AKE_ERR_INVALID,
-                "cqt: decim_half_len must be odd and <= %d", 2 * kMaxOddTaps - 1);
+    AKE_REQUIRE(cfg.decim_half_len == 15 || cfg.decim_half_len == 23 || cfg.decim_half_len == 31, AKE_ERR_INVALID,
+                "cqt: decim_half_len must be 15, 23 or 31 (half-band taps, 4k+3 keeps every tile 16-byte aligned)");
     const int bpo = cfg.bins_per_octave;
     const int n_oct = cfg.n_bins / bpo;
     AKE_REQUIRE(n_oct <= kMaxOct, AKE_ERR_INVALID, "cqt: too many octaves (%d)", n_oct);
@@ -409,12 +444,17 @@ int ake_cqt_logmag_f32(const ake_cqt_plan* p, const float* audio, int batch, int
         float* y = c.take<float>(static_cast<size_t>(batch) * ls);
         call.x[o] = y;
         call.stride[o] = ls;
-        call.lo[o] = -p->half_len;
+        call.lo[o] = -pad_of(p);
         call.count[o] = ls;
         dim3 grid((ls + kDecimOutPerBlock - 1) / kDecimOutPerBlock, batch);
         ake::ProfScope ps("cqt_decimate_kernel", stream);
-        hipLaunchKernelGGL(cqt_decimate_kernel, grid, dim3(kDecimThreads), 0, stream, call.x[o - 1], call.stride[o - 1],
-                           call.lo[o - 1], call.count[o - 1], y, static_cast<long long>(ls), -p->half_len, ls, p->taps);
+        const int in_pad = -call.lo[o - 1];
+#define AKE_DECIM(N_) hipLaunchKernelGGL((cqt_decimate_kernel<N_>), grid, dim3(kDecimThreads), 0, stream, call.x[o - 1], \
+                                         call.stride[o - 1], in_pad, call.count[o - 1], y, static_cast<long long>(ls), pad_of(p), ls, p->taps)
+        if (p->half_len == 15) AKE_DECIM(8);
+        else if (p->half_len == 23) AKE_DECIM(12);
+        else AKE_DECIM(16);
+#undef AKE_DECIM
     }
     if (out_frames > T)
         AKE_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float) * batch * p->cfg.n_bins * out_frames, stream));
