@@ -154,7 +154,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // W fragments are packed on the host with the same tap permutation.
 __global__ __launch_bounds__(256) void cqt_bank_kernel(
     BankCall call, const OctDesc* __restrict__ octs, const float* __restrict__ table,
-    int batch, int hop, int hop_twos, float* __restrict__ out, long long out_clip_stride, int out_frames) {
+    int batch, int hop, int hop_twos, float* __restrict__ out, long long out_clip_stride, int n_bins_total) {
     __shared__ __attribute__((aligned(16))) float ldsB[kChunkBlocks * 4 * kMaxTiles * 64];
     const int t = blockIdx.x;
     const int o = blockIdx.y;
@@ -223,9 +223,33 @@ __global__ __launch_bounds__(256) void cqt_bank_kernel(
             const float v2 = acc[j][reg] * acc[j][reg];
             const float m2 = v2 + __shfl_xor(v2, 1);
             const int cl = blockIdx.z * 64 + wave * 16 + 4 * q + reg;
+            // scratch layout [clip][frame][bin]: the 8 bins of a tile are 32 contiguous bytes, the octave 144
             if ((r16 & 1) == 0 && j < g.n_tiles && b < g.n_bins && cl < batch)
-                out[cl * out_clip_stride + static_cast<long long>(g.k0 + b) * out_frames + t] = log1pf(sqrtf(m2));
+                out[cl * out_clip_stride + static_cast<long long>(t) * n_bins_total + g.k0 + b] = log1pf(sqrtf(m2));
         }
+    }
+}
+
+// [clip][frame][bin] scratch -> [clip][bin][out_frames] (the reference layout), zero-filling frames >= T
+// (KeyDataset.py:245 padding).  32x32 LDS tile transpose: coalesced on both sides.
+__global__ __launch_bounds__(256) void cqt_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int T,
+                                                            int n_bins, int out_frames) {
+    __shared__ float tile[32][33];
+    const int clip = blockIdx.z;
+    const int k0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    const float* s = src + static_cast<long long>(clip) * T * n_bins;
+    float* d = dst + static_cast<long long>(clip) * n_bins * out_frames;
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int t = t0 + ty + r, k = k0 + tx;
+        tile[ty + r][tx] = (t < T && k < n_bins) ? s[static_cast<long long>(t) * n_bins + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int k = k0 + ty + r, t = t0 + tx;
+        if (k < n_bins && t < out_frames) d[static_cast<long long>(k) * out_frames + t] = tile[tx][ty + r];
     }
 }
 
@@ -419,6 +443,7 @@ size_t ake_cqt_workspace_bytes(const ake_cqt_plan* p, int batch, int64_t n_sampl
     if (!p || batch <= 0 || n_samples <= 0) return 0;
     ake::Carver c(nullptr, 0);
     for (int o = 1; o < p->n_oct; ++o) c.take<float>(static_cast<size_t>(batch) * len_store(p, o, n_samples));
+    c.take<float>(static_cast<size_t>(batch) * (1 + n_samples / p->cfg.hop_length) * p->cfg.n_bins);   // [clip][frame][bin] scratch
     return ake::align_up(c.off, 256);
 }
 
@@ -456,14 +481,18 @@ int ake_cqt_logmag_f32(const ake_cqt_plan* p, const float* audio, int batch, int
         else AKE_DECIM(16);
 #undef AKE_DECIM
     }
-    if (out_frames > T)
-        AKE_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float) * batch * p->cfg.n_bins * out_frames, stream));
+    float* scratch = c.take<float>(static_cast<size_t>(batch) * T * p->cfg.n_bins);
     {
         dim3 grid(static_cast<unsigned>(T), p->n_oct, (batch + 63) / 64);
         ake::ProfScope ps("cqt_bank_kernel", stream);
         hipLaunchKernelGGL(cqt_bank_kernel, grid, dim3(256), 0, stream, call, p->octs_dev, p->table_dev, batch,
-                           p->cfg.hop_length, p->hop_twos, out,
-                           static_cast<long long>(p->cfg.n_bins) * out_frames, static_cast<int>(out_frames));
+                           p->cfg.hop_length, p->hop_twos, scratch, static_cast<long long>(T) * p->cfg.n_bins, p->cfg.n_bins);
+    }
+    {
+        dim3 grid((p->cfg.n_bins + 31) / 32, static_cast<unsigned>((out_frames + 31) / 32), batch);
+        ake::ProfScope ps("cqt_transpose_kernel", stream);
+        hipLaunchKernelGGL(cqt_transpose_kernel, grid, dim3(256), 0, stream, scratch, out, static_cast<int>(T), p->cfg.n_bins,
+                           static_cast<int>(out_frames));
     }
     AKE_HIP_CHECK(hipGetLastError());
     return AKE_OK;
