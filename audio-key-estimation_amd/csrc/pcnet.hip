@@ -76,6 +76,14 @@ struct ake_pcnet {
     std::vector<PackedConv> up;                   // per layer (index 0 unused)
     std::vector<std::vector<PackedConv>> p2p;     // per layer (index 0 empty)
     std::vector<PackedConv> head_key, head_tonic, head_genre;
+
+    // training-mode packs: raw convolution weights (no BatchNorm folding) + the BatchNorm layers themselves
+    std::vector<PackedConv> semi_t, up_t, head_key_t, head_tonic_t, head_genre_t;
+    std::vector<std::vector<PackedConv>> pc2pc_t, p2p_t;
+    struct BnLayer { std::string name; int C; size_t gamma_off, beta_off; int ch_off; };
+    std::vector<BnLayer> bns;
+    std::map<std::string, int> bn_index;
+    int bn_channels = 0;
 };
 
 namespace {
@@ -257,7 +265,8 @@ struct Src {
 // One convolution of the net.  `kind`: 0 pitch conv (7x7 circular both axes), 1 equivariant pitch-class
 // conv (12 x k, rows circular), 2 genre conv (kh in {1,2}, rows valid).
 int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int batch, int H, int T_in, bool same_time,
-             bool lrelu, float* dst, int dst_ctot, int dst_coff, hipStream_t s, const char* name) {
+             bool lrelu, float* dst, int dst_ctot, int dst_coff, hipStream_t s, const char* name,
+             const float* in_affine = nullptr, double* stats = nullptr) {
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
     AKE_REQUIRE(pc.kw == 7, AKE_ERR_UNSUPPORTED, "conv: kernel width %d not built (only 7)", pc.kw);
@@ -278,6 +287,7 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
     a.w = n->blob_dev + pc.w_off; a.bias = n->blob_dev + pc.b_off; a.cout = pc.cout;
     a.dst = dst; a.dst_coff = dst_coff; a.dst_clip_stride = static_cast<long long>(dst_ctot) * a.H_out * a.T_out;
     a.lrelu = lrelu ? 1 : 0;
+    a.in_affine = in_affine; a.stats = stats;
     Tile t;
     MTile mtile;
     static const int mt_env = std::getenv("AKE_MT") ? std::atoi(std::getenv("AKE_MT")) : 3;
@@ -339,10 +349,16 @@ struct Buffers {           // workspace carve
     std::vector<int> Tl;    // frames at layer i
     int Tf = 0;             // frames after the last layer
     size_t bytes = 0;
+    // training-mode forward only: BatchNorm statistics, raw semitone-conv outputs and the pending-affine table
+    // ([C][3] = scale, shift, negative slope) of every buffer that can hold a raw (pre-BatchNorm) tensor
+    double* stats = nullptr;           // [bn_channels][2]
+    float* bstats = nullptr;           // [bn_channels][3] batch mean, biased variance, element count
+    std::vector<float*> semi_raw, aff_semi, aff_cat, aff_p2pin, aff_pa, aff_pb, aff_pca, aff_pcb;
+    float* aff_hid[3] = {nullptr, nullptr, nullptr};
 };
 
 // chunk = clips per pitch-stream pass, batch = clips of the call (tail buffers)
-int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws, Buffers* b) {
+int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws, Buffers* b, bool train = false) {
     const auto& c = n->cfg;
     const int L = c.num_layers, P = c.pitches;
     ake::Carver cv(ws, 0);
@@ -374,6 +390,24 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
     b->hid_k = cv.take<float>(2 * hid); b->hid_t = cv.take<float>(2 * hid);
     b->map_k = cv.take<float>(B * 12 * b->Tf); b->map_t = cv.take<float>(B * 12 * b->Tf);
     if (c.genre) { b->hid_g = cv.take<float>(2 * hid); b->map_g = cv.take<float>(B * 12 * b->Tf); }
+    if (train) {
+        b->stats = cv.take<double>(static_cast<size_t>(n->bn_channels) * 2);
+        b->bstats = cv.take<float>(static_cast<size_t>(n->bn_channels) * 3);
+        for (auto* v : {&b->semi_raw, &b->aff_semi, &b->aff_cat, &b->aff_p2pin, &b->aff_pa, &b->aff_pb, &b->aff_pca, &b->aff_pcb}) v->assign(L + 1, nullptr);
+        for (int i = 0; i < L; ++i) {
+            const auto& d = n->dims[i];
+            const int cs = i == 0 ? 1 : d.out_p, pc_out = i == 0 ? c.n_filters : d.out_pc;
+            b->semi_raw[i] = cv.take<float>(B * cs * (P / 3) * b->Tl[i]);
+            b->aff_semi[i] = cv.take<float>(3 * cs);
+            b->aff_pca[i] = cv.take<float>(3 * pc_out); b->aff_pcb[i] = cv.take<float>(3 * pc_out);
+            if (i >= 1) {
+                b->aff_cat[i] = cv.take<float>(3 * (d.prev_pc + d.out_p));
+                b->aff_p2pin[i] = cv.take<float>(3 * (d.prev_pc + d.prev_p));
+                b->aff_pa[i] = cv.take<float>(3 * d.out_p); b->aff_pb[i] = cv.take<float>(3 * d.out_p);
+            }
+        }
+        for (int h = 0; h < 3; ++h) b->aff_hid[h] = cv.take<float>(3 * 2 * 2 * n->final_ch);   // two ping-pong halves
+    }
     b->bytes = ake::align_up(cv.off, 256);
     return AKE_OK;
 }
@@ -501,28 +535,38 @@ int ake_pcnet_set_tensor(ake_pcnet* n, const char* name, const float* host_data,
     return AKE_OK;
 }
 
-int ake_pcnet_finalize(ake_pcnet* n) {
-    AKE_REQUIRE(n, AKE_ERR_INVALID, "finalize: null handle");
-    for (size_t i = 0; i < n->specs.size(); ++i)
-        AKE_REQUIRE(n->host[i].set, AKE_ERR_STATE, "finalize: missing key '%s' (load_state_dict strict=True)", n->specs[i].name.c_str());
+// Packs every convolution of the net into the blob.  train == false: eval-mode BatchNorm folded into w/b.
+// train == true: raw weights; each BatchNorm is registered as a layer of its own (gamma/beta in the blob).
+static void build_packs(ake_pcnet* n, bool train) {
     const auto& c = n->cfg;
     const int L = c.num_layers, k = c.kernel_size;
-    n->blob.clear();
-    n->semi.assign(L, PackedConv()); n->up.assign(L, PackedConv());
-    n->pc2pc.assign(L, {}); n->p2p.assign(L, {});
-    n->head_key.clear(); n->head_tonic.clear(); n->head_genre.clear();
+    auto& semi = train ? n->semi_t : n->semi;
+    auto& up = train ? n->up_t : n->up;
+    auto& pc2pc = train ? n->pc2pc_t : n->pc2pc;
+    auto& p2p = train ? n->p2p_t : n->p2p;
+    semi.assign(L, PackedConv()); up.assign(L, PackedConv());
+    pc2pc.assign(L, {}); p2p.assign(L, {});
+    auto bn = [&](const std::string& prefix, int C) -> std::string {
+        if (!train) return prefix;
+        ake_pcnet::BnLayer l;
+        l.name = prefix; l.C = C; l.ch_off = n->bn_channels;
+        n->blob.resize(ake::align_up(n->blob.size(), 64));
+        l.gamma_off = n->blob.size();
+        for (float v : T(n, prefix + ".weight")) n->blob.push_back(v);
+        l.beta_off = n->blob.size();
+        for (float v : T(n, prefix + ".bias")) n->blob.push_back(v);
+        n->bn_index[prefix] = static_cast<int>(n->bns.size());
+        n->bns.push_back(l);
+        n->bn_channels += C;
+        return "";
+    };
     for (int i = 0; i < L; ++i) {
         const std::string m = "model." + std::to_string(i) + ".";
         const LayerDims& d = n->dims[i];
         const int cs = i == 0 ? 1 : d.out_p;
-        n->semi[i] = fold_pack(n, m + "pool_semi", m + "pool_semi_b", cs, cs, 3, 3);
-        const int pc_in = i == 0 ? 1 : d.out_p + d.prev_pc, pc_out = i == 0 ? c.n_filters : d.out_pc;
-        for (int j = 0; j < c.conv_layers; ++j)
-            n->pc2pc[i].push_back(fold_pack(n, m + "pc2pc.layer." + std::to_string(3 * j) + ".conv2d",
-                                            m + "pc2pc.layer." + std::to_string(3 * j + 1), pc_out, j == 0 ? pc_in : pc_out, 12, k));
-        if (i >= 1) {
+        if (i >= 1) {   // creation order mirrors the forward order: up_sixth, p2p, pool_semi, pc2pc
             std::vector<double> w, b;
-            fold(n, m + "up_sixth.weight", m + "up_sixth.bias", m + "up_sixth_b", d.prev_pc,
+            fold(n, m + "up_sixth.weight", m + "up_sixth.bias", bn(m + "up_sixth_b", d.prev_pc), d.prev_pc,
                  static_cast<size_t>(d.prev_pc) * 3, true, d.prev_pc, w, b);
             PackedConv u;
             u.cin = u.cout = d.prev_pc; u.kh = 3; u.kw = 1;
@@ -532,32 +576,62 @@ int ake_pcnet_finalize(ake_pcnet* n) {
             n->blob.resize(ake::align_up(n->blob.size(), 64));
             u.b_off = n->blob.size();
             for (double v : b) n->blob.push_back(static_cast<float>(v));
-            n->up[i] = u;
+            up[i] = u;
             for (int j = 0; j < c.conv_layers; ++j)
-                n->p2p[i].push_back(fold_pack(n, m + "p2p.layer." + std::to_string(3 * j), m + "p2p.layer." + std::to_string(3 * j + 1),
-                                              d.out_p, j == 0 ? d.prev_pc + d.prev_p : d.out_p, k, k));
+                p2p[i].push_back(fold_pack(n, m + "p2p.layer." + std::to_string(3 * j), bn(m + "p2p.layer." + std::to_string(3 * j + 1), d.out_p),
+                                           d.out_p, j == 0 ? d.prev_pc + d.prev_p : d.out_p, k, k));
         }
+        semi[i] = fold_pack(n, m + "pool_semi", bn(m + "pool_semi_b", cs), cs, cs, 3, 3);
+        const int pc_in = i == 0 ? 1 : d.out_p + d.prev_pc, pc_out = i == 0 ? c.n_filters : d.out_pc;
+        for (int j = 0; j < c.conv_layers; ++j)
+            pc2pc[i].push_back(fold_pack(n, m + "pc2pc.layer." + std::to_string(3 * j) + ".conv2d",
+                                         bn(m + "pc2pc.layer." + std::to_string(3 * j + 1), pc_out), pc_out, j == 0 ? pc_in : pc_out, 12, k));
     }
     for (const char* head : {"tonic_classifier", "key_classifier", "genre_classifier"}) {
         const bool g = std::strcmp(head, "genre_classifier") == 0;
         if (g && !c.genre) continue;
-        auto& vec = g ? n->head_genre : (std::strcmp(head, "key_classifier") == 0 ? n->head_key : n->head_tonic);
+        const bool is_key = std::strcmp(head, "key_classifier") == 0;
+        auto& vec = train ? (g ? n->head_genre_t : (is_key ? n->head_key_t : n->head_tonic_t))
+                          : (g ? n->head_genre : (is_key ? n->head_key : n->head_tonic));
+        vec.clear();
         int ch = n->final_ch;
         for (int i = 0; i < c.head_layers; ++i) {
             const std::string base = std::string(head) + "." + std::to_string(3 * i) + (g ? "" : ".conv2d");
             if (i == c.head_layers - 1) vec.push_back(fold_pack(n, base, "", 1, ch, g ? 2 : 12, k));
             else {
                 const int co = i == 0 ? 2 * ch : ch;
-                vec.push_back(fold_pack(n, base, std::string(head) + "." + std::to_string(3 * i + 1), co, ch, g ? 1 : 12, k));
+                vec.push_back(fold_pack(n, base, bn(std::string(head) + "." + std::to_string(3 * i + 1), co), co, ch, g ? 1 : 12, k));
                 ch = co;
             }
         }
     }
+}
+
+int ake_pcnet_finalize(ake_pcnet* n) {
+    AKE_REQUIRE(n, AKE_ERR_INVALID, "finalize: null handle");
+    for (size_t i = 0; i < n->specs.size(); ++i)
+        AKE_REQUIRE(n->host[i].set, AKE_ERR_STATE, "finalize: missing key '%s' (load_state_dict strict=True)", n->specs[i].name.c_str());
+    n->blob.clear();
+    n->bns.clear(); n->bn_index.clear(); n->bn_channels = 0;
+    build_packs(n, false);
+    build_packs(n, true);
     n->blob.resize(ake::align_up(n->blob.size() + 64, 64), 0.f);
     if (n->blob_dev) { (void)hipFree(n->blob_dev); n->blob_dev = nullptr; }
     AKE_HIP_CHECK(hipMalloc(&n->blob_dev, n->blob.size() * sizeof(float)));
     AKE_HIP_CHECK(hipMemcpy(n->blob_dev, n->blob.data(), n->blob.size() * sizeof(float), hipMemcpyHostToDevice));
     n->finalized = true;
+    return AKE_OK;
+}
+
+// BatchNorm layers of the training-mode forward, in forward order (valid after ake_pcnet_create; channel counts only
+// need the configuration, names are the reference module paths, e.g. "model.1.p2p.layer.1").
+int ake_pcnet_num_bn(const ake_pcnet* n) { return n ? static_cast<int>(n->bns.size()) : 0; }
+
+int ake_pcnet_bn_info(const ake_pcnet* n, int index, const char** name, int* channels, int* channel_offset) {
+    AKE_REQUIRE(n && index >= 0 && index < static_cast<int>(n->bns.size()), AKE_ERR_INVALID, "bn_info: index out of range (finalize first)");
+    if (name) *name = n->bns[index].name.c_str();
+    if (channels) *channels = n->bns[index].C;
+    if (channel_offset) *channel_offset = n->bns[index].ch_off;
     return AKE_OK;
 }
 
@@ -568,186 +642,327 @@ size_t ake_pcnet_workspace_bytes(const ake_pcnet* n, int batch, int frames) {
     return b.bytes;
 }
 
-// Phase A, whole batch: layer 0 (semitone conv + octave fold + pc2pc, models.py:361-369) and layer 1's up_sixth
-// (models.py:372-374).  These are pitch-class sized (12 or 36 rows), so they are launched once for all clips.
-static int forward_entry(const ake_pcnet* n, Buffers& b, const float* mel, int B, hipStream_t s) {
-    const auto& c = n->cfg;
-    const int L = c.num_layers, P = c.pitches;
-    const int T0 = b.Tl[0];
-    int rc;
-    if ((rc = run_semi(n, n->semi[0], mel, B, P, T0, b.fold0, 1, 0, s, "semi_fold_kernel/L0"))) return rc;
-    if (L == 1) return AKE_OK;                               // its pc2pc runs in the tail
-    const LayerDims& d1 = n->dims[1];
-    const int ctot1 = d1.prev_pc + d1.out_p;
-    const float* src = b.fold0;
-    int cin = 1;
-    for (int j = 0; j < c.conv_layers; ++j) {
-        const bool lastj = j == c.conv_layers - 1;           // the last conv writes channels [0, nf) of layer 1's concat buffer
-        float* dst = lastj ? b.cat[1] : ((j & 1) ? b.pcb[0] : b.pca[0]);
-        if ((rc = run_conv(n, n->pc2pc[0][j], 1, Src{src, cin, nullptr, 0, 0}, B, 12, T0, true, true, dst,
-                           lastj ? ctot1 : c.n_filters, 0, s, "conv_mfma_kernel/pc2pc0")))
-            return rc;
-        src = dst; cin = c.n_filters;
-    }
-    const long long total = static_cast<long long>(B) * d1.prev_pc * 36 * T0;
-    ake::ProfScope ps("up_sixth_kernel", s);
-    hipLaunchKernelGGL(up_sixth_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.cat[1],
-                       static_cast<long long>(ctot1) * 12 * T0, n->blob_dev + n->up[1].w_off, n->blob_dev + n->up[1].b_off,
-                       b.psix[1], d1.prev_pc, T0, total);
-    return AKE_OK;
+size_t ake_pcnet_train_workspace_bytes(const ake_pcnet* n, int batch, int frames) {
+    if (!n || batch <= 0 || frames <= 0) return 0;
+    Buffers b;
+    if (plan_buffers(n, batch, batch, frames, nullptr, &b, true) != AKE_OK) return 0;   // batch statistics: no chunking
+    return b.bytes;
 }
 
-// Phase B, per chunk of clips [c0, c0+B): the pitch stream -- pitch convs -> semitone fold for every layer >= 1
-// (plus pc2pc / pooling / the next up_sixth for the inner layers of deeper nets).  Leaves the last layer's concat
-// buffer filled for these clips.
-static int forward_pitch_chunk(const ake_pcnet* n, Buffers& b, const float* mel, int c0, int B, hipStream_t s) {
-    const auto& c = n->cfg;
-    const int L = c.num_layers, P = c.pitches, tp = c.time_pool_size;
-    int rc;
-    const float* p_cur = mel;     // pitch stream [B][cp][P][T]
-    int cp = 1;
-    const float* pc_cur = nullptr;   // pitch-class stream of the previous layer (first channels of cat[i])
-    for (int i = 1; i < L; ++i) {
+namespace {
+
+// One forward pass.  In eval mode BatchNorm is folded into the convolutions and every tensor is final.  In training
+// mode a convolution followed by BatchNorm leaves its RAW output plus a pending (scale, shift, slope) table that the
+// next reader applies while loading: `aff` travels next to every tensor pointer below (null = nothing pending).
+struct Fwd {
+    const ake_pcnet* n;
+    Buffers& b;
+    hipStream_t s;
+    bool train;
+
+    int bn_of(const std::string& name) const { return n->bn_index.at(name); }
+
+    // launch BatchNorm finalisation of layer `bn` (count values per channel) into the affine table `aff_out`
+    void finalize_bn(int bn, double count, float* aff_out) {
+        const auto& l = n->bns[bn];
+        ake::ProfScope ps("bn_finalize_kernel", s);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((l.C + 63) / 64), dim3(64), 0, s, b.stats + 2 * l.ch_off, count,
+                           n->blob_dev + l.gamma_off, n->blob_dev + l.beta_off, aff_out, b.bstats + 3 * l.ch_off, l.C);
+        // the element count rides along for the unbiased running variance (written by the host-visible copy below)
+    }
+    void identity(float* aff, int C) {
+        hipLaunchKernelGGL(affine_identity_kernel, dim3((C + 63) / 64), dim3(64), 0, s, aff, C);
+    }
+
+    // conv (+BatchNorm `bn_name` + LeakyReLU unless bn_name is empty).  Returns via *aff_out_used whether dst is raw.
+    int conv(const PackedConv& pe, const PackedConv& pt, const std::string& bn_name, int kind, Src src, const float* in_aff,
+             int B, int H, int T_in, bool same, float* dst, int ctot, int coff, float* aff_dst, const char* name) {
+        if (!train) return run_conv(n, pe, kind, src, B, H, T_in, same, !bn_name.empty(), dst, ctot, coff, s, name);
+        const bool has_bn = !bn_name.empty();
+        const int bn = has_bn ? bn_of(bn_name) : -1;
+        int rc = run_conv(n, pt, kind, src, B, H, T_in, same, false, dst, ctot, coff, s, name, in_aff,
+                          has_bn ? b.stats + 2 * n->bns[bn].ch_off : nullptr);
+        if (rc) return rc;
+        if (has_bn) {
+            const int T_out = same ? T_in : T_in - pt.kw + 1;
+            const int H_out = kind == 2 ? H - pt.kh + 1 : H;
+            finalize_bn(bn, static_cast<double>(B) * H_out * T_out, aff_dst);
+        }
+        return AKE_OK;
+    }
+
+    // pool_semi (+BN+LReLU) + octave fold of `src` [B][C][P][T] into channels [coff, coff+C) of dst [B][ctot][12][T]
+    int semi(int layer, const float* src, const float* in_aff, int B, int P, int Tn, float* dst, int ctot, int coff, float* aff_cat_rows) {
+        const char* nm = layer == 0 ? "semi_fold_kernel/L0" : "semi_fold_kernel/L1+";
+        if (!train) return run_semi(n, n->semi[layer], src, B, P, Tn, dst, ctot, coff, s, nm);
+        const PackedConv& pc = n->semi_t[layer];
+        const int bn = bn_of("model." + std::to_string(layer) + ".pool_semi_b");
+        SemiTrainArgs ta;
+        SemiArgs& a = ta.s;
+        a.src = src; a.C = pc.cin; a.H = P; a.T = Tn;
+        a.src_clip_stride = static_cast<long long>(pc.cin) * P * Tn;
+        a.w = n->blob_dev + pc.w_off; a.bias = n->blob_dev + pc.b_off;
+        a.dst = b.semi_raw[layer]; a.dst_coff = 0; a.dst_clip_stride = 0;
+        a.n_strips = (Tn + TW - 1) / TW;
+        ta.in_affine = in_aff; ta.stats = b.stats + 2 * n->bns[bn].ch_off;
+        const int per_clip = 12 * a.n_strips;
+        const int threads = per_clip >= 256 ? 256 : (per_clip + 63) / 64 * 64;
+        dim3 grid((per_clip + threads - 1) / threads, pc.groups, B), block(threads);
+        {
+            ake::ProfScope ps("semi_conv_stats_kernel", s);
+            switch (pc.co) {
+                case 8: hipLaunchKernelGGL((semi_conv_stats_kernel<8>), grid, block, 0, s, ta); break;
+                case 4: hipLaunchKernelGGL((semi_conv_stats_kernel<4>), grid, block, 0, s, ta); break;
+                case 1: hipLaunchKernelGGL((semi_conv_stats_kernel<1>), grid, block, 0, s, ta); break;
+                default: ake::set_error("semi: bad CO"); return AKE_ERR_UNSUPPORTED;
+            }
+        }
+        finalize_bn(bn, static_cast<double>(B) * (P / 3) * Tn, b.aff_semi[layer]);
+        const long long total = static_cast<long long>(B) * pc.cin * 12 * Tn;
+        {
+            ake::ProfScope ps("fold_affine_kernel", s);
+            hipLaunchKernelGGL(fold_affine_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.semi_raw[layer],
+                               b.aff_semi[layer], dst, pc.cin, P / 36, Tn, ctot, coff, total);
+        }
+        if (aff_cat_rows) identity(aff_cat_rows, pc.cin);     // the folded channels are final activations
+        return AKE_OK;
+    }
+
+    void up_sixth(int layer, const float* src, long long src_clip_stride, const float* in_aff, int B, int C, int Tn, float* dst, float* aff_dst) {
+        const long long total = static_cast<long long>(B) * C * 36 * Tn;
+        if (!train) {
+            ake::ProfScope ps("up_sixth_kernel", s);
+            hipLaunchKernelGGL(up_sixth_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, src, src_clip_stride,
+                               n->blob_dev + n->up[layer].w_off, n->blob_dev + n->up[layer].b_off, dst, C, Tn, total);
+            return;
+        }
+        const int bn = bn_of("model." + std::to_string(layer) + ".up_sixth_b");
+        {
+            ake::ProfScope ps("up_sixth_train_kernel", s);
+            hipLaunchKernelGGL(up_sixth_train_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, src, src_clip_stride,
+                               in_aff, n->blob_dev + n->up_t[layer].w_off, n->blob_dev + n->up_t[layer].b_off, dst,
+                               b.stats + 2 * n->bns[bn].ch_off, C, Tn, total);
+        }
+        finalize_bn(bn, static_cast<double>(B) * 36 * Tn, aff_dst);
+    }
+
+    void time_pool(const float* src, const float* in_aff, int B, int C, int H, int Tn, float* dst, int ctot, int coff) {
+        const int tp = n->cfg.time_pool_size;
+        const long long total = static_cast<long long>(B) * C * H * (Tn / tp);
+        ake::ProfScope ps("time_pool_kernel", s);
+        if (train && in_aff)
+            hipLaunchKernelGGL(time_pool_affine_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, src, in_aff, dst, C, H,
+                               Tn, tp, ctot, coff, total);
+        else
+            hipLaunchKernelGGL(time_pool_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, src, dst, C, H, Tn, tp, ctot,
+                               coff, total);
+    }
+
+    // Phase A, whole batch: layer 0 (models.py:361-369) and layer 1's up_sixth (models.py:372-374).
+    int entry(const float* mel, int B) {
+        const auto& c = n->cfg;
+        const int L = c.num_layers, P = c.pitches, T0 = b.Tl[0];
+        int rc;
+        if ((rc = semi(0, mel, nullptr, B, P, T0, b.fold0, 1, 0, nullptr))) return rc;
+        if (L == 1) return AKE_OK;                               // its pc2pc runs in the tail
+        const LayerDims& d1 = n->dims[1];
+        const int ctot1 = d1.prev_pc + d1.out_p;
+        const float* src = b.fold0;
+        const float* src_aff = nullptr;
+        int cin = 1;
+        const std::string m = "model.0.pc2pc.layer.";
+        for (int j = 0; j < c.conv_layers; ++j) {
+            const bool lastj = j == c.conv_layers - 1;           // the last conv writes channels [0, nf) of layer 1's concat buffer
+            float* dst = lastj ? b.cat[1] : ((j & 1) ? b.pcb[0] : b.pca[0]);
+            float* aff = !train ? nullptr : (lastj ? b.aff_cat[1] : ((j & 1) ? b.aff_pcb[0] : b.aff_pca[0]));
+            if ((rc = conv(n->pc2pc[0][j], train ? n->pc2pc_t[0][j] : n->pc2pc[0][j], m + std::to_string(3 * j + 1), 1,
+                           Src{src, cin, nullptr, 0, 0}, src_aff, B, 12, T0, true, dst, lastj ? ctot1 : c.n_filters, 0, aff,
+                           "conv_mfma_kernel/pc2pc0")))
+                return rc;
+            src = dst; src_aff = aff; cin = c.n_filters;
+        }
+        // psix's BatchNorm lands in rows [prev_p, ..) of the pitch-conv input table (row 0.. = the pitch stream itself)
+        if (train) identity(b.aff_p2pin[1], d1.prev_p);
+        up_sixth(1, b.cat[1], static_cast<long long>(ctot1) * 12 * T0, train ? b.aff_cat[1] : nullptr, B, d1.prev_pc, T0, b.psix[1],
+                 train ? b.aff_p2pin[1] + 3 * d1.prev_p : nullptr);
+        return AKE_OK;
+    }
+
+    // Phase B, per chunk of clips [c0, c0+B): pitch convs -> semitone fold for every layer >= 1 (plus pc2pc / pooling /
+    // the next up_sixth for the inner layers of deeper nets).
+    int pitch_chunk(const float* mel, int c0, int B) {
+        const auto& c = n->cfg;
+        const int L = c.num_layers, P = c.pitches, tp = c.time_pool_size;
+        int rc;
+        const float* p_cur = mel;     // pitch stream [B][cp][P][T], always a final activation
+        int cp = 1;
+        const float* pc_cur = nullptr;
+        for (int i = 1; i < L; ++i) {
+            const int Ti = b.Tl[i];
+            const LayerDims& d = n->dims[i];
+            const bool last = i == L - 1;
+            const int ctot = d.prev_pc + d.out_p;
+            const std::string m = "model." + std::to_string(i) + ".";
+            float* cat = b.cat[i] + (last || i == 1 ? static_cast<size_t>(c0) * ctot * 12 * Ti : 0);
+            float* psix = b.psix[i] + (i == 1 ? static_cast<size_t>(c0) * d.prev_pc * 36 * Ti : 0);
+            if (i > 1) {   // layer 1's up_sixth ran batch-wide in entry(); pc_cur = pooled (final) features here
+                if (train) identity(b.aff_p2pin[i], d.prev_p);
+                up_sixth(i, pc_cur, static_cast<long long>(ctot) * 12 * Ti, nullptr, B, d.prev_pc, Ti, psix,
+                         train ? b.aff_p2pin[i] + 3 * d.prev_p : nullptr);
+            }
+            // models.py:378-384  repeat + concat (never materialised) + pitch convs
+            Src sdesc{p_cur, cp, psix, d.prev_pc, 36};
+            const float* in_aff = train ? b.aff_p2pin[i] : nullptr;
+            float* out = nullptr;
+            float* out_aff = nullptr;
+            for (int j = 0; j < c.conv_layers; ++j) {
+                out = (j & 1) ? b.pb[i] : b.pa[i];
+                out_aff = !train ? nullptr : ((j & 1) ? b.aff_pb[i] : b.aff_pa[i]);
+                if ((rc = conv(n->p2p[i][j], train ? n->p2p_t[i][j] : n->p2p[i][j], m + "p2p.layer." + std::to_string(3 * j + 1), 0, sdesc,
+                               in_aff, B, P, Ti, true, out, d.out_p, 0, out_aff, "conv_mfma_kernel/p2p")))
+                    return rc;
+                sdesc = Src{out, d.out_p, nullptr, 0, 0};
+                in_aff = out_aff;
+            }
+            // models.py:386-392  pool_semi -> fold, written next to pc in the concat buffer
+            if ((rc = semi(i, out, out_aff, B, P, Ti, cat, ctot, d.prev_pc, train ? b.aff_cat[i] + 3 * d.prev_pc : nullptr))) return rc;
+            if (last) return AKE_OK;                             // pc2pc + pooling + heads run batch-wide
+            // inner layers of deeper nets: pc2pc, then both time pools (models.py:393-396)
+            const float* psrc = cat;
+            const float* psrc_aff = train ? b.aff_cat[i] : nullptr;
+            int cin = ctot;
+            float* pdst = nullptr;
+            float* pdst_aff = nullptr;
+            for (int j = 0; j < c.conv_layers; ++j) {
+                pdst = (j & 1) ? b.pcb[i] : b.pca[i];
+                pdst_aff = !train ? nullptr : ((j & 1) ? b.aff_pcb[i] : b.aff_pca[i]);
+                if ((rc = conv(n->pc2pc[i][j], train ? n->pc2pc_t[i][j] : n->pc2pc[i][j], m + "pc2pc.layer." + std::to_string(3 * j + 1), 1,
+                               Src{psrc, cin, nullptr, 0, 0}, psrc_aff, B, 12, Ti, true, pdst, d.out_pc, 0, pdst_aff, "conv_mfma_kernel/pc2pc")))
+                    return rc;
+                psrc = pdst; psrc_aff = pdst_aff; cin = d.out_pc;
+            }
+            const LayerDims& dn = n->dims[i + 1];
+            const int ctn = dn.prev_pc + dn.out_p;
+            const int Tn = Ti / tp;
+            float* catn = b.cat[i + 1] + (i + 1 == L - 1 ? static_cast<size_t>(c0) * ctn * 12 * Tn : 0);
+            time_pool(pdst, pdst_aff, B, d.out_pc, 12, Ti, catn, ctn, 0);
+            if (train) identity(b.aff_cat[i + 1], d.out_pc);
+            time_pool(out, out_aff, B, d.out_p, P, Ti, b.ppool[i], d.out_p, 0);
+            pc_cur = catn; p_cur = b.ppool[i]; cp = d.out_p;
+        }
+        return AKE_OK;
+    }
+
+    // Phase C, whole batch: last layer's pc2pc, time pool, heads, masked mean.
+    int tail(int B, const int64_t* seq, float* key_out, float* tonic_out, float* genre_out) {
+        const auto& c = n->cfg;
+        const int L = c.num_layers, tp = c.time_pool_size;
+        const int i = L - 1;
         const int Ti = b.Tl[i];
         const LayerDims& d = n->dims[i];
-        const bool last = i == L - 1;
-        const int ctot = d.prev_pc + d.out_p;
-        float* cat = b.cat[i] + (last || i == 1 ? static_cast<size_t>(c0) * ctot * 12 * Ti : 0);
-        float* psix = b.psix[i] + (i == 1 ? static_cast<size_t>(c0) * d.prev_pc * 36 * Ti : 0);
-        if (i > 1) {   // models.py:372-374  up_sixth (+BN+LReLU); layer 1's ran batch-wide in forward_entry
-            const long long total = static_cast<long long>(B) * d.prev_pc * 36 * Ti;
-            ake::ProfScope ps("up_sixth_kernel", s);
-            hipLaunchKernelGGL(up_sixth_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, pc_cur,
-                               static_cast<long long>(ctot) * 12 * Ti, n->blob_dev + n->up[i].w_off,
-                               n->blob_dev + n->up[i].b_off, psix, d.prev_pc, Ti, total);
-        }
-        // models.py:378-384  repeat + concat (never materialised) + pitch convs
-        Src sdesc{p_cur, cp, psix, d.prev_pc, 36};
-        float* out = nullptr;
-        for (int j = 0; j < c.conv_layers; ++j) {
-            out = (j & 1) ? b.pb[i] : b.pa[i];
-            if ((rc = run_conv(n, n->p2p[i][j], 0, sdesc, B, P, Ti, true, true, out, d.out_p, 0, s, "conv_mfma_kernel/p2p"))) return rc;
-            sdesc = Src{out, d.out_p, nullptr, 0, 0};
-        }
-        // models.py:386-392  pool_semi -> fold, written next to pc in the concat buffer
-        if ((rc = run_semi(n, n->semi[i], out, B, P, Ti, cat, ctot, d.prev_pc, s, "semi_fold_kernel/L1+"))) return rc;
-        if (last) return AKE_OK;                             // pc2pc + pooling + heads run batch-wide
-        // inner layers of deeper nets: pc2pc, then both time pools (models.py:393-396)
-        const float* psrc = cat;
-        int cin = ctot;
+        int rc;
+        const float* psrc = L == 1 ? b.fold0 : b.cat[i];
+        const float* psrc_aff = (train && L > 1) ? b.aff_cat[i] : nullptr;
+        int cin = L == 1 ? 1 : d.prev_pc + d.out_p;
+        const int cout = L == 1 ? c.n_filters : d.out_pc;
+        const std::string m = "model." + std::to_string(i) + ".pc2pc.layer.";
         float* pdst = nullptr;
+        float* pdst_aff = nullptr;
         for (int j = 0; j < c.conv_layers; ++j) {
             pdst = (j & 1) ? b.pcb[i] : b.pca[i];
-            if ((rc = run_conv(n, n->pc2pc[i][j], 1, Src{psrc, cin, nullptr, 0, 0}, B, 12, Ti, true, true, pdst, d.out_pc, 0, s,
-                               "conv_mfma_kernel/pc2pc")))
+            pdst_aff = !train ? nullptr : ((j & 1) ? b.aff_pcb[i] : b.aff_pca[i]);
+            if ((rc = conv(n->pc2pc[i][j], train ? n->pc2pc_t[i][j] : n->pc2pc[i][j], m + std::to_string(3 * j + 1), 1,
+                           Src{psrc, cin, nullptr, 0, 0}, psrc_aff, B, 12, Ti, true, pdst, cout, 0, pdst_aff,
+                           L == 1 ? "conv_mfma_kernel/pc2pc0" : "conv_mfma_kernel/pc2pc")))
                 return rc;
-            psrc = pdst; cin = d.out_pc;
+            psrc = pdst; psrc_aff = pdst_aff; cin = cout;
         }
-        const LayerDims& dn = n->dims[i + 1];
-        const int ctn = dn.prev_pc + dn.out_p;
-        const int Tn = Ti / tp;
-        float* catn = b.cat[i + 1] + (i + 1 == L - 1 ? static_cast<size_t>(c0) * ctn * 12 * Tn : 0);   // (i+1 >= 2 here)
+        const float* feat = pdst;                 // features feeding the heads
+        const float* feat_aff = pdst_aff;
+        if (L > 1) {   // models.py:396  (the pitch stream of the last layer feeds nothing: its pool is skipped)
+            time_pool(pdst, pdst_aff, B, cout, 12, Ti, b.pcf, cout, 0);
+            feat = b.pcf; feat_aff = nullptr;
+        }
+        // ---- heads (models.py:750-753) ----
+        const int Tf = b.Tf;
+        struct HeadRun { const std::vector<PackedConv>* ce; const std::vector<PackedConv>* ct; float* hid; float* map; int kind; const char* nm; };
+        HeadRun heads[3] = {{&n->head_key, &n->head_key_t, b.hid_k, b.map_k, 1, "key_classifier"},
+                            {&n->head_tonic, &n->head_tonic_t, b.hid_t, b.map_t, 1, "tonic_classifier"},
+                            {&n->head_genre, &n->head_genre_t, b.hid_g, b.map_g, 2, "genre_classifier"}};
+        int Tm = Tf;
+        for (int h = 0; h < (c.genre ? 3 : 2); ++h) {
+            const float* src = feat;
+            const float* src_aff = feat_aff;
+            int hc = n->final_ch, Tcur = Tf;
+            const size_t hid_half = static_cast<size_t>(B) * 2 * n->final_ch * 12 * Tf;
+            for (int j = 0; j < c.head_layers; ++j) {
+                const PackedConv& pe = (*heads[h].ce)[j];
+                const bool lastj = j == c.head_layers - 1;
+                float* dst = lastj ? heads[h].map : heads[h].hid + (j & 1) * hid_half;
+                float* aff = (!train || lastj) ? nullptr : b.aff_hid[h] + (j & 1) * 3 * 2 * n->final_ch;
+                if ((rc = conv(pe, train ? (*heads[h].ct)[j] : pe, lastj ? "" : std::string(heads[h].nm) + "." + std::to_string(3 * j + 1),
+                               heads[h].kind, Src{src, hc, nullptr, 0, 0}, src_aff, B, 12, Tcur, false, dst, pe.cout, 0, aff,
+                               h == 2 ? "conv_mfma_kernel/genre_head" : "conv_mfma_kernel/head")))
+                    return rc;
+                src = dst; src_aff = aff; hc = pe.cout; Tcur -= c.kernel_size - 1;
+            }
+            Tm = Tcur;
+        }
+        // ---- masked temporal mean, sigmoid (models.py:754-804) ----
+        PoolHeadArgs pa;
+        std::memset(&pa, 0, sizeof(pa));
+        pa.maps[0] = b.map_k; pa.maps[1] = b.map_t; pa.maps[2] = c.genre ? b.map_g : nullptr;
+        pa.outs[0] = key_out; pa.outs[1] = tonic_out; pa.outs[2] = genre_out;
+        pa.rows[0] = 12; pa.rows[1] = 12; pa.rows[2] = 11;
+        pa.Tm = Tm; pa.seq = reinterpret_cast<const long long*>(seq);
+        pa.n_pool_layers = L - 1; pa.tp = tp; pa.shrink = (c.kernel_size - 1) * c.head_layers;
+        pa.max_pool = c.max_pool; pa.batch = B; pa.clip0 = 0;
         {
-            const long long total = static_cast<long long>(B) * d.out_pc * 12 * Tn;
-            ake::ProfScope ps("time_pool_kernel", s);
-            hipLaunchKernelGGL(time_pool_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, pdst, catn,
-                               d.out_pc, 12, Ti, tp, ctn, 0, total);
+            ake::ProfScope ps("head_pool_kernel", s);
+            hipLaunchKernelGGL(head_pool_kernel, dim3((B * 12 + 63) / 64, 3), dim3(64), 0, s, pa);
         }
-        {
-            const long long total = static_cast<long long>(B) * d.out_p * P * Tn;
-            ake::ProfScope ps("time_pool_kernel", s);
-            hipLaunchKernelGGL(time_pool_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, out, b.ppool[i],
-                               d.out_p, P, Ti, tp, d.out_p, 0, total);
-        }
-        pc_cur = catn; p_cur = b.ppool[i]; cp = d.out_p;
+        AKE_HIP_CHECK(hipGetLastError());
+        return AKE_OK;
     }
+};
+
+int forward_impl(const ake_pcnet* n, bool train, const float* mel, int batch, int frames, const int64_t* seq_length, float* key_out,
+                 float* tonic_out, float* genre_out, float* bn_stats_out, void* workspace, size_t ws_bytes, ake_stream_t stream) {
+    AKE_REQUIRE(n && mel && key_out && tonic_out, AKE_ERR_INVALID, "pcnet forward: null argument");
+    AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
+    AKE_REQUIRE(batch > 0 && frames > 0, AKE_ERR_INVALID, "pcnet: bad batch/frames");
+    AKE_REQUIRE(!n->cfg.genre || genre_out, AKE_ERR_INVALID, "pcnet: genre head enabled but genre_out is null");
+    const int chunk = train ? batch : std::min(batch, n->chunk_clips);     // batch statistics need the whole batch at once
+    Buffers b;
+    int rc = plan_buffers(n, batch, chunk, frames, workspace, &b, train);
+    if (rc) return rc;
+    AKE_REQUIRE(workspace && ws_bytes >= b.bytes, AKE_ERR_WORKSPACE, "pcnet: workspace %zu < %zu bytes", ws_bytes, b.bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (train) AKE_HIP_CHECK(hipMemsetAsync(b.stats, 0, sizeof(double) * 2 * n->bn_channels, s));
+    Fwd f{n, b, s, train};
+    if ((rc = f.entry(mel, batch))) return rc;
+    for (int c0 = 0; c0 < batch && n->cfg.num_layers > 1; c0 += chunk) {
+        const int B = std::min(chunk, batch - c0);
+        if ((rc = f.pitch_chunk(mel + static_cast<size_t>(c0) * n->cfg.pitches * frames, c0, B))) return rc;
+    }
+    if ((rc = f.tail(batch, seq_length, key_out, tonic_out, genre_out))) return rc;
+    if (train && bn_stats_out)
+        AKE_HIP_CHECK(hipMemcpyAsync(bn_stats_out, b.bstats, sizeof(float) * 3 * n->bn_channels, hipMemcpyDeviceToDevice, s));
     return AKE_OK;
 }
 
-// Pitch-class tail over the whole batch: last layer's pc2pc, time pool, heads, masked mean.
-static int forward_tail(const ake_pcnet* n, Buffers& b, int B, const int64_t* seq, float* key_out, float* tonic_out,
-                        float* genre_out, hipStream_t s) {
-    const auto& c = n->cfg;
-    const int L = c.num_layers, tp = c.time_pool_size;
-    const int i = L - 1;
-    const int Ti = b.Tl[i];
-    const LayerDims& d = n->dims[i];
-    int rc;
-    const float* psrc = L == 1 ? b.fold0 : b.cat[i];
-    int cin = L == 1 ? 1 : d.prev_pc + d.out_p;
-    const int cout = L == 1 ? c.n_filters : d.out_pc;
-    float* pdst = nullptr;
-    for (int j = 0; j < c.conv_layers; ++j) {
-        const bool lastj = j == c.conv_layers - 1;
-        pdst = (L == 1 && lastj) ? b.pcf : ((j & 1) ? b.pcb[i] : b.pca[i]);
-        if ((rc = run_conv(n, n->pc2pc[i][j], 1, Src{psrc, cin, nullptr, 0, 0}, B, 12, Ti, true, true, pdst, cout, 0, s,
-                           L == 1 ? "conv_mfma_kernel/pc2pc0" : "conv_mfma_kernel/pc2pc")))
-            return rc;
-        psrc = pdst; cin = cout;
-    }
-    if (L > 1) {   // models.py:396  time pooling of the pitch-class stream (the pitch stream of the last layer feeds nothing)
-        const long long total = static_cast<long long>(B) * cout * 12 * (Ti / tp);
-        ake::ProfScope ps("time_pool_kernel", s);
-        hipLaunchKernelGGL(time_pool_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, pdst, b.pcf, cout, 12,
-                           Ti, tp, cout, 0, total);
-    }
-    // ---- heads (models.py:750-753) ----
-    const int Tf = b.Tf;
-    struct HeadRun { const std::vector<PackedConv>* convs; float* hid; float* map; int kind; };
-    HeadRun heads[3] = {{&n->head_key, b.hid_k, b.map_k, 1}, {&n->head_tonic, b.hid_t, b.map_t, 1}, {&n->head_genre, b.hid_g, b.map_g, 2}};
-    int Tm = Tf;
-    for (int h = 0; h < (c.genre ? 3 : 2); ++h) {
-        const float* src = b.pcf;
-        int hc = n->final_ch, Tcur = Tf;
-        const size_t hid_half = static_cast<size_t>(B) * 2 * n->final_ch * 12 * Tf;
-        for (int j = 0; j < c.head_layers; ++j) {
-            const PackedConv& pcv = (*heads[h].convs)[j];
-            const bool lastj = j == c.head_layers - 1;
-            float* dst = lastj ? heads[h].map : heads[h].hid + (j & 1) * hid_half;
-            if ((rc = run_conv(n, pcv, heads[h].kind, Src{src, hc, nullptr, 0, 0}, B, 12, Tcur, false, !lastj, dst, pcv.cout, 0, s,
-                               h == 2 ? "conv_mfma_kernel/genre_head" : "conv_mfma_kernel/head")))
-                return rc;
-            src = dst; hc = pcv.cout; Tcur -= c.kernel_size - 1;
-        }
-        Tm = Tcur;
-    }
-    // ---- masked temporal mean, sigmoid (models.py:754-804) ----
-    PoolHeadArgs pa;
-    std::memset(&pa, 0, sizeof(pa));
-    pa.maps[0] = b.map_k; pa.maps[1] = b.map_t; pa.maps[2] = c.genre ? b.map_g : nullptr;
-    pa.outs[0] = key_out; pa.outs[1] = tonic_out; pa.outs[2] = genre_out;
-    pa.rows[0] = 12; pa.rows[1] = 12; pa.rows[2] = 11;
-    pa.Tm = Tm; pa.seq = reinterpret_cast<const long long*>(seq);
-    pa.n_pool_layers = L - 1; pa.tp = tp; pa.shrink = (c.kernel_size - 1) * c.head_layers;
-    pa.max_pool = c.max_pool; pa.batch = B; pa.clip0 = 0;
-    {
-        ake::ProfScope ps("head_pool_kernel", s);
-        hipLaunchKernelGGL(head_pool_kernel, dim3((B * 12 + 63) / 64, 3), dim3(64), 0, s, pa);
-    }
-    AKE_HIP_CHECK(hipGetLastError());
-    return AKE_OK;
-}
+}  // namespace
 
 int ake_pcnet_forward_f32(const ake_pcnet* n, const float* mel, int batch, int frames, const int64_t* seq_length,
                           float* key_out, float* tonic_out, float* genre_out, void* workspace, size_t ws_bytes,
                           ake_stream_t stream) {
-    AKE_REQUIRE(n && mel && key_out && tonic_out, AKE_ERR_INVALID, "ake_pcnet_forward_f32: null argument");
-    AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
-    AKE_REQUIRE(batch > 0 && frames > 0, AKE_ERR_INVALID, "pcnet: bad batch/frames");
-    AKE_REQUIRE(!n->cfg.genre || genre_out, AKE_ERR_INVALID, "pcnet: genre head enabled but genre_out is null");
-    const int chunk = std::min(batch, n->chunk_clips);
-    Buffers b;
-    int rc = plan_buffers(n, batch, chunk, frames, workspace, &b);
-    if (rc) return rc;
-    AKE_REQUIRE(workspace && ws_bytes >= b.bytes, AKE_ERR_WORKSPACE, "pcnet: workspace %zu < %zu bytes", ws_bytes, b.bytes);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if ((rc = forward_entry(n, b, mel, batch, s))) return rc;
-    for (int c0 = 0; c0 < batch && n->cfg.num_layers > 1; c0 += chunk) {
-        const int B = std::min(chunk, batch - c0);
-        rc = forward_pitch_chunk(n, b, mel + static_cast<size_t>(c0) * n->cfg.pitches * frames, c0, B, s);
-        if (rc) return rc;
-    }
-    return forward_tail(n, b, batch, seq_length, key_out, tonic_out, genre_out, s);
+    return forward_impl(n, false, mel, batch, frames, seq_length, key_out, tonic_out, genre_out, nullptr, workspace, ws_bytes, stream);
+}
+
+int ake_pcnet_forward_train_f32(const ake_pcnet* n, const float* mel, int batch, int frames, const int64_t* seq_length,
+                                float* key_out, float* tonic_out, float* genre_out, float* bn_stats_out, void* workspace,
+                                size_t ws_bytes, ake_stream_t stream) {
+    return forward_impl(n, true, mel, batch, frames, seq_length, key_out, tonic_out, genre_out, bn_stats_out, workspace, ws_bytes, stream);
 }
 
 // ---- debug taps ---------------------------------------------------------------------------

@@ -8,16 +8,15 @@
 //   equivariant pitch-class conv (models.py:45-47): H = 12, KH = 12, py = 0, time zero-pad / valid
 //   genre convs (models.py:724,733): KH = 1 / 2, py = 0, valid; the row H_out..H-1 is not stored
 //
-// so one kernel template covers them.  MI355X mapping:
-//   * a workgroup owns (clip, R rows, TT frames, CO output channels); its input patch
-//     [Cin][R+KH-1][TT+KW-1] is staged once in LDS with both halos materialised (no modulo in
-//     the inner loop);
-//   * a thread owns CO x 4 outputs (CO channels x 4 consecutive frames): per (ci,dy) it reads
-//     one 40-byte strip from LDS (three ds_read_b128) and issues KW*4*CO FMAs;
-//   * the weights of a workgroup are wave-uniform: they are packed [group][ci][dy][dx][CO] so
-//     that the compiler fetches them with s_load_dwordx8/x16 into SGPRs -- the FMA's second
-//     operand is a scalar register and costs no VGPR, no LDS bandwidth;
-//   * BatchNorm (eval) is folded into w/b on the host, LeakyReLU is the epilogue.
+// so one kernel template (conv_mfma_kernel, f32-MFMA implicit GEMM, further down) covers them.  Small ops
+// (semitone conv + octave fold, up_sixth, time pooling, head pooling) are plain vector kernels whose convolution
+// weights are wave-uniform and therefore come in through SGPRs (s_load), never through VGPRs or LDS.
+//
+// Inference: BatchNorm (running statistics) is folded into w/b on the host, LeakyReLU is the epilogue.
+// Training-mode forward (batch statistics): a convolution writes its RAW output and accumulates per-channel
+// sum / sum-of-squares in its epilogue (`stats`); BatchNorm + LeakyReLU are applied by whoever reads the tensor
+// next, as a per-input-channel (scale, shift, negative slope) triple applied while staging (`in_affine`), so the
+// normalisation never costs a pass of its own over the activations.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -50,113 +49,13 @@ struct ConvArgs {
     int TT;                   // output frames per workgroup (multiple of TW)
     int n_row_tiles, n_time_tiles;
     int Tp;                   // LDS row pitch in floats (multiple of 4, >= TT + KW - 1)
+    const float* in_affine;   // [c0+c1][3] (scale, shift, negative slope) applied to every staged input value, or null
+    double* stats;            // [cout][2] += (sum, sum of squares) of the raw outputs, or null
 };
 
 __device__ __forceinline__ int wrap(int i, int n) {
     i %= n;
     return i < 0 ? i + n : i;
-}
-
-template <int KH, int KW, int CO, bool FULLROWS>
-__global__ void conv_rows_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int cin = a.c0 + a.c1;
-    const int tile = blockIdx.x;
-    const int row_tile = tile / a.n_time_tiles;
-    const int time_tile = tile - row_tile * a.n_time_tiles;
-    const int grp = blockIdx.y;
-    const int clip = blockIdx.z;
-    const int y0 = FULLROWS ? 0 : row_tile * a.R;
-    const int t0 = time_tile * a.TT;
-    const int R_in = FULLROWS ? a.H : a.R + KH - 1;
-    const int Tp = a.Tp;
-
-    // ---- stage the input patch (both halos resolved here) ----
-    const float* s0 = a.src0 + clip * a.src0_clip_stride;
-    const float* s1 = a.src1 ? a.src1 + clip * a.src1_clip_stride : nullptr;
-    const int rowsz = R_in * Tp;
-    const int total = cin * rowsz;
-    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-        const int ci = idx / rowsz;
-        const int rem = idx - ci * rowsz;
-        const int rj = rem / Tp;
-        const int tj = rem - rj * Tp;
-        const int row = FULLROWS ? rj : wrap(y0 - a.py + rj, a.H);
-        int ti = t0 - a.pad_l + tj;
-        float v = 0.f;
-        bool ok = true;
-        if (a.time_circ) ti = wrap(ti, a.T_in);
-        else ok = (ti >= 0) && (ti < a.T_in);
-        if (ok) {
-            if (ci < a.c0) v = s0[(static_cast<long long>(ci) * a.H + row) * a.T_in + ti];
-            else v = s1[(static_cast<long long>(ci - a.c0) * a.h1 + (row % a.h1)) * a.T_in + ti];
-        }
-        lds[idx] = v;
-    }
-    __syncthreads();
-
-    // ---- compute ----
-    const int strips = a.TT / TW;
-    const int r = threadIdx.x / strips;
-    const int s = threadIdx.x - r * strips;
-    const int rows_here = FULLROWS ? a.H : a.R;
-    if (r >= rows_here) return;
-    const int y = y0 + r;
-    if (y >= a.H) return;
-
-    float acc[CO][TW];
-#pragma unroll
-    for (int co = 0; co < CO; ++co)
-#pragma unroll
-        for (int j = 0; j < TW; ++j) acc[co][j] = 0.f;
-
-    const float* __restrict__ wg = a.w + static_cast<long long>(grp) * cin * (KH * KW * CO);
-    constexpr int NIN = TW + KW - 1;
-    constexpr int NV4 = (NIN + 3) / 4;
-    int lrow = FULLROWS ? wrap(y - a.py, a.H) : r;
-    for (int ci = 0; ci < cin; ++ci) {
-        int lr = lrow;
-        for (int dy = 0; dy < KH; ++dy) {
-            const float4* p4 = reinterpret_cast<const float4*>(lds + (ci * R_in + lr) * Tp + s * TW);
-            float in[NV4 * 4];
-#pragma unroll
-            for (int q = 0; q < NV4; ++q) {
-                const float4 v = p4[q];
-                in[4 * q + 0] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
-            }
-            const float* __restrict__ wp = wg + (ci * KH + dy) * (KW * CO);
-#pragma unroll
-            for (int dx = 0; dx < KW; ++dx)
-#pragma unroll
-                for (int co = 0; co < CO; ++co) {
-                    const float wv = wp[dx * CO + co];
-#pragma unroll
-                    for (int j = 0; j < TW; ++j) acc[co][j] = fmaf(in[j + dx], wv, acc[co][j]);
-                }
-            if (FULLROWS) { lr = lr + 1; if (lr == a.H) lr = 0; }
-            else lr = lr + 1;
-        }
-    }
-
-    // ---- epilogue: bias (BN folded), LeakyReLU, store ----
-    if (y >= a.H_out) return;
-    float* d = a.dst + clip * a.dst_clip_stride;
-#pragma unroll
-    for (int co = 0; co < CO; ++co) {
-        const int c = grp * CO + co;
-        if (c >= a.cout) break;
-        const float b = a.bias[c];
-        float* drow = d + (static_cast<long long>(a.dst_coff + c) * a.H_out + y) * a.T_out;
-#pragma unroll
-        for (int j = 0; j < TW; ++j) {
-            const int t = t0 + s * TW + j;
-            if (t < a.T_out) {
-                float v = acc[co][j] + b;
-                if (a.lrelu) v = v > 0.f ? v : v * kSlope;
-                drow[t] = v;
-            }
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -473,6 +372,8 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
                     int row = y0 - a.py + rj;                            // in (-H, 2H): one conditional wrap each way
                     row += row < 0 ? a.H : 0;
                     row -= row >= a.H ? a.H : 0;
+                    float asc = 1.f, ash = 0.f, ang = 1.f;                // BatchNorm + LeakyReLU of the producer, applied on load
+                    if (a.in_affine) { asc = a.in_affine[3 * cs]; ash = a.in_affine[3 * cs + 1]; ang = a.in_affine[3 * cs + 2]; }
                     const float* srow;
                     if (cs < a.c0) srow = s0 + (static_cast<long long>(cs) * a.H + row) * a.T_in;
                     else {
@@ -492,7 +393,10 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
                             } else {
                                 ok = ti >= 0 && ti < a.T_in;
                             }
-                            if (ok) v[u][h] = srow[ti];
+                            if (ok) {
+                                float x = fmaf(srow[ti], asc, ash);
+                                v[u][h] = x > 0.f ? x : x * ang;          // zero padding stays zero: it pads the activation
+                            }
                         }
                     }
                 }
@@ -582,6 +486,9 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
     //      carried into the next row when j reaches J. ----
     float* d = a.dst + clip * a.dst_clip_stride + t0;
     const int row_elems = a.T_out;
+    float st1[NT], st2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { st1[nt] = 0.f; st2[nt] = 0.f; }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m0 = (grp * MT + mt) * 16 + 4 * q;
@@ -596,6 +503,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
                 const int tl = TB * j + tau;
                 if (ok_m && co < a.cout && tl < tt_here) {
                     float v = acc[mt][nt][reg] + a.bias[co];
+                    if (a.stats) { st1[nt] += v; st2[nt] = fmaf(v, v, st2[nt]); }
                     if (a.lrelu) v = v > 0.f ? v : v * kSlope;
                     d[((a.dst_coff + co) * a.H_out + (y0 + r)) * row_elems + tl] = v;
                 }
@@ -603,6 +511,206 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
             if (++j == J) { j = 0; ++r; }
         }
     }
+    if (a.stats) {   // per-channel batch statistics: lanes of one channel = TB adjacent columns x 4 row groups
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float s1 = st1[nt], s2 = st2[nt];
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            for (int o = 1; o < TB; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            const int n = (ngrp * NT + nt) * 16 + r16;
+            const int co = n / TB;
+            if (q == 0 && n - co * TB == 0 && co < a.cout) {
+                atomicAdd(a.stats + 2 * co, static_cast<double>(s1));
+                atomicAdd(a.stats + 2 * co + 1, static_cast<double>(s2));
+            }
+        }
+    }
 }
+
+// ==========================================================================================
+// Training-mode forward helpers (BatchNorm with batch statistics, nn.BatchNorm2d in train(), models.py:196 etc.)
+// ==========================================================================================
+
+__device__ __forceinline__ float affine_act(float x, const float* aff, int c) {
+    if (!aff) return x;
+    const float y = fmaf(x, aff[3 * c], aff[3 * c + 1]);
+    return y > 0.f ? y : y * aff[3 * c + 2];
+}
+
+// wave-level (sum, sumsq) -> one double atomic pair per wave
+__device__ __forceinline__ void stats_commit(double* stats, int c, float s1, float s2) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(stats + 2 * c, static_cast<double>(s1));
+        atomicAdd(stats + 2 * c + 1, static_cast<double>(s2));
+    }
+}
+
+// Semitone conv (models.py:313 / :337) WITHOUT its BatchNorm: raw output [B][C][H/3][T] + per-channel statistics.
+// Same thread mapping as semi_fold_kernel; the input may carry a pending BatchNorm+LeakyReLU (in_affine).
+struct SemiTrainArgs {
+    SemiArgs s;               // dst = raw [B][C][H/3][T] (dst_coff / dst_clip_stride unused: dense)
+    const float* in_affine;   // [C][3] or null
+    double* stats;            // [C][2]
+};
+
+template <int CO>
+__global__ void semi_conv_stats_kernel(SemiTrainArgs ta) {
+    const SemiArgs& a = ta.s;
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_clip = 12 * a.n_strips;
+    const bool live = item < per_clip;
+    const int p = live ? item / a.n_strips : 0;
+    const int sidx = live ? item - p * a.n_strips : 0;
+    const int grp = blockIdx.y;
+    const int clip = blockIdx.z;
+    const int t0 = sidx * TW;
+    int tix[TW + 2];
+#pragma unroll
+    for (int j = 0; j < TW + 2; ++j) tix[j] = wrap(t0 - 1 + j, a.T);
+    const float* src = a.src + clip * a.src_clip_stride;
+    const float* __restrict__ wg = a.w + static_cast<long long>(grp) * a.C * (9 * CO);
+    const int rows_out = a.H / 3;
+    float* d = a.dst + static_cast<long long>(clip) * a.C * rows_out * a.T;
+    float s1[CO], s2[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) { s1[co] = 0.f; s2[co] = 0.f; }
+    const int n_oct = a.H / 36;
+    for (int o = 0; o < n_oct; ++o) {
+        const int srow = p + 12 * o;
+        const int row0 = 3 * srow;
+        float acc[CO][TW];
+#pragma unroll
+        for (int co = 0; co < CO; ++co)
+#pragma unroll
+            for (int j = 0; j < TW; ++j) acc[co][j] = 0.f;
+        for (int ci = 0; ci < a.C; ++ci) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const float* rowp = src + (static_cast<long long>(ci) * a.H + row0 + dy) * a.T;
+                float in[TW + 2];
+#pragma unroll
+                for (int j = 0; j < TW + 2; ++j) in[j] = affine_act(rowp[tix[j]], ta.in_affine, ci);
+                const float* __restrict__ wp = wg + (ci * 3 + dy) * (3 * CO);
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) {
+                        const float wv = wp[dx * CO + co];
+#pragma unroll
+                        for (int j = 0; j < TW; ++j) acc[co][j] = fmaf(in[j + dx], wv, acc[co][j]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            const int c = grp * CO + co;
+            if (c >= a.C) break;
+            const float b = a.bias[c];
+            float* drow = d + (static_cast<long long>(c) * rows_out + srow) * a.T;
+#pragma unroll
+            for (int j = 0; j < TW; ++j) {
+                const float v = acc[co][j] + b;
+                if (live && t0 + j < a.T) { drow[t0 + j] = v; s1[co] += v; s2[co] = fmaf(v, v, s2[co]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        const int c = grp * CO + co;
+        if (c < a.C) stats_commit(ta.stats, c, s1[co], s2[co]);
+    }
+}
+
+// BatchNorm + LeakyReLU (as `aff`) then Pitch2PitchClassPool (models.py:95-106): raw [B][C][12*n_oct][T] -> [B][ctot][12][T]
+__global__ void fold_affine_kernel(const float* __restrict__ src, const float* __restrict__ aff, float* __restrict__ dst, int C,
+                                   int n_oct, int T, int dst_ctot, int dst_coff, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int t = static_cast<int>(i % T);
+    long long q = i / T;
+    const int p = static_cast<int>(q % 12);
+    q /= 12;
+    const int c = static_cast<int>(q % C);
+    const long long clip = q / C;
+    const float* s = src + ((clip * C + c) * (12 * n_oct) + p) * T + t;
+    float m = -INFINITY;
+    for (int o = 0; o < n_oct; ++o) m = fmaxf(m, affine_act(s[static_cast<long long>(o) * 12 * T], aff, c));
+    dst[((clip * dst_ctot + dst_coff + c) * 12 + p) * T + t] = m;
+}
+
+// up_sixth in training mode: raw ConvTranspose2d output + statistics; input carries a pending affine.
+__global__ void up_sixth_train_kernel(const float* __restrict__ src, long long src_clip_stride, const float* __restrict__ in_aff,
+                                      const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ dst,
+                                      double* __restrict__ stats, int C, int T, long long total) {
+    __shared__ double sh[2 * 128];
+    for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) sh[k] = 0.0;
+    __syncthreads();
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < total) {
+        const int t = static_cast<int>(i % T);
+        long long q = i / T;
+        const int row = static_cast<int>(q % 36);
+        q /= 36;
+        const int co = static_cast<int>(q % C);
+        const long long clip = q / C;
+        const int p = row / 3, j = row - 3 * p;
+        const float* s = src + clip * src_clip_stride + static_cast<long long>(p) * T + t;
+        float acc = bias[co];
+        for (int ci = 0; ci < C; ++ci) acc = fmaf(affine_act(s[static_cast<long long>(ci) * 12 * T], in_aff, ci), w[(ci * C + co) * 3 + j], acc);
+        dst[i] = acc;
+        atomicAdd(&sh[2 * co], static_cast<double>(acc));
+        atomicAdd(&sh[2 * co + 1], static_cast<double>(acc) * acc);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * C; k += blockDim.x)
+        if (sh[k] != 0.0) atomicAdd(stats + k, sh[k]);
+}
+
+// time pooling with a pending affine on the input
+__global__ void time_pool_affine_kernel(const float* __restrict__ src, const float* __restrict__ aff, float* __restrict__ dst, int C,
+                                        int H, int T, int tp, int dst_ctot, int dst_coff, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int To = T / tp;
+    const int t = static_cast<int>(i % To);
+    long long q = i / To;
+    const int y = static_cast<int>(q % H);
+    q /= H;
+    const int c = static_cast<int>(q % C);
+    const long long clip = q / C;
+    const float* s = src + ((clip * C + c) * H + y) * T + static_cast<long long>(t) * tp;
+    float m = affine_act(s[0], aff, c);
+    for (int j = 1; j < tp; ++j) m = fmaxf(m, affine_act(s[j], aff, c));
+    dst[((clip * dst_ctot + dst_coff + c) * H + y) * To + t] = m;
+}
+
+// (sum, sumsq) over `count` values per channel -> BatchNorm(train) as an affine triple, plus (batch mean, biased
+// variance, count) for the running-statistics update done by the caller (momentum 0.1, unbiased variance: torch semantics).
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ aff, float* __restrict__ batch_stats, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = stats[2 * c] / count;
+    double var = stats[2 * c + 1] / count - mean * mean;
+    if (var < 0) var = 0;
+    const double sc = static_cast<double>(gamma[c]) / sqrt(var + 1e-5);
+    aff[3 * c] = static_cast<float>(sc);
+    aff[3 * c + 1] = static_cast<float>(static_cast<double>(beta[c]) - mean * sc);
+    aff[3 * c + 2] = kSlope;
+    batch_stats[3 * c] = static_cast<float>(mean);
+    batch_stats[3 * c + 1] = static_cast<float>(var);
+    batch_stats[3 * c + 2] = static_cast<float>(count);
+}
+
+__global__ void affine_identity_kernel(float* __restrict__ aff, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    aff[3 * c] = 1.f; aff[3 * c + 1] = 0.f; aff[3 * c + 2] = 1.f;
+}
+
+// masked temporal mean with a pending affine on nothing (the last head conv has no BatchNorm): reuse head_pool_kernel.
 
 }  // namespace ake_k

@@ -222,9 +222,6 @@ class PitchClassNet(LightningModule):
 
     # ------------------------------------------------------------------ forward (models.py:747-817)
     def forward(self, mel, seq_length):
-        if self.training:
-            raise NotImplementedError("train-mode forward (batch-statistics BatchNorm) and backward are not built yet: "
-                                      "call .eval(); see DESIGN.md 'Out of scope this round'")
         device = self._device()
         self._sync_weights(device)
         assert mel.dim() == 4 and mel.shape[1] == 1 and mel.shape[2] == self.pitches, \
@@ -243,16 +240,52 @@ class PitchClassNet(LightningModule):
         tonic = torch.empty((B, 12), dtype=torch.float32, device=device)
         genre = torch.empty((B, 11), dtype=torch.float32, device=device) if self.genre else None
         L = _lib.lib()
-        ws = self._workspace(L.ake_pcnet_workspace_bytes(self._h, B, Tn), device)
+        ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(device):
-            _lib.check(L.ake_pcnet_forward_f32(self._h, x.data_ptr(), B, Tn, seq.data_ptr() if seq is not None else None,
-                                               key.data_ptr(), tonic.data_ptr(), genre.data_ptr() if genre is not None else None,
-                                               ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
-                       "ake_pcnet_forward_f32")
+            stream = torch.cuda.current_stream().cuda_stream
+            if self.training:
+                # BatchNorm with batch statistics (train()), forward only: there is no autograd graph behind the
+                # outputs -- the backward kernels are not built yet (DESIGN.md section 7)
+                ws = self._workspace(L.ake_pcnet_train_workspace_bytes(self._h, B, Tn), device)
+                n_ch = sum(c for _, c, _ in self._bn_layers())
+                stats = torch.empty((n_ch, 3), dtype=torch.float32, device=device)
+                _lib.check(L.ake_pcnet_forward_train_f32(self._h, x.data_ptr(), B, Tn, ptr(seq), key.data_ptr(), tonic.data_ptr(),
+                                                         ptr(genre), stats.data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                           "ake_pcnet_forward_train_f32")
+                self._update_running_stats(stats)
+            else:
+                ws = self._workspace(L.ake_pcnet_workspace_bytes(self._h, B, Tn), device)
+                _lib.check(L.ake_pcnet_forward_f32(self._h, x.data_ptr(), B, Tn, ptr(seq), key.data_ptr(), tonic.data_ptr(),
+                                                   ptr(genre), ws.data_ptr(), ws.numel(), stream), "ake_pcnet_forward_f32")
         self._last_shape = (B, Tn)
         if self.genre:
             return key.to(out_dtype), tonic.to(out_dtype), genre.to(out_dtype)               # models.py:813
         return key.to(out_dtype), tonic.to(out_dtype)                                         # models.py:815
+
+    def _bn_layers(self):
+        """[(reference module path, channels, channel offset)] of the BatchNorm layers in the device's forward order."""
+        if getattr(self, "_bn_cache", None) is None or self._bn_cache[0] is not self._h:
+            L, out = _lib.lib(), []
+            for i in range(L.ake_pcnet_num_bn(self._h)):
+                name, ch, off = C.c_char_p(), C.c_int(), C.c_int()
+                _lib.check(L.ake_pcnet_bn_info(self._h, i, C.byref(name), C.byref(ch), C.byref(off)), "ake_pcnet_bn_info")
+                out.append((name.value.decode(), ch.value, off.value))
+            self.__dict__["_bn_cache"] = (self._h, out)
+        return self._bn_cache[1]
+
+    @torch.no_grad()
+    def _update_running_stats(self, stats):
+        """nn.BatchNorm2d's train-mode side effect: running stats <- momentum blend with (mean, unbiased var) of the batch."""
+        mods = dict(self.named_modules())
+        for name, ch, off in self._bn_layers():
+            bn = mods[name]
+            mean, var, cnt = stats[off:off + ch, 0], stats[off:off + ch, 1], stats[off:off + ch, 2]
+            m = bn.momentum if bn.momentum is not None else 0.1
+            unbiased = var * cnt / (cnt - 1).clamp_min(1)
+            bn.running_mean.mul_(1 - m).add_(mean.to(bn.running_mean.dtype) * m)
+            bn.running_var.mul_(1 - m).add_(unbiased.to(bn.running_var.dtype) * m)
+            bn.num_batches_tracked += 1
+        # the device copy of the weights does not depend on the running statistics in train mode; eval re-syncs lazily
 
     def tap(self, name):
         """Intermediate activation of the last forward (debug / bisecting): reference module path -> tensor."""

@@ -127,6 +127,20 @@ int ake_pcnet_forward_f32(const ake_pcnet* net, const float* mel_dev, int batch,
                           const int64_t* seq_length_dev, float* key_out_dev, float* tonic_out_dev,
                           float* genre_out_dev, void* workspace, size_t workspace_bytes, ake_stream_t stream);
 
+/* Training-mode forward: BatchNorm uses the statistics of this batch (nn.BatchNorm2d in train(), as
+ * equivariance_test.py:178 runs the net and as training_step does, models.py:952).  Convolutions keep their raw
+ * outputs and per-channel sums; normalisation + LeakyReLU are applied by the next reader, never as a pass of their own.
+ * bn_stats_out (optional, device): [sum of BN channels][3] = batch mean, biased batch variance, elements per channel, in
+ * the layer order of ake_pcnet_bn_info -- what the caller needs for torch's running_mean / running_var update
+ * (momentum 0.1, unbiased variance).  The whole batch is processed in one pass (no chunking). */
+int ake_pcnet_num_bn(const ake_pcnet* net);
+int ake_pcnet_bn_info(const ake_pcnet* net, int index, const char** name, int* channels, int* channel_offset);
+size_t ake_pcnet_train_workspace_bytes(const ake_pcnet* net, int batch, int frames);
+int ake_pcnet_forward_train_f32(const ake_pcnet* net, const float* mel_dev, int batch, int frames,
+                                const int64_t* seq_length_dev, float* key_out_dev, float* tonic_out_dev,
+                                float* genre_out_dev, float* bn_stats_out_dev, void* workspace, size_t workspace_bytes,
+                                ake_stream_t stream);
+
 /* Debug tap: copy an intermediate activation of the LAST forward call out of the workspace.
  * name is the reference module path whose output it is (e.g. "model.1.p2p.layer.8"). */
 int ake_pcnet_tap_info(const ake_pcnet* net, const char* name, int batch, int frames, int64_t shape[4]);

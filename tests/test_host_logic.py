@@ -58,8 +58,8 @@ def test_forward_fails_loudly_without_a_gpu_tensor():
     net = ake_amd.PitchClassNet(288, 12, 2, 7, Namespace(genre=True)).eval()
     with pytest.raises(ake_amd._lib.AkeError, match="No CPU fallback"):
         net(torch.zeros(1, 1, 288, 76), None)
-    with pytest.raises(NotImplementedError):
-        net.train()(torch.zeros(1, 1, 288, 76), None)
+    with pytest.raises(ake_amd._lib.AkeError, match="No CPU fallback"):
+        net.train()(torch.zeros(1, 1, 288, 76), None)            # the train-mode forward is HIP-only as well
 
 
 @pytest.mark.parametrize("flag", ["resblock", "denseblock", "stay_sixth", "only_semitones", "p2pc_conv", "pc2p_mem", "local"])
