@@ -54,6 +54,9 @@ SYMBOLS = {
     "ake_pcnet_bn_info": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_I), C.POINTER(_I)]),
     "ake_pcnet_train_workspace_bytes": (_SZ, [_P, _I, _I]),
     "ake_pcnet_forward_train_f32": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "ake_pcnet_grad_floats": (_SZ, [_P]),
+    "ake_pcnet_grad_offset": (_I64, [_P, C.c_char_p]),
+    "ake_pcnet_backward_f32": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "ake_pcnet_tap_info": (_I, [_P, C.c_char_p, _I, _I, C.POINTER(_I64)]),
     "ake_pcnet_tap_copy": (_I, [_P, C.c_char_p, _I, _I, _P, _P, _P]),
     "ake_pipeline_workspace_bytes": (_SZ, [_P, _P, _I, _I64]),

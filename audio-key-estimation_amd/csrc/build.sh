@@ -6,10 +6,15 @@ OUT=../libake_hip.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
 mkdir -p build
+HEADERS="common.h pcnet_kernels.h pcnet_bwd_kernels.h pcnet_backward.h ../../include/ake_hip.h"
 pids=()
 for f in common.cpp cqt.hip pcnet.hip pipeline.hip; do
-  if [ ! -f build/${f%.*}.o ] || [ "$f" -nt build/${f%.*}.o ] || [ pcnet_kernels.h -nt build/${f%.*}.o ] || [ common.h -nt build/${f%.*}.o ] || [ ../../include/ake_hip.h -nt build/${f%.*}.o ]; then
-    ( $HIPCC $FLAGS -x hip -c "$f" -o build/${f%.*}.o ) &
+  obj=build/${f%.*}.o
+  stale=0
+  [ -f "$obj" ] || stale=1
+  for d in "$f" $HEADERS; do [ "$d" -nt "$obj" ] && stale=1; done
+  if [ $stale = 1 ]; then
+    ( $HIPCC $FLAGS -x hip -c "$f" -o "$obj" ) &
     pids+=($!)
   fi
 done

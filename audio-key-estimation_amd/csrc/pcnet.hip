@@ -23,6 +23,7 @@
 
 #include "common.h"
 #include "pcnet_kernels.h"
+#include "pcnet_bwd_kernels.h"
 
 using namespace ake_k;
 
@@ -84,6 +85,12 @@ struct ake_pcnet {
     std::vector<BnLayer> bns;
     std::map<std::string, int> bn_index;
     int bn_channels = 0;
+    // backward: data-gradient packs (transposed + flipped raw weights, same fragment format) and the flat gradient layout
+    std::vector<std::vector<PackedConv>> pc2pc_d, p2p_d;
+    std::vector<PackedConv> head_key_d, head_tonic_d, head_genre_d;
+    std::vector<size_t> grad_off;      // float offset of specs[i] in the flat gradient buffer
+    size_t grad_floats = 0;
+    std::vector<size_t> raw_w_off;     // float offset in the blob of specs[i]'s raw values (convolution weights used by small kernels)
 };
 
 namespace {
@@ -188,6 +195,19 @@ PackedConv pack_conv(ake_pcnet* n, const std::vector<double>& w, const std::vect
     return p;
 }
 
+// Data-gradient pack of a convolution: the transposed + flipped raw weights as a forward-type conv (cin' = cout, cout' = cin)
+PackedConv dgrad_pack(ake_pcnet* n, const std::string& wkey, int cout, int cin, int kh, int kw) {
+    const auto& w32 = T(n, wkey);
+    std::vector<double> w(static_cast<size_t>(cin) * cout * kh * kw), b(cin, 0.0);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int dy = 0; dy < kh; ++dy)
+                for (int dx = 0; dx < kw; ++dx)
+                    w[((static_cast<size_t>(ci) * cout + co) * kh + (kh - 1 - dy)) * kw + (kw - 1 - dx)] =
+                        w32[((static_cast<size_t>(co) * cin + ci) * kh + dy) * kw + dx];
+    return pack_conv(n, w, b, cin, cout, kh, kw);
+}
+
 PackedConv fold_pack(ake_pcnet* n, const std::string& conv_prefix, const std::string& bn_prefix, int cout, int cin, int kh, int kw) {
     std::vector<double> w, b;
     fold(n, conv_prefix + ".weight", conv_prefix + ".bias", bn_prefix, cout, static_cast<size_t>(cin) * kh * kw, false, cin, w, b);
@@ -262,11 +282,15 @@ struct Src {
     const float* p0; int c0; const float* p1; int c1; int h1;
 };
 
+struct ConvGeom {            // explicit geometry for the data-gradient convolutions
+    int py, pad_l, T_out, H_out, time_circ;
+};
+
 // One convolution of the net.  `kind`: 0 pitch conv (7x7 circular both axes), 1 equivariant pitch-class
 // conv (12 x k, rows circular), 2 genre conv (kh in {1,2}, rows valid).
 int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int batch, int H, int T_in, bool same_time,
              bool lrelu, float* dst, int dst_ctot, int dst_coff, hipStream_t s, const char* name,
-             const float* in_affine = nullptr, double* stats = nullptr) {
+             const float* in_affine = nullptr, double* stats = nullptr, const ConvGeom* geom = nullptr, bool accumulate = false) {
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
     AKE_REQUIRE(pc.kw == 7, AKE_ERR_UNSUPPORTED, "conv: kernel width %d not built (only 7)", pc.kw);
@@ -283,11 +307,12 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
         a.T_out = same_time ? T_in : T_in - pc.kw + 1;
         a.H_out = kind == 1 ? H : H - pc.kh + 1;
     }
+    if (geom) { a.py = geom->py; a.pad_l = geom->pad_l; a.T_out = geom->T_out; a.H_out = geom->H_out; a.time_circ = geom->time_circ; }
     AKE_REQUIRE(a.T_out > 0, AKE_ERR_INVALID, "conv %s: %d frames is too short for the valid head convolutions", name, T_in);
     a.w = n->blob_dev + pc.w_off; a.bias = n->blob_dev + pc.b_off; a.cout = pc.cout;
     a.dst = dst; a.dst_coff = dst_coff; a.dst_clip_stride = static_cast<long long>(dst_ctot) * a.H_out * a.T_out;
     a.lrelu = lrelu ? 1 : 0;
-    a.in_affine = in_affine; a.stats = stats;
+    a.in_affine = in_affine; a.stats = stats; a.accumulate = accumulate ? 1 : 0;
     Tile t;
     MTile mtile;
     static const int mt_env = std::getenv("AKE_MT") ? std::atoi(std::getenv("AKE_MT")) : 3;
@@ -353,8 +378,16 @@ struct Buffers {           // workspace carve
     // ([C][3] = scale, shift, negative slope) of every buffer that can hold a raw (pre-BatchNorm) tensor
     double* stats = nullptr;           // [bn_channels][2]
     float* bstats = nullptr;           // [bn_channels][3] batch mean, biased variance, element count
-    std::vector<float*> semi_raw, aff_semi, aff_cat, aff_p2pin, aff_pa, aff_pb, aff_pca, aff_pcb;
-    float* aff_hid[3] = {nullptr, nullptr, nullptr};
+    std::vector<float*> semi_raw, aff_semi, aff_cat, aff_p2pin;
+    // every convolution keeps its own raw output in training mode (the backward pass needs all of them)
+    std::vector<std::vector<float*>> pst, aff_pst, pcst, aff_pcst;   // [layer][conv]
+    std::vector<float*> hst[3], aff_hst[3];                            // [head][hidden conv]
+    // backward
+    double* stats2 = nullptr;          // [bn_channels][3]  (sum g1, sum g1*zhat, sum (z - mean))
+    float* coef = nullptr;             // [bn_channels][4]  (c0, c1, c2, mean)
+    float* g_map[3] = {nullptr, nullptr, nullptr};
+    float *g_hid = nullptr, *g_pcf = nullptr, *g_fold0 = nullptr;
+    std::vector<float*> g_pc, g_cat, g_semi, g_p, g_pin, g_psix;      // per layer (g_pc / g_p: ping-pong pair packed as 2x)
 };
 
 // chunk = clips per pitch-stream pass, batch = clips of the call (tail buffers)
@@ -391,22 +424,49 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
     b->map_k = cv.take<float>(B * 12 * b->Tf); b->map_t = cv.take<float>(B * 12 * b->Tf);
     if (c.genre) { b->hid_g = cv.take<float>(2 * hid); b->map_g = cv.take<float>(B * 12 * b->Tf); }
     if (train) {
-        b->stats = cv.take<double>(static_cast<size_t>(n->bn_channels) * 2);
+        b->stats = cv.take<double>(static_cast<size_t>(n->bn_channels) * 3);
+        b->stats2 = cv.take<double>(static_cast<size_t>(n->bn_channels) * 3);
         b->bstats = cv.take<float>(static_cast<size_t>(n->bn_channels) * 3);
-        for (auto* v : {&b->semi_raw, &b->aff_semi, &b->aff_cat, &b->aff_p2pin, &b->aff_pa, &b->aff_pb, &b->aff_pca, &b->aff_pcb}) v->assign(L + 1, nullptr);
+        b->coef = cv.take<float>(static_cast<size_t>(n->bn_channels) * 4);
+        for (auto* v : {&b->semi_raw, &b->aff_semi, &b->aff_cat, &b->aff_p2pin, &b->g_pc, &b->g_cat, &b->g_semi, &b->g_p, &b->g_pin, &b->g_psix})
+            v->assign(L + 1, nullptr);
+        b->pst.assign(L, {}); b->aff_pst.assign(L, {}); b->pcst.assign(L, {}); b->aff_pcst.assign(L, {});
         for (int i = 0; i < L; ++i) {
             const auto& d = n->dims[i];
+            const int Ti = b->Tl[i];
             const int cs = i == 0 ? 1 : d.out_p, pc_out = i == 0 ? c.n_filters : d.out_pc;
-            b->semi_raw[i] = cv.take<float>(B * cs * (P / 3) * b->Tl[i]);
+            b->semi_raw[i] = cv.take<float>(B * cs * (P / 3) * Ti);
+            b->g_semi[i] = cv.take<float>(B * cs * (P / 3) * Ti);
             b->aff_semi[i] = cv.take<float>(3 * cs);
-            b->aff_pca[i] = cv.take<float>(3 * pc_out); b->aff_pcb[i] = cv.take<float>(3 * pc_out);
+            for (int j = 0; j < c.conv_layers; ++j) {
+                b->pcst[i].push_back(cv.take<float>(B * pc_out * 12 * Ti));
+                b->aff_pcst[i].push_back(cv.take<float>(3 * pc_out));
+            }
+            b->g_pc[i] = cv.take<float>(2 * B * pc_out * 12 * Ti);
             if (i >= 1) {
                 b->aff_cat[i] = cv.take<float>(3 * (d.prev_pc + d.out_p));
                 b->aff_p2pin[i] = cv.take<float>(3 * (d.prev_pc + d.prev_p));
-                b->aff_pa[i] = cv.take<float>(3 * d.out_p); b->aff_pb[i] = cv.take<float>(3 * d.out_p);
+                b->g_cat[i] = cv.take<float>(B * (d.prev_pc + d.out_p) * 12 * Ti);
+                for (int j = 0; j < c.conv_layers; ++j) {
+                    b->pst[i].push_back(cv.take<float>(B * d.out_p * P * Ti));
+                    b->aff_pst[i].push_back(cv.take<float>(3 * d.out_p));
+                }
+                b->g_p[i] = cv.take<float>(2 * B * d.out_p * P * Ti);
+                b->g_pin[i] = cv.take<float>(B * (d.prev_p + d.prev_pc) * P * Ti);
+                b->g_psix[i] = cv.take<float>(B * d.prev_pc * 36 * Ti);
             }
         }
-        for (int h = 0; h < 3; ++h) b->aff_hid[h] = cv.take<float>(3 * 2 * 2 * n->final_ch);   // two ping-pong halves
+        b->g_fold0 = cv.take<float>(B * 12 * frames);
+        b->g_pcf = cv.take<float>(B * n->final_ch * 12 * b->Tf);
+        b->g_hid = cv.take<float>(hid);
+        for (int h = 0; h < 3; ++h) {
+            if (h == 2 && !c.genre) break;
+            for (int j = 0; j + 1 < c.head_layers; ++j) {
+                b->hst[h].push_back(cv.take<float>(hid));
+                b->aff_hst[h].push_back(cv.take<float>(3 * 2 * n->final_ch));
+            }
+            b->g_map[h] = cv.take<float>(B * 12 * b->Tf);
+        }
     }
     b->bytes = ake::align_up(cv.off, 256);
     return AKE_OK;
@@ -546,6 +606,7 @@ static void build_packs(ake_pcnet* n, bool train) {
     auto& p2p = train ? n->p2p_t : n->p2p;
     semi.assign(L, PackedConv()); up.assign(L, PackedConv());
     pc2pc.assign(L, {}); p2p.assign(L, {});
+    if (train) { n->pc2pc_d.assign(L, {}); n->p2p_d.assign(L, {}); n->head_key_d.clear(); n->head_tonic_d.clear(); n->head_genre_d.clear(); }
     auto bn = [&](const std::string& prefix, int C) -> std::string {
         if (!train) return prefix;
         ake_pcnet::BnLayer l;
@@ -577,15 +638,21 @@ static void build_packs(ake_pcnet* n, bool train) {
             u.b_off = n->blob.size();
             for (double v : b) n->blob.push_back(static_cast<float>(v));
             up[i] = u;
-            for (int j = 0; j < c.conv_layers; ++j)
+            for (int j = 0; j < c.conv_layers; ++j) {
                 p2p[i].push_back(fold_pack(n, m + "p2p.layer." + std::to_string(3 * j), bn(m + "p2p.layer." + std::to_string(3 * j + 1), d.out_p),
                                            d.out_p, j == 0 ? d.prev_pc + d.prev_p : d.out_p, k, k));
+                if (train) n->p2p_d[i].push_back(dgrad_pack(n, m + "p2p.layer." + std::to_string(3 * j) + ".weight", d.out_p,
+                                                            j == 0 ? d.prev_pc + d.prev_p : d.out_p, k, k));
+            }
         }
         semi[i] = fold_pack(n, m + "pool_semi", bn(m + "pool_semi_b", cs), cs, cs, 3, 3);
         const int pc_in = i == 0 ? 1 : d.out_p + d.prev_pc, pc_out = i == 0 ? c.n_filters : d.out_pc;
-        for (int j = 0; j < c.conv_layers; ++j)
+        for (int j = 0; j < c.conv_layers; ++j) {
             pc2pc[i].push_back(fold_pack(n, m + "pc2pc.layer." + std::to_string(3 * j) + ".conv2d",
                                          bn(m + "pc2pc.layer." + std::to_string(3 * j + 1), pc_out), pc_out, j == 0 ? pc_in : pc_out, 12, k));
+            if (train) n->pc2pc_d[i].push_back(dgrad_pack(n, m + "pc2pc.layer." + std::to_string(3 * j) + ".conv2d.weight", pc_out,
+                                                          j == 0 ? pc_in : pc_out, 12, k));
+        }
     }
     for (const char* head : {"tonic_classifier", "key_classifier", "genre_classifier"}) {
         const bool g = std::strcmp(head, "genre_classifier") == 0;
@@ -597,13 +664,30 @@ static void build_packs(ake_pcnet* n, bool train) {
         int ch = n->final_ch;
         for (int i = 0; i < c.head_layers; ++i) {
             const std::string base = std::string(head) + "." + std::to_string(3 * i) + (g ? "" : ".conv2d");
-            if (i == c.head_layers - 1) vec.push_back(fold_pack(n, base, "", 1, ch, g ? 2 : 12, k));
-            else {
+            auto& dvec = g ? n->head_genre_d : (is_key ? n->head_key_d : n->head_tonic_d);
+            if (i == c.head_layers - 1) {
+                vec.push_back(fold_pack(n, base, "", 1, ch, g ? 2 : 12, k));
+                if (train) dvec.push_back(dgrad_pack(n, base + ".weight", 1, ch, g ? 2 : 12, k));
+            } else {
                 const int co = i == 0 ? 2 * ch : ch;
                 vec.push_back(fold_pack(n, base, bn(std::string(head) + "." + std::to_string(3 * i + 1), co), co, ch, g ? 1 : 12, k));
+                if (train) dvec.push_back(dgrad_pack(n, base + ".weight", co, ch, g ? 1 : 12, k));
                 ch = co;
             }
         }
+    }
+    if (train) {   // raw copies of every tensor (small backward kernels read the reference layout) + the flat gradient layout
+        n->raw_w_off.assign(n->specs.size(), 0);
+        n->grad_off.assign(n->specs.size(), 0);
+        size_t goff = 0;
+        for (size_t i = 0; i < n->specs.size(); ++i) {
+            n->blob.resize(ake::align_up(n->blob.size(), 64));
+            n->raw_w_off[i] = n->blob.size();
+            for (float v : n->host[i].data) n->blob.push_back(v);
+            n->grad_off[i] = goff;
+            goff += n->host[i].data.size();
+        }
+        n->grad_floats = goff;
     }
 }
 
@@ -773,8 +857,8 @@ struct Fwd {
         const std::string m = "model.0.pc2pc.layer.";
         for (int j = 0; j < c.conv_layers; ++j) {
             const bool lastj = j == c.conv_layers - 1;           // the last conv writes channels [0, nf) of layer 1's concat buffer
-            float* dst = lastj ? b.cat[1] : ((j & 1) ? b.pcb[0] : b.pca[0]);
-            float* aff = !train ? nullptr : (lastj ? b.aff_cat[1] : ((j & 1) ? b.aff_pcb[0] : b.aff_pca[0]));
+            float* dst = lastj ? b.cat[1] : (train ? b.pcst[0][j] : ((j & 1) ? b.pcb[0] : b.pca[0]));
+            float* aff = !train ? nullptr : (lastj ? b.aff_cat[1] : b.aff_pcst[0][j]);
             if ((rc = conv(n->pc2pc[0][j], train ? n->pc2pc_t[0][j] : n->pc2pc[0][j], m + std::to_string(3 * j + 1), 1,
                            Src{src, cin, nullptr, 0, 0}, src_aff, B, 12, T0, true, dst, lastj ? ctot1 : c.n_filters, 0, aff,
                            "conv_mfma_kernel/pc2pc0")))
@@ -816,8 +900,8 @@ struct Fwd {
             float* out = nullptr;
             float* out_aff = nullptr;
             for (int j = 0; j < c.conv_layers; ++j) {
-                out = (j & 1) ? b.pb[i] : b.pa[i];
-                out_aff = !train ? nullptr : ((j & 1) ? b.aff_pb[i] : b.aff_pa[i]);
+                out = train ? b.pst[i][j] : ((j & 1) ? b.pb[i] : b.pa[i]);
+                out_aff = !train ? nullptr : b.aff_pst[i][j];
                 if ((rc = conv(n->p2p[i][j], train ? n->p2p_t[i][j] : n->p2p[i][j], m + "p2p.layer." + std::to_string(3 * j + 1), 0, sdesc,
                                in_aff, B, P, Ti, true, out, d.out_p, 0, out_aff, "conv_mfma_kernel/p2p")))
                     return rc;
@@ -834,8 +918,8 @@ struct Fwd {
             float* pdst = nullptr;
             float* pdst_aff = nullptr;
             for (int j = 0; j < c.conv_layers; ++j) {
-                pdst = (j & 1) ? b.pcb[i] : b.pca[i];
-                pdst_aff = !train ? nullptr : ((j & 1) ? b.aff_pcb[i] : b.aff_pca[i]);
+                pdst = train ? b.pcst[i][j] : ((j & 1) ? b.pcb[i] : b.pca[i]);
+                pdst_aff = !train ? nullptr : b.aff_pcst[i][j];
                 if ((rc = conv(n->pc2pc[i][j], train ? n->pc2pc_t[i][j] : n->pc2pc[i][j], m + "pc2pc.layer." + std::to_string(3 * j + 1), 1,
                                Src{psrc, cin, nullptr, 0, 0}, psrc_aff, B, 12, Ti, true, pdst, d.out_pc, 0, pdst_aff, "conv_mfma_kernel/pc2pc")))
                     return rc;
@@ -869,8 +953,8 @@ struct Fwd {
         float* pdst = nullptr;
         float* pdst_aff = nullptr;
         for (int j = 0; j < c.conv_layers; ++j) {
-            pdst = (j & 1) ? b.pcb[i] : b.pca[i];
-            pdst_aff = !train ? nullptr : ((j & 1) ? b.aff_pcb[i] : b.aff_pca[i]);
+            pdst = train ? b.pcst[i][j] : ((j & 1) ? b.pcb[i] : b.pca[i]);
+            pdst_aff = !train ? nullptr : b.aff_pcst[i][j];
             if ((rc = conv(n->pc2pc[i][j], train ? n->pc2pc_t[i][j] : n->pc2pc[i][j], m + std::to_string(3 * j + 1), 1,
                            Src{psrc, cin, nullptr, 0, 0}, psrc_aff, B, 12, Ti, true, pdst, cout, 0, pdst_aff,
                            L == 1 ? "conv_mfma_kernel/pc2pc0" : "conv_mfma_kernel/pc2pc")))
@@ -898,8 +982,8 @@ struct Fwd {
             for (int j = 0; j < c.head_layers; ++j) {
                 const PackedConv& pe = (*heads[h].ce)[j];
                 const bool lastj = j == c.head_layers - 1;
-                float* dst = lastj ? heads[h].map : heads[h].hid + (j & 1) * hid_half;
-                float* aff = (!train || lastj) ? nullptr : b.aff_hid[h] + (j & 1) * 3 * 2 * n->final_ch;
+                float* dst = lastj ? heads[h].map : (train ? b.hst[h][j] : heads[h].hid + (j & 1) * hid_half);
+                float* aff = (!train || lastj) ? nullptr : b.aff_hst[h][j];
                 if ((rc = conv(pe, train ? (*heads[h].ct)[j] : pe, lastj ? "" : std::string(heads[h].nm) + "." + std::to_string(3 * j + 1),
                                heads[h].kind, Src{src, hc, nullptr, 0, 0}, src_aff, B, 12, Tcur, false, dst, pe.cout, 0, aff,
                                h == 2 ? "conv_mfma_kernel/genre_head" : "conv_mfma_kernel/head")))
@@ -953,6 +1037,38 @@ int forward_impl(const ake_pcnet* n, bool train, const float* mel, int batch, in
 
 }  // namespace
 
+#include "pcnet_backward.h"
+
+// Flat gradient buffer: float entries of the state_dict in ake_pcnet_tensor_info order (running statistics get zeros).
+size_t ake_pcnet_grad_floats(const ake_pcnet* n) { return n ? n->grad_floats : 0; }
+
+int64_t ake_pcnet_grad_offset(const ake_pcnet* n, const char* name) {
+    if (!n || !name) return -1;
+    auto it = n->spec_index.find(name);
+    if (it == n->spec_index.end() || n->grad_off.empty()) return -1;
+    return static_cast<int64_t>(n->grad_off[it->second]);
+}
+
+int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int frames, const int64_t* seq_length, const float* key_out,
+                           const float* d_key, const float* d_tonic, const float* d_genre, float* grads_out, void* workspace,
+                           size_t ws_bytes, ake_stream_t stream) {
+    AKE_REQUIRE(n && mel && key_out && d_key && d_tonic && grads_out, AKE_ERR_INVALID, "pcnet backward: null argument");
+    AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
+    AKE_REQUIRE(!n->cfg.genre || d_genre, AKE_ERR_INVALID, "pcnet backward: genre head enabled but d_genre is null");
+    Buffers b;
+    int rc = plan_buffers(n, batch, batch, frames, workspace, &b, true);
+    if (rc) return rc;
+    AKE_REQUIRE(workspace && ws_bytes >= b.bytes, AKE_ERR_WORKSPACE, "pcnet backward: workspace %zu < %zu bytes", ws_bytes, b.bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    AKE_HIP_CHECK(hipMemsetAsync(grads_out, 0, sizeof(float) * n->grad_floats, s));
+    AKE_HIP_CHECK(hipMemsetAsync(b.stats2, 0, sizeof(double) * 3 * n->bn_channels, s));
+    Bwd bw{n, b, s, grads_out, batch};
+    rc = bw.run(mel, seq_length, d_key, d_tonic, d_genre, key_out);
+    if (rc) return rc;
+    AKE_HIP_CHECK(hipGetLastError());
+    return AKE_OK;
+}
+
 int ake_pcnet_forward_f32(const ake_pcnet* n, const float* mel, int batch, int frames, const int64_t* seq_length,
                           float* key_out, float* tonic_out, float* genre_out, void* workspace, size_t ws_bytes,
                           ake_stream_t stream) {
@@ -970,9 +1086,25 @@ static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frame
     AKE_REQUIRE(n && name, AKE_ERR_INVALID, "tap: null argument");
     AKE_REQUIRE(batch <= n->chunk_clips, AKE_ERR_INVALID, "tap: batch %d exceeds the chunk size %d", batch, n->chunk_clips);
     Buffers b;
-    int rc = plan_buffers(n, batch, batch, frames, const_cast<void*>(ws), &b);
+    const bool tr = std::strncmp(name, "train:", 6) == 0;      // buffers of the training-mode workspace (debugging the backward pass)
+    int rc = plan_buffers(n, batch, batch, frames, const_cast<void*>(ws), &b, tr);
     if (rc) return rc;
     const auto& c = n->cfg;
+    if (tr) {
+        const std::string t = name + 6;
+        const int L1 = c.num_layers - 1;
+        const LayerDims& dd = n->dims[L1];
+        *p = nullptr;
+        shape[0] = batch; shape[1] = 0;
+        if (t == "g_p") { *p = b.g_p[L1]; shape[1] = dd.out_p; shape[2] = c.pitches; shape[3] = b.Tl[L1]; }
+        if (t == "g_semi") { *p = b.g_semi[L1]; shape[1] = dd.out_p; shape[2] = c.pitches / 3; shape[3] = b.Tl[L1]; }
+        if (t == "g_cat") { *p = b.g_cat[L1]; shape[1] = dd.prev_pc + dd.out_p; shape[2] = 12; shape[3] = b.Tl[L1]; }
+        if (t == "g_pin") { *p = b.g_pin[L1]; shape[1] = dd.prev_pc + dd.prev_p; shape[2] = c.pitches; shape[3] = b.Tl[L1]; }
+        if (t == "z_p_last") { *p = b.pst[L1].back(); shape[1] = dd.out_p; shape[2] = c.pitches; shape[3] = b.Tl[L1]; }
+        AKE_REQUIRE(shape[1] > 0, AKE_ERR_INVALID, "tap: unknown training buffer '%s'", name);
+        if (std::getenv("AKE_DEBUG")) fprintf(stderr, "[ake] tap %s -> %p\n", name, (void*)*p);
+        return AKE_OK;
+    }
     const int L = c.num_layers, P = c.pitches;
     const std::string nm = name;
     auto set = [&](float* ptr, int64_t C, int64_t H, int64_t Tn) { *p = ptr; shape[0] = batch; shape[1] = C; shape[2] = H; shape[3] = Tn; return AKE_OK; };

@@ -1,0 +1,299 @@
+// Backward pass orchestration (implementation include of pcnet.hip; lives in its translation unit).
+//
+// ake_pcnet_backward_f32 consumes the workspace left by ake_pcnet_forward_train_f32 (raw convolution outputs, BatchNorm
+// batch statistics and affine tables) and the gradients of the loss with respect to the three outputs, and writes
+// dL/d(parameter) for every float entry of the state_dict into one flat buffer (layout: ake_pcnet_grad_offset).
+// Built for num_layers <= 2 (the reference default); deeper nets return AKE_ERR_UNSUPPORTED.
+#pragma once
+
+namespace {
+
+struct Bwd {
+    const ake_pcnet* n;
+    Buffers& b;
+    hipStream_t s;
+    float* grads;        // flat gradient buffer (device)
+    int B;
+
+    float* grad_of(const std::string& key) const { return grads + n->grad_off[n->spec_index.at(key)]; }
+    const float* raw_of(const std::string& key) const { return n->blob_dev + n->raw_w_off[n->spec_index.at(key)]; }
+    int bn_of(const std::string& name) const { return n->bn_index.at(name); }
+
+    // ga (gradient w.r.t. the activation a = lrelu(bn(z))) -> dz (gradient w.r.t. the raw conv output z), in place in `g`.
+    // g and z share the layout [B][ctot][HT]; the BatchNorm layer `bn_name` owns channels [coff, coff + C).
+    void bn_block_backward(const std::string& bn_name, float* g, const float* z, const float* aff, int ctot, int coff, int HT) {
+        const int bn = bn_of(bn_name);
+        const auto& l = n->bns[bn];
+        double* st2 = b.stats2 + 3 * l.ch_off;
+        const float* bst = b.bstats + 3 * l.ch_off;
+        float* coef = b.coef + 4 * l.ch_off;
+        dim3 grid(l.C, B);
+        {
+            ake::ProfScope ps("act_bwd_stats_kernel", s);
+            hipLaunchKernelGGL(act_bwd_stats_kernel, grid, dim3(256), 0, s, g, z, aff, bst, st2, ctot, coff, HT);
+        }
+        {
+            ake::ProfScope ps("bn_bwd_coef_kernel", s);
+            hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((l.C + 63) / 64), dim3(64), 0, s, st2, bst, n->blob_dev + l.gamma_off, coef,
+                               grad_of(bn_name + ".weight"), grad_of(bn_name + ".bias"), l.C);
+        }
+        {
+            ake::ProfScope ps("bn_bwd_apply_kernel", s);
+            hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, g, z, coef, ctot, coff, HT);
+        }
+    }
+
+    // weight gradient of one convolution: dW += corr(act(input), dz)
+    int wgrad(const PackedConv& pc, int kind, Src src, const float* in_aff, int H, int T_in, bool same_time, const float* dz, int dz_ctot,
+              int dz_coff, float* dW, const char* name) {
+        WgradArgs wa;
+        std::memset(&wa, 0, sizeof(wa));
+        ConvArgs& a = wa.c;
+        a.src0 = src.p0; a.c0 = src.c0; a.src1 = src.p1; a.c1 = src.c1; a.h1 = src.h1 > 0 ? src.h1 : 1;
+        a.H = H; a.T_in = T_in;
+        a.src0_clip_stride = static_cast<long long>(src.c0) * H * T_in;
+        a.src1_clip_stride = static_cast<long long>(src.c1) * a.h1 * T_in;
+        if (kind == 0) { a.py = pc.kh / 2; a.pad_l = pc.kw / 2; a.time_circ = 1; a.T_out = T_in; a.H_out = H; }
+        else {
+            a.py = 0; a.time_circ = 0;
+            a.pad_l = same_time ? pc.kw / 2 : 0;
+            a.T_out = same_time ? T_in : T_in - pc.kw + 1;
+            a.H_out = kind == 1 ? H : H - pc.kh + 1;
+        }
+        a.cout = pc.cout;
+        a.dst = const_cast<float*>(dz); a.dst_coff = dz_coff; a.dst_clip_stride = static_cast<long long>(dz_ctot) * a.H_out * a.T_out;
+        a.in_affine = in_aff;
+        wa.dW = dW; wa.KH = pc.kh; wa.KW = pc.kw;
+        const int KK = pc.kh * pc.kw;
+        const int MTC = (pc.cout + 15) / 16, NTK = (KK + 15) / 16;
+        // tile: rows x frames such that the patch of 8 channels + the dz tile fit the LDS budget
+        const int T4 = (a.T_out + 3) / 4 * 4;
+        int TT = std::min(T4, 128);
+        int R = kind == 0 ? std::min(H, 16) : H;
+        auto lds_of = [&](int R_, int TT_) {
+            const int Tp = (TT_ + pc.kw - 1 + 3) / 4 * 4;
+            return (static_cast<size_t>(8) * (R_ + pc.kh - 1) * Tp + static_cast<size_t>(pc.cout) * R_ * TT_) * sizeof(float);
+        };
+        while (lds_of(R, TT) > kLdsBudget && kind == 0 && R > 1) --R;
+        while (lds_of(R, TT) > kLdsBudget && TT > 4) TT -= 4;
+        AKE_REQUIRE(lds_of(R, TT) <= 160 * 1024, AKE_ERR_UNSUPPORTED, "wgrad %s: tile does not fit LDS", name);
+        a.R = R; a.TT = TT; a.Tp = (TT + pc.kw - 1 + 3) / 4 * 4;
+        a.n_row_tiles = (a.H_out + R - 1) / R;
+        a.n_time_tiles = (a.T_out + TT - 1) / TT;
+        const int tiles = a.n_row_tiles * a.n_time_tiles;
+        wa.rt_per_block = std::max(1, (tiles + 3) / 4);          // up to 4 workgroups per clip
+        dim3 grid((tiles + wa.rt_per_block - 1) / wa.rt_per_block, 1, B), block(512);
+        const size_t lds = lds_of(R, TT);
+        ake::ProfScope ps(name, s);
+#define AKE_WG(M_, N_) if (MTC == M_ && NTK == N_) { hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_>), grid, block, lds, s, wa); return AKE_OK; }
+        AKE_WG(1, 4) AKE_WG(1, 6) AKE_WG(2, 6) AKE_WG(1, 1) AKE_WG(2, 1) AKE_WG(1, 2) AKE_WG(2, 2)
+#undef AKE_WG
+        ake::set_error("wgrad %s: no kernel for cout=%d taps=%d", name, pc.cout, KK);
+        return AKE_ERR_UNSUPPORTED;
+    }
+
+    // data gradient of one convolution: dst(+)= conv(dz, flipped weights)
+    int dgrad(const PackedConv& pd, const PackedConv& fwd, int kind, const float* dz, int H, int T_dz, int T_in, bool same_time, float* dst,
+              int dst_ctot, int dst_coff, bool accumulate, const char* name) {
+        ConvGeom g;
+        g.py = fwd.kh - 1 - (kind == 0 ? fwd.kh / 2 : 0);
+        g.time_circ = kind == 0 ? 1 : 0;
+        const int pad_fwd = kind == 0 ? fwd.kw / 2 : (same_time ? fwd.kw / 2 : 0);
+        g.pad_l = fwd.kw - 1 - pad_fwd;
+        g.T_out = T_in;
+        g.H_out = H;
+        return run_conv(n, pd, kind == 0 ? 0 : 1, Src{dz, pd.cin, nullptr, 0, 0}, B, H, T_dz, true, false, dst, dst_ctot, dst_coff, s, name,
+                        nullptr, nullptr, &g, accumulate);
+    }
+
+    void bias_grad(const float* dz, int ctot, int coff, int C, int HT, float* db) {
+        ake::ProfScope ps("channel_sum_kernel", s);
+        hipLaunchKernelGGL(channel_sum_kernel, dim3(C, B), dim3(256), 0, s, dz, db, ctot, coff, HT);
+    }
+
+    // A stack of `nconv` convolutions (conv -> BN -> LReLU each).  g holds ga w.r.t. the last activation on entry and is
+    // ping-ponged with g2.  On exit *g_in_out holds ga w.r.t. the stack input (shape of the input: in_ctot channels).
+    int stack_backward(const std::vector<PackedConv>& fwd_t, const std::vector<PackedConv>& dpack, const std::string& prefix, bool conv2d_suffix,
+                       int kind, Src stack_in, const float* stack_in_aff, const std::vector<float*>& z, const std::vector<float*>& aff,
+                       int H, int Tn, float* g, float* g2, float* g_in, int g_in_ctot, const char* wname, const char* dname) {
+        const int nconv = static_cast<int>(fwd_t.size());
+        int rc;
+        for (int j = nconv - 1; j >= 0; --j) {
+            const PackedConv& pc = fwd_t[j];
+            const std::string cname = prefix + std::to_string(3 * j) + (conv2d_suffix ? ".conv2d" : "");
+            bn_block_backward(prefix + std::to_string(3 * j + 1), g, z[j], aff[j], pc.cout, 0, H * Tn);
+            // bias gradient under BatchNorm is exactly zero (the mean subtraction removes it); grads were zero-filled
+            Src in = j == 0 ? stack_in : Src{z[j - 1], fwd_t[j - 1].cout, nullptr, 0, 0};
+            const float* in_aff = j == 0 ? stack_in_aff : aff[j - 1];
+            if ((rc = wgrad(pc, kind, in, in_aff, H, Tn, true, g, pc.cout, 0, grad_of(cname + ".weight"), wname))) return rc;
+            float* dst = j == 0 ? g_in : g2;
+            const int dst_ctot = j == 0 ? g_in_ctot : fwd_t[j - 1].cout;
+            if (dst) {
+                if ((rc = dgrad(dpack[j], pc, kind, g, H, Tn, Tn, true, dst, dst_ctot, 0, false, dname))) return rc;
+            }
+            if (j > 0) std::swap(g, g2);
+        }
+        return AKE_OK;
+    }
+
+    int run(const float* mel, const int64_t* seq, const float* d_key, const float* d_tonic, const float* d_genre, const float* key_out) {
+        const auto& c = n->cfg;
+        const int L = c.num_layers, P = c.pitches, tp = c.time_pool_size;
+        AKE_REQUIRE(L <= 2, AKE_ERR_UNSUPPORTED, "backward: num_layers > 2 is not built yet");
+        AKE_REQUIRE(!c.max_pool, AKE_ERR_UNSUPPORTED, "backward: --max_pool is not built");
+        int rc;
+        const int Tf = b.Tf;
+        const int Tm = Tf - (c.kernel_size - 1) * c.head_layers;
+        const int i = L - 1;
+        const int Ti = b.Tl[i];
+        const LayerDims& d = n->dims[i];
+        const int fin = n->final_ch;
+
+        // ---- masked mean + sigmoid ----
+        PoolHeadBwdArgs pa;
+        std::memset(&pa, 0, sizeof(pa));
+        pa.d_out[0] = d_key; pa.d_out[1] = d_tonic; pa.d_out[2] = c.genre ? d_genre : nullptr;
+        pa.key_out = key_out;
+        pa.d_map[0] = b.g_map[0]; pa.d_map[1] = b.g_map[1]; pa.d_map[2] = c.genre ? b.g_map[2] : nullptr;
+        pa.rows[0] = 12; pa.rows[1] = 12; pa.rows[2] = 11;
+        pa.Tm = Tm; pa.seq = reinterpret_cast<const long long*>(seq);
+        pa.n_pool_layers = L - 1; pa.tp = tp; pa.shrink = (c.kernel_size - 1) * c.head_layers; pa.batch = B;
+        {
+            ake::ProfScope ps("head_pool_bwd_kernel", s);
+            hipLaunchKernelGGL(head_pool_bwd_kernel, dim3((B * 12 + 63) / 64, 3), dim3(64), 0, s, pa);
+        }
+        // features feeding the heads: pcf (final) for L > 1, the raw last pc2pc output (+affine) for L == 1
+        const float* feat = L > 1 ? b.pcf : b.pcst[0].back();
+        const float* feat_aff = L > 1 ? nullptr : b.aff_pcst[0].back();
+        float* g_feat = L > 1 ? b.g_pcf : b.g_pc[0];          // gradient w.r.t. the head input activation
+        AKE_HIP_CHECK(hipMemsetAsync(g_feat, 0, sizeof(float) * B * fin * 12 * Tf, s));
+
+        struct HeadRun { const std::vector<PackedConv>* ct; const std::vector<PackedConv>* cd; int kind; const char* nm; bool conv2d; };
+        HeadRun heads[3] = {{&n->head_key_t, &n->head_key_d, 1, "key_classifier", true},
+                            {&n->head_tonic_t, &n->head_tonic_d, 1, "tonic_classifier", true},
+                            {&n->head_genre_t, &n->head_genre_d, 2, "genre_classifier", false}};
+        for (int h = 0; h < (c.genre ? 3 : 2); ++h) {
+            const auto& ct = *heads[h].ct;
+            const auto& cd = *heads[h].cd;
+            const int nl = c.head_layers;
+            float* g = b.g_map[h];                 // dz of the last conv (no BatchNorm): [B][1][12][Tm] (genre: row 11 zero)
+            int Tcur = Tm;
+            for (int j = nl - 1; j >= 0; --j) {
+                const PackedConv& pc = ct[j];
+                const std::string cname = std::string(heads[h].nm) + "." + std::to_string(3 * j) + (heads[h].conv2d ? ".conv2d" : "");
+                const int T_in = Tcur + c.kernel_size - 1;
+                const int H_out = heads[h].kind == 2 ? 12 - pc.kh + 1 : 12;
+                if (j < nl - 1) bn_block_backward(std::string(heads[h].nm) + "." + std::to_string(3 * j + 1), g, b.hst[h][j], b.aff_hst[h][j], pc.cout, 0, 12 * Tcur);
+                else bias_grad(g, pc.cout, 0, pc.cout, 12 * Tcur, grad_of(cname + ".bias"));   // row 11 of the genre map gradient is zero
+                Src in = j == 0 ? Src{feat, fin, nullptr, 0, 0} : Src{b.hst[h][j - 1], ct[j - 1].cout, nullptr, 0, 0};
+                const float* in_aff = j == 0 ? feat_aff : b.aff_hst[h][j - 1];
+                // the genre gradient maps carry 12 rows (the last one zero), so circular rows reproduce its "valid" rows exactly
+                const int kind_w = 1;
+                if ((rc = wgrad(pc, kind_w, in, in_aff, 12, T_in, false, g, pc.cout, 0, grad_of(cname + ".weight"), "conv_wgrad_kernel/head"))) return rc;
+                float* dst = j == 0 ? g_feat : b.g_hid;
+                if ((rc = dgrad(cd[j], pc, 1, g, 12, Tcur, T_in, false, dst, j == 0 ? fin : ct[j - 1].cout, 0, j == 0, "conv_mfma_kernel/head_dgrad")))
+                    return rc;
+                g = b.g_hid;
+                Tcur = T_in;
+                (void)H_out;
+            }
+        }
+
+        float* g_last = b.g_pc[i];                                   // ga w.r.t. the last pc2pc activation of the last layer
+        float* g_last2 = b.g_pc[i] + static_cast<size_t>(B) * (i == 0 ? c.n_filters : d.out_pc) * 12 * Ti;
+        if (L > 1) {
+            const long long total = static_cast<long long>(B) * d.out_pc * 12 * ((Ti / tp) + (Ti % tp ? 1 : 0));
+            ake::ProfScope ps("time_pool_bwd_kernel", s);
+            hipLaunchKernelGGL(time_pool_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_pcf, b.pcst[i].back(),
+                               b.aff_pcst[i].back(), g_last, d.out_pc, 12, Ti, tp, d.out_pc, 0, total);
+        }
+        if (L == 1) {
+            // single layer: pc2pc0 stack straight down to fold0
+            if ((rc = stack_backward(n->pc2pc_t[0], n->pc2pc_d[0], "model.0.pc2pc.layer.", true, 1, Src{b.fold0, 1, nullptr, 0, 0}, nullptr,
+                                     b.pcst[0], b.aff_pcst[0], 12, Ti, g_last, g_last2, b.g_fold0, 1, "conv_wgrad_kernel/pc2pc0", "conv_mfma_kernel/pc2pc0_dgrad")))
+                return rc;
+            return semi_backward(0, mel, nullptr, b.g_fold0, 1, 0, nullptr);
+        }
+
+        // ---- layer 1: pc2pc stack (input = concat buffer) ----
+        const int ctot = d.prev_pc + d.out_p;
+        if ((rc = stack_backward(n->pc2pc_t[1], n->pc2pc_d[1], "model.1.pc2pc.layer.", true, 1, Src{b.cat[1], ctot, nullptr, 0, 0}, b.aff_cat[1],
+                                 b.pcst[1], b.aff_pcst[1], 12, Ti, g_last, g_last2, b.g_cat[1], ctot, "conv_wgrad_kernel/pc2pc", "conv_mfma_kernel/pc2pc_dgrad")))
+            return rc;
+        // channels [prev_pc, ctot) of g_cat: gradient of the folded semitone features -> pool_semi(1) -> pitch stream
+        const std::vector<float*>& zp = b.pst[1];
+        float* g_p = b.g_p[1];
+        float* g_p2 = b.g_p[1] + static_cast<size_t>(B) * d.out_p * P * Ti;
+        if ((rc = semi_backward(1, zp.back(), b.aff_pst[1].back(), b.g_cat[1], ctot, d.prev_pc, g_p))) return rc;
+        // ---- pitch convs; input = (mel | psix repeated) ----
+        Src pin{mel, d.prev_p, b.psix[1], d.prev_pc, 36};
+        if ((rc = stack_backward(n->p2p_t[1], n->p2p_d[1], "model.1.p2p.layer.", false, 0, pin, b.aff_p2pin[1], zp, b.aff_pst[1], P, Ti, g_p, g_p2,
+                                 b.g_pin[1], d.prev_p + d.prev_pc, "conv_wgrad_kernel/p2p", "conv_mfma_kernel/p2p_dgrad")))
+            return rc;
+        // ---- repeat (x P/36) backward, then up_sixth ----
+        {
+            const long long total = static_cast<long long>(B) * d.prev_pc * 36 * Ti;
+            ake::ProfScope ps("repeat_sum_kernel", s);
+            hipLaunchKernelGGL(repeat_sum_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_pin[1], b.g_psix[1],
+                               d.prev_p + d.prev_pc, d.prev_p, d.prev_pc, P, Ti, total);
+        }
+        bn_block_backward("model.1.up_sixth_b", b.g_psix[1], b.psix[1], b.aff_p2pin[1] + 3 * d.prev_p, d.prev_pc, 0, 36 * Ti);
+        {
+            ake::ProfScope ps("up_sixth_bwd_weight_kernel", s);
+            hipLaunchKernelGGL(up_sixth_bwd_weight_kernel, dim3(d.prev_pc * d.prev_pc * 3, B), dim3(64), 0, s, b.g_psix[1], b.cat[1],
+                               static_cast<long long>(ctot) * 12 * Ti, b.aff_cat[1], grad_of("model.1.up_sixth.weight"), d.prev_pc, Ti);
+        }
+        {
+            const long long total = static_cast<long long>(B) * d.prev_pc * 12 * Ti;
+            ake::ProfScope ps("up_sixth_bwd_data_kernel", s);
+            hipLaunchKernelGGL(up_sixth_bwd_data_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_psix[1],
+                               raw_of("model.1.up_sixth.weight"), b.g_cat[1], ctot, d.prev_pc, Ti, total);
+        }
+        // ---- layer 0: its last conv's activation = channels [0, nf) of the concat buffer (two consumers, both summed into g_cat) ----
+        {
+            // move the slice into the dense pc0 gradient buffer, then the generic stack walk
+            float* g0 = b.g_pc[0];
+            AKE_HIP_CHECK(hipMemcpy2DAsync(g0, sizeof(float) * c.n_filters * 12 * Ti, b.g_cat[1], sizeof(float) * ctot * 12 * Ti,
+                                           sizeof(float) * c.n_filters * 12 * Ti, B, hipMemcpyDeviceToDevice, s));
+            // the raw output of that conv lives inside cat[1] (strided): the stack walk needs it dense as well
+            AKE_HIP_CHECK(hipMemcpy2DAsync(b.pcst[0].back(), sizeof(float) * c.n_filters * 12 * Ti, b.cat[1], sizeof(float) * ctot * 12 * Ti,
+                                           sizeof(float) * c.n_filters * 12 * Ti, B, hipMemcpyDeviceToDevice, s));
+            std::vector<float*> aff0 = b.aff_pcst[0];
+            aff0.back() = b.aff_cat[1];
+            float* g02 = g0 + static_cast<size_t>(B) * c.n_filters * 12 * Ti;
+            if ((rc = stack_backward(n->pc2pc_t[0], n->pc2pc_d[0], "model.0.pc2pc.layer.", true, 1, Src{b.fold0, 1, nullptr, 0, 0}, nullptr, b.pcst[0],
+                                     aff0, 12, Ti, g0, g02, b.g_fold0, 1, "conv_wgrad_kernel/pc2pc0", "conv_mfma_kernel/pc2pc0_dgrad")))
+                return rc;
+        }
+        return semi_backward(0, mel, nullptr, b.g_fold0, 1, 0, nullptr);
+    }
+
+    // pool_semi(layer) + BatchNorm + LeakyReLU + octave fold, backward.  gfold: channel slice [g_coff, g_coff + C) of a [B][g_ctot][12][T]
+    // gradient.  x / x_aff: the pitch tensor the semitone conv read.  ga_x (nullable): receives dL/d(act(x)).
+    int semi_backward(int layer, const float* x, const float* x_aff, const float* gfold, int g_ctot, int g_coff, float* ga_x) {
+        const PackedConv& pc = n->semi_t[layer];
+        const int C = pc.cin, P = n->cfg.pitches, Tn = b.Tl[layer];
+        const std::string m = "model." + std::to_string(layer) + ".";
+        float* g = b.g_semi[layer];
+        {
+            const long long total = static_cast<long long>(B) * C * 12 * Tn;
+            ake::ProfScope ps("fold_bwd_kernel", s);
+            hipLaunchKernelGGL(fold_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, gfold, b.semi_raw[layer],
+                               b.aff_semi[layer], g, C, P / 36, Tn, g_ctot, g_coff, total);
+        }
+        bn_block_backward(m + "pool_semi_b", g, b.semi_raw[layer], b.aff_semi[layer], C, 0, (P / 3) * Tn);
+        {
+            ake::ProfScope ps("semi_bwd_weight_kernel", s);
+            hipLaunchKernelGGL(semi_bwd_weight_kernel, dim3(C * C * 9, B), dim3(64), 0, s, g, x, x_aff, grad_of(m + "pool_semi.weight"), C, P, Tn);
+        }
+        if (ga_x) {
+            const long long total = static_cast<long long>(B) * C * P * Tn;
+            ake::ProfScope ps("semi_bwd_data_kernel", s);
+            hipLaunchKernelGGL(semi_bwd_data_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, g, raw_of(m + "pool_semi.weight"),
+                               ga_x, C, P, Tn, total);
+        }
+        return AKE_OK;
+    }
+};
+
+}  // namespace

@@ -1,0 +1,417 @@
+// Backward-pass kernels of PitchClassNet (training, models.py:952-963 -> autograd in the reference).
+// Included by pcnet.hip only.  First correct version: every op has its own kernel; BatchNorm backward is two
+// passes (reduce, apply).  The convolution data gradients reuse conv_mfma_kernel with transposed / flipped
+// weight fragments; the weight gradients use conv_wgrad_kernel below (f32 MFMA, reduction over positions).
+//
+// Notation per BatchNorm block   z = conv(x)   a = lrelu(gamma * zhat + beta),  zhat = (z - mu) * rstd:
+//   ga  = dL/da            (arrives from the consumer's data-gradient)
+//   g1  = ga * lrelu'(.)   S1 = sum g1,  S2 = sum g1 * zhat,  S3 = sum (z - mu)   (act_bwd_stats_kernel)
+//   dz  = gamma*rstd * (g1 - S1/N - zhat * S2/N)                   (bn_bwd_coef_kernel + bn_bwd_apply_kernel)
+//   dgamma = S2, dbeta = S1
+#pragma once
+
+#include "pcnet_kernels.h"
+
+namespace ake_k {
+
+// ---- masked temporal mean + sigmoid, backward (models.py:754-804) -----------------------------------------------
+struct PoolHeadBwdArgs {
+    const float* d_out[3];    // dL/d(key_out, tonic_out, genre_out)  [B][rows]
+    const float* key_out;     // sigmoid output (for sigma')
+    float* d_map[3];          // [B][12][Tm] each (genre: row 11 is written as zeros)
+    int rows[3];
+    int Tm;
+    const long long* seq;
+    int n_pool_layers, tp, shrink, batch;
+};
+
+__global__ void head_pool_bwd_kernel(PoolHeadBwdArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int which = blockIdx.y;
+    if (a.d_map[which] == nullptr || i >= a.batch * 12) return;
+    const int clip = i / 12, row = i - clip * 12;
+    float* dm = a.d_map[which] + static_cast<long long>(i) * a.Tm;
+    if (row >= a.rows[which]) {
+        for (int t = 0; t < a.Tm; ++t) dm[t] = 0.f;
+        return;
+    }
+    int L = a.Tm;
+    if (a.seq) {
+        long long l = a.seq[clip];
+        for (int k = 0; k < a.n_pool_layers; ++k) l = l / a.tp;
+        L = static_cast<int>(l) - a.shrink;
+        if (L > a.Tm) L = a.Tm;
+        if (L < 0) L = a.Tm + L > 0 ? a.Tm + L : 0;
+    }
+    float g = a.d_out[which][clip * a.rows[which] + row];
+    if (which == 0) {
+        const float y = a.key_out[clip * 12 + row];
+        g *= y * (1.f - y);
+    }
+    const float gl = L > 0 ? g / static_cast<float>(L) : 0.f;
+    for (int t = 0; t < a.Tm; ++t) dm[t] = t < L ? gl : 0.f;
+}
+
+// ---- LeakyReLU' and the BatchNorm reductions -------------------------------------------------------------------------
+// g (in: ga, out: g1) and z share the layout [B][ctot][HT]; channels [coff, coff + C) are processed.
+// grid = (C, B); stats2[c] += (sum g1, sum g1 * zhat, sum (z - mean_f32))
+// The third sum is what makes the gradient leave this block with sum(dz) == 0 to rounding: the consumers (weight
+// gradients) multiply dz with activations that have a large common mean, so a per-channel offset of a few 1e-8 in dz
+// would otherwise show up as a 1e-3 relative error in dW.
+__global__ __launch_bounds__(256) void act_bwd_stats_kernel(float* __restrict__ g, const float* __restrict__ z,
+                                                            const float* __restrict__ aff, const float* __restrict__ bstats,
+                                                            double* __restrict__ stats2, int ctot, int coff, int HT) {
+    const int c = blockIdx.x, clip = blockIdx.y;
+    const long long base = (static_cast<long long>(clip) * ctot + coff + c) * HT;
+    const float sc = aff[3 * c], sh = aff[3 * c + 1], ng = aff[3 * c + 2];
+    const float mu = bstats[3 * c], rstd = rsqrtf(bstats[3 * c + 1] + 1e-5f);
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int i = threadIdx.x; i < HT; i += 256) {
+        const float zz = z[base + i];
+        const float pre = fmaf(zz, sc, sh);
+        const float g1 = g[base + i] * (pre > 0.f ? 1.f : ng);
+        g[base + i] = g1;
+        const float zc = zz - mu;
+        s1 += g1;
+        s2 = fmaf(g1, zc * rstd, s2);
+        s3 += zc;
+    }
+    __shared__ float r1[4], r2[4], r3[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); s3 += __shfl_xor(s3, o); }
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; r3[threadIdx.x >> 6] = s3; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(stats2 + 3 * c, static_cast<double>(r1[0]) + r1[1] + r1[2] + r1[3]);
+        atomicAdd(stats2 + 3 * c + 1, static_cast<double>(r2[0]) + r2[1] + r2[2] + r2[3]);
+        atomicAdd(stats2 + 3 * c + 2, static_cast<double>(r3[0]) + r3[1] + r3[2] + r3[3]);
+    }
+}
+
+// per channel: dz = c0 * g1 + c1 * (z - mean) + c2;  dgamma = S2, dbeta = S1.  coef[c] = (c0, c1, c2, mean)
+// c2 is solved in double from the ROUNDED c0, c1 so that sum(dz) vanishes for the values the apply kernel really uses.
+__global__ void bn_bwd_coef_kernel(const double* __restrict__ stats2, const float* __restrict__ bstats, const float* __restrict__ gamma,
+                                   float* __restrict__ coef, float* __restrict__ d_gamma, float* __restrict__ d_beta, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double N = bstats[3 * c + 2];
+    const double rstd = 1.0 / sqrt(static_cast<double>(bstats[3 * c + 1]) + 1e-5);
+    const double S1 = stats2[3 * c], S2 = stats2[3 * c + 1], S3 = stats2[3 * c + 2];
+    const double k1 = gamma[c] * rstd;
+    const float c0 = static_cast<float>(k1);
+    const float c1 = static_cast<float>(-k1 * S2 / N * rstd);
+    coef[4 * c] = c0;
+    coef[4 * c + 1] = c1;
+    coef[4 * c + 2] = static_cast<float>(-(static_cast<double>(c0) * S1 + static_cast<double>(c1) * S3) / N);
+    coef[4 * c + 3] = bstats[3 * c];
+    d_gamma[c] = static_cast<float>(S2);
+    d_beta[c] = static_cast<float>(S1);
+}
+
+// dz = c0*g1 + c1*(z - mean) + c2 in place on g; same layout / grid as act_bwd_stats_kernel
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ z,
+                                                           const float* __restrict__ coef, int ctot, int coff, int HT) {
+    const int c = blockIdx.x, clip = blockIdx.y;
+    const long long base = (static_cast<long long>(clip) * ctot + coff + c) * HT;
+    const float c0 = coef[4 * c], c1 = coef[4 * c + 1], c2 = coef[4 * c + 2], mu = coef[4 * c + 3];
+    for (int i = threadIdx.x; i < HT; i += 256) g[base + i] = fmaf(g[base + i], c0, fmaf(z[base + i] - mu, c1, c2));
+}
+
+// sum over (clip, positions) of one channel slice -> bias gradient of a convolution without BatchNorm
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int ctot, int coff, int HT) {
+    const int c = blockIdx.x, clip = blockIdx.y;
+    const long long base = (static_cast<long long>(clip) * ctot + coff + c) * HT;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < HT; i += 256) s += g[base + i];
+    __shared__ float r[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + c, r[0] + r[1] + r[2] + r[3]);
+}
+
+// ---- pooling / fold / repeat routing -------------------------------------------------------------------------------
+// MaxPool2d((1,tp)) backward: the pooled input was a = act(z) (aff may be null = already final); the gradient goes to the
+// first maximum of each window, everything else (and the floor tail) gets zero.  One thread per pooled element.
+__global__ void time_pool_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ z, const float* __restrict__ aff,
+                                     float* __restrict__ ga, int C, int H, int T, int tp, int gp_ctot, int gp_coff, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int To = T / tp;
+    const int nt = To + (T - To * tp > 0 ? 1 : 0);                 // one extra "window" zero-fills the tail
+    const int t = static_cast<int>(i % nt);
+    long long q = i / nt;
+    const int y = static_cast<int>(q % H);
+    q /= H;
+    const int c = static_cast<int>(q % C);
+    const long long clip = q / C;
+    const long long zb = ((clip * C + c) * H + y) * T;
+    if (t >= To) {
+        for (int j = To * tp; j < T; ++j) ga[zb + j] = 0.f;
+        return;
+    }
+    int best = 0;
+    float bv = affine_act(z[zb + static_cast<long long>(t) * tp], aff, c);
+    for (int j = 1; j < tp; ++j) {
+        const float v = affine_act(z[zb + static_cast<long long>(t) * tp + j], aff, c);
+        if (v > bv) { bv = v; best = j; }
+    }
+    const float g = gp[((clip * gp_ctot + gp_coff + c) * H + y) * To + t];
+    for (int j = 0; j < tp; ++j) ga[zb + static_cast<long long>(t) * tp + j] = j == best ? g : 0.f;
+}
+
+// Pitch2PitchClassPool backward: route gfold[c][p][t] (channel slice of a concat gradient) to the arg-max octave.
+__global__ void fold_bwd_kernel(const float* __restrict__ gfold, const float* __restrict__ z, const float* __restrict__ aff,
+                                float* __restrict__ ga, int C, int n_oct, int T, int g_ctot, int g_coff, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int t = static_cast<int>(i % T);
+    long long q = i / T;
+    const int p = static_cast<int>(q % 12);
+    q /= 12;
+    const int c = static_cast<int>(q % C);
+    const long long clip = q / C;
+    const long long zb = ((clip * C + c) * (12 * n_oct) + p) * T + t;
+    int best = 0;
+    float bv = affine_act(z[zb], aff, c);
+    for (int o = 1; o < n_oct; ++o) {
+        const float v = affine_act(z[zb + static_cast<long long>(o) * 12 * T], aff, c);
+        if (v > bv) { bv = v; best = o; }
+    }
+    const float g = gfold[((clip * g_ctot + g_coff + c) * 12 + p) * T + t];
+    for (int o = 0; o < n_oct; ++o) ga[zb + static_cast<long long>(o) * 12 * T] = o == best ? g : 0.f;
+}
+
+// PitchClass2Pitch backward: gpsix[c][r][t] = sum_o gin[cp + c][36*o + r][t]   (gin = gradient of the pitch-conv input)
+__global__ void repeat_sum_kernel(const float* __restrict__ gin, float* __restrict__ gps, int cin_tot, int cp, int C, int P, int T,
+                                  long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int t = static_cast<int>(i % T);
+    long long q = i / T;
+    const int r = static_cast<int>(q % 36);
+    q /= 36;
+    const int c = static_cast<int>(q % C);
+    const long long clip = q / C;
+    const float* s = gin + ((clip * cin_tot + cp + c) * P + r) * T + t;
+    float acc = 0.f;
+    for (int o = 0; o < P / 36; ++o) acc += s[static_cast<long long>(o) * 36 * T];
+    gps[i] = acc;
+}
+
+// ---- semitone conv (3x3, stride (3,1), frames circular) backward ----------------------------------------------------
+// data: ga[ci][3s+dy][t] = sum_{co,dx} dz[co][s][(t - dx + 1) mod T] * w[co][ci][dy][dx]      (w in reference layout)
+__global__ void semi_bwd_data_kernel(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ ga, int C, int H, int T,
+                                     long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int t = static_cast<int>(i % T);
+    long long q = i / T;
+    const int r = static_cast<int>(q % H);
+    q /= H;
+    const int ci = static_cast<int>(q % C);
+    const long long clip = q / C;
+    const int s = r / 3, dy = r - 3 * s;
+    float acc = 0.f;
+    for (int co = 0; co < C; ++co) {
+        const float* drow = dz + ((clip * C + co) * (H / 3) + s) * T;
+        const float* wp = w + ((co * C + ci) * 3 + dy) * 3;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) acc = fmaf(drow[wrap(t - dx + 1, T)], wp[dx], acc);
+    }
+    ga[i] = acc;
+}
+
+// weight: dW[co][ci][dy][dx] += sum_{s,t} dz[co][s][t] * act(x[ci][3s+dy][(t+dx-1) mod T]);  grid (C*C*9 / 64.., B), wave-reduced
+__global__ __launch_bounds__(64) void semi_bwd_weight_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                             const float* __restrict__ x_aff, float* __restrict__ dW, int C, int H, int T) {
+    const int widx = blockIdx.x;                 // (co, ci, dy, dx)
+    const int clip = blockIdx.y;
+    const int dx = widx % 3, dy = (widx / 3) % 3, ci = (widx / 9) % C, co = widx / (9 * C);
+    const int S = H / 3;
+    const float* d = dz + (static_cast<long long>(clip) * C + co) * S * T;
+    const float* xs = x + (static_cast<long long>(clip) * C + ci) * H * T;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < S * T; i += 64) {
+        const int s = i / T, t = i - s * T;
+        acc = fmaf(d[i], affine_act(xs[(3 * s + dy) * T + wrap(t + dx - 1, T)], x_aff, ci), acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (threadIdx.x == 0) atomicAdd(dW + widx, acc);
+}
+
+// ---- up_sixth (ConvTranspose2d (3,1)/(3,1)) backward -----------------------------------------------------------------
+// data: ga_pc[ci][p][t] += sum_{co,j} dz[co][3p+j][t] * w[ci][co][j]      (accumulates into a channel slice of a concat gradient)
+__global__ void up_sixth_bwd_data_kernel(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ gcat, int g_ctot, int C,
+                                         int T, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int t = static_cast<int>(i % T);
+    long long q = i / T;
+    const int p = static_cast<int>(q % 12);
+    q /= 12;
+    const int ci = static_cast<int>(q % C);
+    const long long clip = q / C;
+    float acc = 0.f;
+    for (int co = 0; co < C; ++co)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc = fmaf(dz[((clip * C + co) * 36 + 3 * p + j) * T + t], w[(ci * C + co) * 3 + j], acc);
+    gcat[((clip * g_ctot + ci) * 12 + p) * T + t] += acc;
+}
+
+// weight: dW[ci][co][j] += sum_{p,t} dz[co][3p+j][t] * act(x[ci][p][t])     grid (C*C*3, B)
+__global__ __launch_bounds__(64) void up_sixth_bwd_weight_kernel(const float* __restrict__ dz, const float* __restrict__ x, long long x_clip_stride,
+                                                                 const float* __restrict__ x_aff, float* __restrict__ dW, int C, int T) {
+    const int widx = blockIdx.x;                 // (ci, co, j)
+    const int clip = blockIdx.y;
+    const int j = widx % 3, co = (widx / 3) % C, ci = widx / (3 * C);
+    const float* d = dz + (static_cast<long long>(clip) * C + co) * 36 * T;
+    const float* xs = x + clip * x_clip_stride + static_cast<long long>(ci) * 12 * T;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < 12 * T; i += 64) {
+        const int p = i / T, t = i - p * T;
+        acc = fmaf(d[(3 * p + j) * T + t], affine_act(xs[i], x_aff, ci), acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (threadIdx.x == 0) atomicAdd(dW + widx, acc);
+}
+
+// ---- convolution weight gradient on f32 MFMA --------------------------------------------------------------------------
+//   dW[co][ci][dy][dx] = sum_{clip, y, t} dz[co][y][t] * act(in[ci][(y + dy - py) mod H][t + dx - pad_l])
+// GEMM view per input channel: D[m = co][n = (dy,dx)] += sum_{k = position} A[m][k] * B[k][n]
+//   A[co][pos] = dz tile in LDS,   B[pos][(dy,dx)] = the forward's input patch in LDS read at (y+dy, t+dx)
+// Workgroup = (clip, group of row tiles); wave w owns input channel c_lo + w of the current chunk of <= 8 channels and keeps
+// MTC x NTK accumulator tiles (16 output channels x 16 kernel taps each) across all row tiles; they are flushed with float
+// atomics once per (clip group, chunk).
+struct WgradArgs {
+    ConvArgs c;               // forward geometry; c.dst = dz (read), c.dst_coff / dst_clip_stride address it; c.w unused
+    float* dW;                // [cout][cin][KH][KW] (+=)
+    int KH, KW;
+    int rt_per_block;         // row tiles per workgroup
+};
+
+template <int MTC, int NTK>
+__global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs wa) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ConvArgs& a = wa.c;
+    const int KH = wa.KH, KW = wa.KW, KK = KH * KW;
+    const int cin = a.c0 + a.c1;
+    const int clip = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int R_in = a.R + KH - 1;
+    const int Tp = a.Tp;                       // patch pitch (>= TT + KW - 1)
+    const int TTp = a.TT;                      // dz tile pitch (multiple of 4)
+    const int cstride = R_in * Tp;
+    float* const ldsZ = lds + nw * cstride;    // dz tile [cout][R][TTp]
+    const float* s0 = a.src0 + clip * a.src0_clip_stride;
+    const float* s1 = a.src1 ? a.src1 + clip * a.src1_clip_stride : nullptr;
+    const float* dzc = a.dst + clip * a.dst_clip_stride;
+    const int ncb = (Tp + 63) >> 6;
+    const bool fast_wrap = a.T_in >= Tp;
+    // per-lane kernel-tap offsets of the B operand: column c16 of N-tile nt <-> tap k' = 16*nt + c16 -> (dy, dx)
+    int koff[NTK];
+#pragma unroll
+    for (int nt = 0; nt < NTK; ++nt) {
+        int kk = 16 * nt + r16;
+        if (kk >= KK) kk = KK - 1;             // padded columns read a valid address, never stored
+        const int dy = kk / KW;
+        koff[nt] = dy * Tp + (kk - dy * KW);
+    }
+    const int tile0 = blockIdx.x * wa.rt_per_block;
+
+    for (int c_lo = 0; c_lo < cin; c_lo += nw) {
+        const int cc = cin - c_lo < nw ? cin - c_lo : nw;
+        f32x4 acc[MTC][NTK];
+#pragma unroll
+        for (int m = 0; m < MTC; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NTK; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ti = 0; ti < wa.rt_per_block; ++ti) {
+            const int tile = tile0 + ti;
+            const int row_tile = tile / a.n_time_tiles;
+            if (row_tile >= a.n_row_tiles) break;
+            const int time_tile = tile - row_tile * a.n_time_tiles;
+            const int y0 = row_tile * a.R, t0 = time_tile * a.TT;
+            const int rows_here = a.H_out - y0 < a.R ? a.H_out - y0 : a.R;
+            const int tt_here = a.T_out - t0 < a.TT ? a.T_out - t0 : a.TT;
+            __syncthreads();
+            // ---- stage the input patch of channels [c_lo, c_lo+cc) (same loader as the forward conv) ----
+            {
+                const int nrows = cc * R_in;
+                for (int rr = wave; rr < nrows; rr += nw) {
+                    const int cl = rr / R_in, rj = rr - cl * R_in;
+                    const int cs = c_lo + cl;
+                    int row = y0 - a.py + rj;
+                    row += row < 0 ? a.H : 0;
+                    row -= row >= a.H ? a.H : 0;
+                    float asc = 1.f, ash = 0.f, ang = 1.f;
+                    if (a.in_affine) { asc = a.in_affine[3 * cs]; ash = a.in_affine[3 * cs + 1]; ang = a.in_affine[3 * cs + 2]; }
+                    const float* srow = cs < a.c0 ? s0 + (static_cast<long long>(cs) * a.H + row) * a.T_in
+                                                  : s1 + (static_cast<long long>(cs - a.c0) * a.h1 + (row % a.h1)) * a.T_in;
+                    for (int h = 0; h < ncb; ++h) {
+                        const int tj = lane + 64 * h;
+                        if (tj >= Tp) break;
+                        int tin = t0 - a.pad_l + tj;
+                        float v = 0.f;
+                        bool ok = true;
+                        if (a.time_circ) {
+                            if (fast_wrap) { tin += tin < 0 ? a.T_in : 0; tin -= tin >= a.T_in ? a.T_in : 0; }
+                            else tin = wrap(tin, a.T_in);
+                        } else ok = tin >= 0 && tin < a.T_in;
+                        if (ok) { const float x = fmaf(srow[tin], asc, ash); v = x > 0.f ? x : x * ang; }
+                        lds[rr * Tp + tj] = v;
+                    }
+                }
+                // ---- dz tile, zero outside the valid rows / frames ----
+                const int nz = a.cout * a.R;
+                for (int rr = wave; rr < nz; rr += nw) {
+                    const int co = rr / a.R, ry = rr - co * a.R;
+                    const float* zrow = dzc + (static_cast<long long>(a.dst_coff + co) * a.H_out + y0 + ry) * a.T_out + t0;
+                    for (int tj = lane; tj < TTp; tj += 64) ldsZ[rr * TTp + tj] = (ry < rows_here && tj < tt_here) ? zrow[tj] : 0.f;
+                }
+            }
+            __syncthreads();
+            if (wave >= cc) continue;
+            const float* patch = lds + wave * cstride;
+            for (int y = 0; y < rows_here; ++y) {
+                for (int ts = 0; ts < TTp; ts += 4) {
+                    float av[MTC], bv[NTK];
+#pragma unroll
+                    for (int m = 0; m < MTC; ++m) {
+                        const int co = 16 * m + r16;
+                        av[m] = co < a.cout ? ldsZ[(co * a.R + y) * TTp + ts + q] : 0.f;
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NTK; ++nt) bv[nt] = patch[y * Tp + ts + q + koff[nt]];
+#pragma unroll
+                    for (int m = 0; m < MTC; ++m)
+#pragma unroll
+                        for (int nt = 0; nt < NTK; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[nt], acc[m][nt], 0, 0, 0);
+                }
+            }
+        }
+        // ---- flush: D[row = co 4q+reg][col = tap c16] ----
+        if (wave < cc) {
+            const int ci = c_lo + wave;
+#pragma unroll
+            for (int m = 0; m < MTC; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NTK; ++nt) {
+                    const int kk = 16 * nt + r16;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int co = 16 * m + 4 * q + reg;
+                        if (co < a.cout && kk < KK) atomicAdd(wa.dW + (static_cast<long long>(co) * cin + ci) * KK + kk, acc[m][nt][reg]);
+                    }
+                }
+        }
+    }
+}
+
+}  // namespace ake_k

@@ -51,6 +51,7 @@ struct ConvArgs {
     int Tp;                   // LDS row pitch in floats (multiple of 4, >= TT + KW - 1)
     const float* in_affine;   // [c0+c1][3] (scale, shift, negative slope) applied to every staged input value, or null
     double* stats;            // [cout][2] += (sum, sum of squares) of the raw outputs, or null
+    int accumulate;           // 1: dst += result (several data-gradients landing on one tensor)
 };
 
 __device__ __forceinline__ int wrap(int i, int n) {
@@ -505,7 +506,8 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
                     float v = acc[mt][nt][reg] + a.bias[co];
                     if (a.stats) { st1[nt] += v; st2[nt] = fmaf(v, v, st2[nt]); }
                     if (a.lrelu) v = v > 0.f ? v : v * kSlope;
-                    d[((a.dst_coff + co) * a.H_out + (y0 + r)) * row_elems + tl] = v;
+                    float* dp = d + ((a.dst_coff + co) * a.H_out + (y0 + r)) * row_elems + tl;
+                    *dp = a.accumulate ? *dp + v : v;
                 }
             }
             if (++j == J) { j = 0; ++r; }

@@ -87,6 +87,36 @@ class PitchClassNetLayer(nn.Module):
         self.out_pc = out_pc
 
 
+class _TrainStep(torch.autograd.Function):
+    """Autograd node for the whole network: forward = ake_pcnet_forward_train_f32, backward = ake_pcnet_backward_f32.
+
+    The parameters are passed as inputs only so that autograd routes their gradients; no torch op touches the activations.
+    """
+
+    @staticmethod
+    def forward(ctx, net, x, seq, *params):
+        key, tonic, genre = net._forward_train_raw(x, seq)
+        ctx.net, ctx.x, ctx.seq, ctx.key = net, x, seq, key
+        ctx.param_meta = [(p.dtype, p.shape) for p in params]
+        ctx.set_materialize_grads(True)
+        if genre is None:
+            return key, tonic
+        return key, tonic, genre
+
+    @staticmethod
+    def backward(ctx, d_key, d_tonic, d_genre=None):
+        net = ctx.net
+        flat = net._backward_raw(ctx.x, ctx.seq, ctx.key, d_key, d_tonic, d_genre)
+        grads = []
+        for (name, _), (dtype, shape) in zip(net.named_parameters(), ctx.param_meta):
+            off = net._grad_offsets()[name]
+            n = 1
+            for d in shape:
+                n *= d
+            grads.append(flat[off:off + n].view(shape).to(dtype))
+        return (None, None, None) + tuple(grads)
+
+
 def _opt_get(opt, name, default):
     return getattr(opt, name, default) if opt is not None else default
 
@@ -244,15 +274,14 @@ class PitchClassNet(LightningModule):
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream().cuda_stream
             if self.training:
-                # BatchNorm with batch statistics (train()), forward only: there is no autograd graph behind the
-                # outputs -- the backward kernels are not built yet
-                ws = self._workspace(L.ake_pcnet_train_workspace_bytes(self._h, B, Tn), device)
-                n_ch = sum(c for _, c, _ in self._bn_layers())
-                stats = torch.empty((n_ch, 3), dtype=torch.float32, device=device)
-                _lib.check(L.ake_pcnet_forward_train_f32(self._h, x.data_ptr(), B, Tn, ptr(seq), key.data_ptr(), tonic.data_ptr(),
-                                                         ptr(genre), stats.data_ptr(), ws.data_ptr(), ws.numel(), stream),
-                           "ake_pcnet_forward_train_f32")
-                self._update_running_stats(stats)
+                # BatchNorm with batch statistics; with autograd enabled the call becomes one autograd node whose backward
+                # runs the HIP backward kernels (gradients for every parameter), as loss.backward() does in the reference
+                if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                    outs = _TrainStep.apply(self, x, seq, *self.parameters())
+                    key, tonic = outs[0], outs[1]
+                    genre = outs[2] if self.genre else None
+                else:
+                    key, tonic, genre = self._forward_train_raw(x, seq)
             else:
                 ws = self._workspace(L.ake_pcnet_workspace_bytes(self._h, B, Tn), device)
                 _lib.check(L.ake_pcnet_forward_f32(self._h, x.data_ptr(), B, Tn, ptr(seq), key.data_ptr(), tonic.data_ptr(),
@@ -261,6 +290,50 @@ class PitchClassNet(LightningModule):
         if self.genre:
             return key.to(out_dtype), tonic.to(out_dtype), genre.to(out_dtype)               # models.py:813
         return key.to(out_dtype), tonic.to(out_dtype)                                         # models.py:815
+
+    def _forward_train_raw(self, x, seq):
+        """x (B,1,P,T) float32 contiguous on the device -> float32 outputs; updates the BatchNorm running statistics."""
+        device = x.device
+        B, _, _, Tn = x.shape
+        L = _lib.lib()
+        key = torch.empty((B, 12), dtype=torch.float32, device=device)
+        tonic = torch.empty((B, 12), dtype=torch.float32, device=device)
+        genre = torch.empty((B, 11), dtype=torch.float32, device=device) if self.genre else None
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(device):
+            ws = self._workspace(L.ake_pcnet_train_workspace_bytes(self._h, B, Tn), device)
+            n_ch = sum(c for _, c, _ in self._bn_layers())
+            stats = torch.empty((n_ch, 3), dtype=torch.float32, device=device)
+            _lib.check(L.ake_pcnet_forward_train_f32(self._h, x.data_ptr(), B, Tn, ptr(seq), key.data_ptr(), tonic.data_ptr(),
+                                                     ptr(genre), stats.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                     torch.cuda.current_stream().cuda_stream), "ake_pcnet_forward_train_f32")
+        self._update_running_stats(stats)
+        return key, tonic, genre
+
+    def _grad_offsets(self):
+        if getattr(self, "_goff_cache", None) is None or self._goff_cache[0] is not self._h:
+            L = _lib.lib()
+            offs = {name: int(L.ake_pcnet_grad_offset(self._h, name.encode())) for name, _ in self.named_parameters()}
+            assert all(v >= 0 for v in offs.values())
+            self.__dict__["_goff_cache"] = (self._h, offs)
+        return self._goff_cache[1]
+
+    def _backward_raw(self, x, seq, key, d_key, d_tonic, d_genre):
+        """Flat float32 gradient buffer (state_dict order) for the forward that just ran on (x, seq)."""
+        device = x.device
+        B, _, _, Tn = x.shape
+        L = _lib.lib()
+        f32 = lambda t: None if t is None else t.to(device=device, dtype=torch.float32).contiguous()
+        d_key, d_tonic, d_genre = f32(d_key), f32(d_tonic), f32(d_genre)
+        if self.genre and d_genre is None:
+            d_genre = torch.zeros((B, 11), dtype=torch.float32, device=device)
+        flat = torch.empty(int(L.ake_pcnet_grad_floats(self._h)), dtype=torch.float32, device=device)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(device):
+            _lib.check(L.ake_pcnet_backward_f32(self._h, x.data_ptr(), B, Tn, ptr(seq), key.data_ptr(), d_key.data_ptr(), d_tonic.data_ptr(),
+                                                ptr(d_genre), flat.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                                torch.cuda.current_stream().cuda_stream), "ake_pcnet_backward_f32")
+        return flat
 
     def _bn_layers(self):
         """[(reference module path, channels, channel offset)] of the BatchNorm layers in the device's forward order."""

@@ -141,6 +141,18 @@ int ake_pcnet_forward_train_f32(const ake_pcnet* net, const float* mel_dev, int 
                                 float* genre_out_dev, float* bn_stats_out_dev, void* workspace, size_t workspace_bytes,
                                 ake_stream_t stream);
 
+/* Backward pass of the training-mode forward (what autograd does for the reference's training_step, models.py:952-963).
+ * Must follow ake_pcnet_forward_train_f32 on the same (mel, batch, frames, seq_length, workspace): the workspace holds the raw
+ * convolution outputs and BatchNorm batch statistics it needs.  d_*_dev are dLoss/d(key_out, tonic_out, genre_out); key_out_dev
+ * is the forward's key output (for the sigmoid derivative).  grads_out_dev receives dLoss/d(parameter) for every float entry of
+ * the state_dict, flat, at ake_pcnet_grad_offset(name) (ake_pcnet_grad_floats() floats in total; running statistics get zeros).
+ * Built for num_layers <= 2 without --max_pool; otherwise AKE_ERR_UNSUPPORTED. */
+size_t ake_pcnet_grad_floats(const ake_pcnet* net);
+int64_t ake_pcnet_grad_offset(const ake_pcnet* net, const char* name);
+int ake_pcnet_backward_f32(const ake_pcnet* net, const float* mel_dev, int batch, int frames, const int64_t* seq_length_dev,
+                           const float* key_out_dev, const float* d_key_dev, const float* d_tonic_dev, const float* d_genre_dev,
+                           float* grads_out_dev, void* workspace, size_t workspace_bytes, ake_stream_t stream);
+
 /* Debug tap: copy an intermediate activation of the LAST forward call out of the workspace.
  * name is the reference module path whose output it is (e.g. "model.1.p2p.layer.8"). */
 int ake_pcnet_tap_info(const ake_pcnet* net, const char* name, int batch, int frames, int64_t shape[4]);

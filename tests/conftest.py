@@ -52,6 +52,7 @@ def gold_mirex():
 
 def rel_err(a, b):
     """max|a-b| / max(|b|, 1e-6) -- the per-tensor measure of SURVEY.md section 8d."""
+    a, b = (t.detach().cpu().numpy() if hasattr(t, "detach") else t for t in (a, b))
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-6))

@@ -1,0 +1,135 @@
+"""PARITY (GPU): the HIP backward pass (through autograd's loss.backward(), as training_step does) against float64
+autograd through the oracle restatement (which is pinned to the reference forward incl. train-mode BatchNorm).
+
+Tolerances.  The network has ~3M LeakyReLU pre-activations per step; the f32 forward differs from the f64 forward by
+~1e-6, so in most random cases ONE OR A FEW pre-activations within ~1e-6 of zero take the other branch ("kink flip").
+The gradient is discontinuous there: one flipped element moves dbeta of its BatchNorm by 0.99*|ga| and, through the
+batch statistics, every gradient upstream of it by 1e-4..5e-2 of its max (measured; float32 PyTorch on the CPU shows
+the same 1e-3 gaps against float64, at other layers).  tools/debug_bwd.py counts the flips of one layer and
+tools/grad_seed_scan.py scans (shape, seed) cases.  So:
+  * TIGHT cases are (shape, seed) pairs without a flip: every tensor must agree to 2e-5 of its max -- this is what
+    proves each kernel of the chain (a systematic error fails every seed);
+  * KINKED cases only bound the damage (5e-2) and require the median tensor to stay tight.
+If a change of summation order moves a flip into a tight case, re-pick its seed with tools/grad_seed_scan.py."""
+import json
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import ake_amd
+from conftest import golden_state_dict
+from oracle import pcnet_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def loss_fn(key, tonic, genre, key_labels, tonic_idx, genre_idx, genre_mask):
+    loss = F.binary_cross_entropy(key, key_labels.to(key.dtype)) + F.cross_entropy(tonic, tonic_idx)     # models.py:878-889
+    if genre is not None and genre_mask.any():
+        loss = loss + 0.1 * F.cross_entropy(genre[genre_mask], genre_idx[genre_mask])                     # models.py:881-893
+    return loss
+
+
+def reference_grads(sd32, x, seq, labels, genre=True):
+    sd = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.double() if v.is_floating_point() else v)
+          for k, v in sd32.items()}
+    out = pcnet_oracle.pcnet_forward(sd, x.double(), seq, training=True)
+    loss = loss_fn(out[0], out[1], out[2] if genre else None, *labels)
+    loss.backward()
+    return float(loss.detach()), {k: v.grad for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad}
+
+
+def grad_errors(net, ref):
+    """[(max|g - ref| / max|ref|, name, max|ref|)], worst first.  Convolution biases in front of a BatchNorm have an
+    exactly-zero gradient (the mean subtraction removes them): there the device must return (near) zero too."""
+    rows = []
+    for name, p in net.named_parameters():
+        g = p.grad.detach().cpu().double()
+        r = ref[name]
+        if name.endswith(".bias") and float(r.abs().max()) < 1e-9:
+            assert float(g.abs().max()) < 1e-6, name
+            continue
+        rows.append((float((g - r).abs().max()) / max(float(r.abs().max()), 1e-7), name, float(r.abs().max())))
+    rows.sort(reverse=True)
+    return rows
+
+
+def check_grads(net, ref, tol, verbose=False):
+    rows = grad_errors(net, ref)
+    if verbose:
+        for e, n, m in rows:
+            print(f"   {e:9.2e}  max|ref|={m:9.2e}  {n}")
+    assert rows[0][0] < tol, rows[:5]
+    return rows[0][1], rows[0][0]
+
+
+def make_case(batch, frames, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand((batch, 1, 288, frames), generator=g) * 2.5
+    seq = torch.tensor([frames, frames - 6, frames - 13, frames][:batch])
+    key_labels = (torch.rand((batch, 12), generator=g) > 0.5).float()
+    tonic_idx = torch.randint(0, 12, (batch,), generator=g)
+    genre_idx = torch.randint(0, 11, (batch,), generator=g)
+    genre_mask = torch.tensor([True, False, True, True][:batch])
+    return x, seq, (key_labels, tonic_idx, genre_idx, genre_mask)
+
+
+def _run_default(gold_default, batch, frames, seed):
+    opt = Namespace(**json.loads(str(gold_default["opt"])))
+    net = ake_amd.PitchClassNet(288, 12, 2, 7, opt)
+    sd32 = golden_state_dict(gold_default)
+    net.load_state_dict(sd32, strict=True)
+    net = net.to(DEV).train()
+    x, seq, labels = make_case(batch, frames, seed)
+    loss_ref, ref = reference_grads(sd32, x, seq, labels)
+    out = net(x.to(DEV), seq.to(DEV))
+    loss = loss_fn(out[0], out[1], out[2], *(t.to(DEV) for t in labels))
+    assert abs(float(loss) - loss_ref) < 2e-5 * max(1.0, abs(loss_ref))
+    loss.backward()
+    return grad_errors(net, ref)
+
+
+# dgamma of the very first BatchNorm is a heavily cancelling sum (max|ref| ~2e-3 next to a dbeta of 6e-2): float32
+# PyTorch is itself ~1e-4 off there
+ILL_CONDITIONED = {"model.0.pool_semi_b.weight": 2e-3}
+
+
+@pytest.mark.parametrize("batch,frames,seed", [(4, 40, 1), (4, 52, 0), (3, 64, 5), (2, 76, 0)])
+def test_default_net_gradients_tight(gold_default, batch, frames, seed):
+    rows = _run_default(gold_default, batch, frames, seed)
+    bad = [(e, n) for e, n, _ in rows if e > ILL_CONDITIONED.get(n, 2e-5)]
+    assert not bad, bad[:6]
+
+
+@pytest.mark.parametrize("batch,frames,seed", [(4, 52, 4), (2, 76, 3)])
+def test_default_net_gradients_kinked(gold_default, batch, frames, seed):
+    rows = _run_default(gold_default, batch, frames, seed)
+    assert rows[0][0] < 5e-2, rows[:5]
+    assert rows[len(rows) // 2][0] < 1e-4, rows[len(rows) // 2]
+
+
+def test_single_layer_and_no_genre():
+    opt = Namespace(conv_layers=3, n_filters=4, head_layers=2, time_pool_size=2, genre=False, max_pool=False, frames=5)
+    torch.manual_seed(3)
+    net = ake_amd.PitchClassNet(288, 12, 1, 7, opt)
+    sd32 = {k: v.clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand((3, 1, 288, 30), generator=g) * 2.5
+    seq = torch.tensor([30, 25, 30])
+    labels = ((torch.rand((3, 12), generator=g) > 0.5).float(), torch.randint(0, 12, (3,), generator=g), None, None)
+    sd = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd32.items()}
+    out = pcnet_oracle.pcnet_forward(sd, x.double(), seq, training=True)
+    lref = F.binary_cross_entropy(out[0], labels[0].double()) + F.cross_entropy(out[1], labels[1])
+    lref.backward()
+    ref = {k: v.grad for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad}
+    net = net.to(DEV).train()
+    o = net(x.to(DEV), seq.to(DEV))
+    loss = F.binary_cross_entropy(o[0], labels[0].to(DEV)) + F.cross_entropy(o[1], labels[1].to(DEV))
+    loss.backward()
+    check_grads(net, ref, 5e-2)
+    rows = grad_errors(net, ref)
+    assert rows[len(rows) // 2][0] < 1e-4, rows[:5]

@@ -75,10 +75,10 @@ def test_equivariance_script_semantics_train_mode(gold_guard):
     rows_k, rows_t = [], []
     for i in range(0, 13):
         k, t = net(torch.from_numpy(mirex_oracle.mel_shifting_up(mel_g, i)).reshape(1, 1, 360, 40).to(DEV), seq)
-        rows_k.insert(0, k[0].cpu().numpy()); rows_t.insert(0, t[0].cpu().numpy())
+        rows_k.insert(0, k[0].detach().cpu().numpy()); rows_t.insert(0, t[0].detach().cpu().numpy())
     for i in range(1, 13):
         k, t = net(torch.from_numpy(mirex_oracle.mel_shifting_down(mel_g, i)).reshape(1, 1, 360, 40).to(DEV), seq)
-        rows_k.append(k[0].cpu().numpy()); rows_t.append(t[0].cpu().numpy())
+        rows_k.append(k[0].detach().cpu().numpy()); rows_t.append(t[0].detach().cpu().numpy())
     K, T = np.stack(rows_k), np.stack(rows_t)
     assert rel_err(K, gold_guard["key_train"]) < TOL and rel_err(T, gold_guard["tonic_train"]) < TOL
     for s in range(1, 13):          # batch statistics are shift-invariant, so the roll identity holds in train mode too
