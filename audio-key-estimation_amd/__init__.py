@@ -9,6 +9,8 @@ from .cqt import CQTPlan, cqt_logmag, get_plan, hop_for  # noqa: F401
 from .KeyDataset import DatasetLoader, KeyDataset, SyntheticSineMixLoader, WaveformLoader  # noqa: F401
 from .metrics import KEY_SIGNATURE_MAP, mirex_score  # noqa: F401
 from .models import PitchClassNet  # noqa: F401
+from .optim import FusedAdam  # noqa: F401
+from .lightning_shim import Trainer  # noqa: F401
 from .pipeline import KeyEstimator  # noqa: F401
 
 __all__ = ["PitchClassNet", "KeyDataset", "DatasetLoader", "SyntheticSineMixLoader", "WaveformLoader", "CQTPlan",

@@ -91,6 +91,19 @@ struct ake_pcnet {
     std::vector<size_t> grad_off;      // float offset of specs[i] in the flat gradient buffer
     size_t grad_floats = 0;
     std::vector<size_t> raw_w_off;     // float offset in the blob of specs[i]'s raw values (convolution weights used by small kernels)
+
+    // device-side rebuild of the blob from a flat parameter buffer (same layout as the gradient buffer):
+    //   folded[i] = eval-mode BatchNorm folded into params[i] (conv weights / biases in front of a BatchNorm), else params[i]
+    //   blob[j]   = map[j] < 0 ? 0 : (map[j] & kMapFolded ? folded : params)[map[j] & kMapIndex]
+    struct FoldRecord { std::string wkey, bkey, bn; int cout; size_t per_out; bool transposed; int cin; };
+    std::vector<FoldRecord> fold_records;
+    std::vector<int32_t> map_host;     // one entry per blob float
+    int32_t* map_dev = nullptr;
+    int32_t* fold_ch_dev = nullptr;    // per flat float: -1, or (eval BatchNorm channel << 1) | is_bias
+    int32_t* fold_bn_dev = nullptr;    // per eval BatchNorm channel: flat offsets of gamma, beta, running_mean, running_var
+    int32_t* run_off_dev = nullptr;    // per training BatchNorm channel (BnLayer::ch_off order): flat offsets of running_mean, running_var
+    float* folded_dev = nullptr;
+    bool tracing = false;
 };
 
 namespace {
@@ -128,6 +141,7 @@ void fold(const ake_pcnet* n, const std::string& wkey, const std::string& bkey, 
     w.assign(w32.begin(), w32.end());
     b.assign(b32.begin(), b32.end());
     if (bn_prefix.empty()) return;
+    if (n->tracing) const_cast<ake_pcnet*>(n)->fold_records.push_back({wkey, bkey, bn_prefix, cout, per_out, transposed_cin_first, cin});
     const auto& g = T(n, bn_prefix + ".weight");
     const auto& be = T(n, bn_prefix + ".bias");
     const auto& mu = T(n, bn_prefix + ".running_mean");
@@ -553,6 +567,15 @@ int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
         }
     }
     n->host.resize(n->specs.size());
+    n->grad_off.assign(n->specs.size(), 0);
+    size_t goff = 0;
+    for (size_t i = 0; i < n->specs.size(); ++i) {
+        n->grad_off[i] = goff;
+        size_t cnt = 1;
+        for (int d = 0; d < n->specs[i].ndim; ++d) cnt *= static_cast<size_t>(n->specs[i].shape[d]);
+        goff += cnt;
+    }
+    n->grad_floats = goff;
     *out = n;
     return AKE_OK;
 }
@@ -560,6 +583,9 @@ int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
 void ake_pcnet_destroy(ake_pcnet* n) {
     if (!n) return;
     if (n->blob_dev) (void)hipFree(n->blob_dev);
+    for (void* p : {static_cast<void*>(n->map_dev), static_cast<void*>(n->fold_ch_dev), static_cast<void*>(n->fold_bn_dev),
+                    static_cast<void*>(n->run_off_dev), static_cast<void*>(n->folded_dev)})
+        if (p) (void)hipFree(p);
     delete n;
 }
 
@@ -678,32 +704,204 @@ static void build_packs(ake_pcnet* n, bool train) {
     }
     if (train) {   // raw copies of every tensor (small backward kernels read the reference layout) + the flat gradient layout
         n->raw_w_off.assign(n->specs.size(), 0);
-        n->grad_off.assign(n->specs.size(), 0);
-        size_t goff = 0;
         for (size_t i = 0; i < n->specs.size(); ++i) {
             n->blob.resize(ake::align_up(n->blob.size(), 64));
             n->raw_w_off[i] = n->blob.size();
             for (float v : n->host[i].data) n->blob.push_back(v);
-            n->grad_off[i] = goff;
-            goff += n->host[i].data.size();
         }
-        n->grad_floats = goff;
     }
 }
+
+constexpr int32_t kMapFolded = 1 << 30, kMapIndex = kMapFolded - 1;
+
+namespace {
+
+__global__ void fold_params_kernel(const float* __restrict__ params, const int32_t* __restrict__ fold_ch, const int32_t* __restrict__ fold_bn,
+                                   float* __restrict__ folded, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = params[i];
+    const int32_t f = fold_ch[i];
+    if (f >= 0) {
+        const int32_t* o = fold_bn + 4 * (f >> 1);
+        const double s = static_cast<double>(params[o[0]]) / sqrt(static_cast<double>(params[o[3]]) + 1e-5);
+        v = (f & 1) ? static_cast<float>((static_cast<double>(v) - static_cast<double>(params[o[2]])) * s + static_cast<double>(params[o[1]]))
+                    : static_cast<float>(static_cast<double>(v) * s);
+    }
+    folded[i] = v;
+}
+
+__global__ void gather_blob_kernel(const float* __restrict__ params, const float* __restrict__ folded, const int32_t* __restrict__ map,
+                                   float* __restrict__ blob, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int32_t m = map[j];
+    blob[j] = m < 0 ? 0.f : ((m & kMapFolded) ? folded : params)[m & kMapIndex];
+}
+
+// nn.BatchNorm2d's train-mode side effect on the flat parameter buffer: running <- (1-m)*running + m*(mean, unbiased var)
+__global__ void running_stats_kernel(const float* __restrict__ bstats, const int32_t* __restrict__ run_off, float* __restrict__ params,
+                                     float momentum, int n_ch) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_ch) return;
+    const float mean = bstats[3 * c], var = bstats[3 * c + 1], cnt = bstats[3 * c + 2];
+    const float unbiased = var * cnt / fmaxf(cnt - 1.f, 1.f);
+    float* rm = params + run_off[2 * c];
+    float* rv = params + run_off[2 * c + 1];
+    *rm = (1.f - momentum) * *rm + momentum * mean;
+    *rv = (1.f - momentum) * *rv + momentum * unbiased;
+}
+
+void reset_packs(ake_pcnet* n) {
+    n->blob.clear();
+    n->bns.clear(); n->bn_index.clear(); n->bn_channels = 0;
+}
+
+// The blob layout is a pure function of the configuration: build it once with index-coded values to learn, for every
+// blob float, which flat parameter it comes from.  (Indices + 1 < 2^24 are exact in f32; the eval fold is neutralised by
+// gamma = 1, beta = mean = 0, var = 1 - eps so that folded values still round to the index.)
+int trace_maps(ake_pcnet* n) {
+    std::vector<std::vector<float>> saved(n->specs.size());
+    for (size_t i = 0; i < n->specs.size(); ++i) saved[i] = n->host[i].data;
+    AKE_REQUIRE(n->grad_floats + 1 < (1u << 24), AKE_ERR_UNSUPPORTED, "finalize: %zu parameters exceed the index-trace range", n->grad_floats);
+    auto ends_with = [](const std::string& a, const char* suf) { const size_t l = std::strlen(suf); return a.size() >= l && a.compare(a.size() - l, l, suf) == 0; };
+    auto is_bn = [&](size_t i) {     // BatchNorm tensors are the ones that come with running statistics
+        const std::string& nm = n->specs[i].name;
+        const std::string prefix = nm.substr(0, nm.rfind('.'));
+        return n->spec_index.count(prefix + ".running_mean") > 0;
+    };
+    auto fill_index = [&](size_t i) { for (size_t j = 0; j < n->host[i].data.size(); ++j) n->host[i].data[j] = static_cast<float>(n->grad_off[i] + j + 1); };
+    // pass A: eval packs
+    for (size_t i = 0; i < n->specs.size(); ++i) {
+        const std::string& nm = n->specs[i].name;
+        if (!is_bn(i)) { fill_index(i); continue; }
+        const float v = ends_with(nm, ".weight") ? 1.f : (ends_with(nm, ".running_var") ? 1.f - 1e-5f : 0.f);
+        std::fill(n->host[i].data.begin(), n->host[i].data.end(), v);
+    }
+    reset_packs(n);
+    n->fold_records.clear();
+    n->tracing = true;
+    build_packs(n, false);
+    n->tracing = false;
+    const size_t eval_end = n->blob.size();
+    // pass B: training packs (raw values everywhere)
+    for (size_t i = 0; i < n->specs.size(); ++i) fill_index(i);
+    build_packs(n, true);
+    n->blob.resize(ake::align_up(n->blob.size() + 64, 64), 0.f);
+    n->map_host.assign(n->blob.size(), -1);
+    for (size_t j = 0; j < n->blob.size(); ++j) {
+        const long v = std::lround(static_cast<double>(n->blob[j]));
+        if (v <= 0) continue;
+        AKE_REQUIRE(static_cast<size_t>(v) <= n->grad_floats, AKE_ERR_STATE, "finalize: index trace out of range at blob[%zu]", j);
+        n->map_host[j] = static_cast<int32_t>(v - 1) | (j < eval_end ? kMapFolded : 0);
+    }
+    for (size_t i = 0; i < n->specs.size(); ++i) n->host[i].data = saved[i];
+    return AKE_OK;
+}
+
+int upload_i32(const std::vector<int32_t>& v, int32_t** dev) {
+    if (*dev) { (void)hipFree(*dev); *dev = nullptr; }
+    AKE_HIP_CHECK(hipMalloc(dev, std::max<size_t>(v.size(), 1) * sizeof(int32_t)));
+    AKE_HIP_CHECK(hipMemcpy(*dev, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return AKE_OK;
+}
+
+int build_fold_tables(ake_pcnet* n) {
+    std::vector<int32_t> fold_ch(n->grad_floats, -1), fold_bn, run_off(static_cast<size_t>(n->bn_channels) * 2, 0);
+    auto off = [&](const std::string& key) { return static_cast<int32_t>(n->grad_off[n->spec_index.at(key)]); };
+    int base = 0;
+    for (const auto& r : n->fold_records) {
+        const int32_t w0 = off(r.wkey), b0 = off(r.bkey);
+        const size_t total = r.per_out * r.cout, k = r.transposed ? r.per_out / r.cin : 0;
+        for (size_t i = 0; i < total; ++i) {
+            const int co = r.transposed ? static_cast<int>((i / k) % r.cout) : static_cast<int>(i / r.per_out);
+            fold_ch[w0 + i] = (base + co) << 1;
+        }
+        for (int co = 0; co < r.cout; ++co) {
+            fold_ch[b0 + co] = ((base + co) << 1) | 1;
+            fold_bn.push_back(off(r.bn + ".weight") + co);
+            fold_bn.push_back(off(r.bn + ".bias") + co);
+            fold_bn.push_back(off(r.bn + ".running_mean") + co);
+            fold_bn.push_back(off(r.bn + ".running_var") + co);
+        }
+        base += r.cout;
+    }
+    for (const auto& l : n->bns)
+        for (int c = 0; c < l.C; ++c) {
+            run_off[2 * (l.ch_off + c)] = off(l.name + ".running_mean") + c;
+            run_off[2 * (l.ch_off + c) + 1] = off(l.name + ".running_var") + c;
+        }
+    int rc;
+    if ((rc = upload_i32(fold_ch, &n->fold_ch_dev)) || (rc = upload_i32(fold_bn, &n->fold_bn_dev)) || (rc = upload_i32(run_off, &n->run_off_dev)) ||
+        (rc = upload_i32(n->map_host, &n->map_dev)))
+        return rc;
+    if (n->folded_dev) { (void)hipFree(n->folded_dev); n->folded_dev = nullptr; }
+    AKE_HIP_CHECK(hipMalloc(&n->folded_dev, n->grad_floats * sizeof(float)));
+    return AKE_OK;
+}
+
+}  // namespace
 
 int ake_pcnet_finalize(ake_pcnet* n) {
     AKE_REQUIRE(n, AKE_ERR_INVALID, "finalize: null handle");
     for (size_t i = 0; i < n->specs.size(); ++i)
         AKE_REQUIRE(n->host[i].set, AKE_ERR_STATE, "finalize: missing key '%s' (load_state_dict strict=True)", n->specs[i].name.c_str());
-    n->blob.clear();
-    n->bns.clear(); n->bn_index.clear(); n->bn_channels = 0;
+    int rc;
+    if (n->map_host.empty()) {
+        if ((rc = trace_maps(n))) return rc;
+        if ((rc = build_fold_tables(n))) return rc;
+    }
+    reset_packs(n);
     build_packs(n, false);
     build_packs(n, true);
     n->blob.resize(ake::align_up(n->blob.size() + 64, 64), 0.f);
-    if (n->blob_dev) { (void)hipFree(n->blob_dev); n->blob_dev = nullptr; }
-    AKE_HIP_CHECK(hipMalloc(&n->blob_dev, n->blob.size() * sizeof(float)));
+    AKE_REQUIRE(n->blob.size() == n->map_host.size(), AKE_ERR_STATE, "finalize: blob layout changed between builds");
+    if (!n->blob_dev) AKE_HIP_CHECK(hipMalloc(&n->blob_dev, n->blob.size() * sizeof(float)));
     AKE_HIP_CHECK(hipMemcpy(n->blob_dev, n->blob.data(), n->blob.size() * sizeof(float), hipMemcpyHostToDevice));
     n->finalized = true;
+    return AKE_OK;
+}
+
+// Device-resident parameters: (re)build every packed weight from a flat f32 parameter buffer on the device (layout =
+// ake_pcnet_grad_offset).  No host round trip after the first call; asynchronous on `stream`.
+int ake_pcnet_load_from_device_f32(ake_pcnet* n, const float* params_dev, ake_stream_t stream) {
+    AKE_REQUIRE(n && params_dev, AKE_ERR_INVALID, "load_from_device: null argument");
+    if (n->map_host.empty()) {          // first use: learn the layout (values are irrelevant; host tensors only need their sizes)
+        for (size_t i = 0; i < n->specs.size(); ++i) {
+            size_t cnt = 1;
+            for (int d = 0; d < n->specs[i].ndim; ++d) cnt *= static_cast<size_t>(n->specs[i].shape[d]);
+            if (n->host[i].data.size() != cnt) n->host[i].data.assign(cnt, 0.f);
+        }
+        int rc;
+        if ((rc = trace_maps(n))) return rc;
+        if ((rc = build_fold_tables(n))) return rc;
+        if (!n->blob_dev) AKE_HIP_CHECK(hipMalloc(&n->blob_dev, n->blob.size() * sizeof(float)));
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int P = static_cast<int>(n->grad_floats), NB = static_cast<int>(n->map_host.size());
+    {
+        ake::ProfScope ps("fold_params_kernel", s);
+        hipLaunchKernelGGL(fold_params_kernel, dim3((P + 255) / 256), dim3(256), 0, s, params_dev, n->fold_ch_dev, n->fold_bn_dev, n->folded_dev, P);
+    }
+    {
+        ake::ProfScope ps("gather_blob_kernel", s);
+        hipLaunchKernelGGL(gather_blob_kernel, dim3((NB + 255) / 256), dim3(256), 0, s, params_dev, n->folded_dev, n->map_dev, n->blob_dev, NB);
+    }
+    AKE_HIP_CHECK(hipGetLastError());
+    n->finalized = true;
+    return AKE_OK;
+}
+
+// running_mean / running_var inside the flat parameter buffer <- momentum blend with the batch statistics that
+// ake_pcnet_forward_train_f32 returned in bn_stats (torch semantics: unbiased variance; models use momentum 0.1).
+int ake_pcnet_update_running_stats_f32(const ake_pcnet* n, const float* bn_stats_dev, float* params_dev, float momentum, ake_stream_t stream) {
+    AKE_REQUIRE(n && bn_stats_dev && params_dev, AKE_ERR_INVALID, "update_running_stats: null argument");
+    AKE_REQUIRE(n->finalized && n->run_off_dev, AKE_ERR_STATE, "update_running_stats: the handle has no parameters yet");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ake::ProfScope ps("running_stats_kernel", s);
+    hipLaunchKernelGGL(running_stats_kernel, dim3((n->bn_channels + 63) / 64), dim3(64), 0, s, bn_stats_dev, n->run_off_dev, params_dev, momentum,
+                       n->bn_channels);
+    AKE_HIP_CHECK(hipGetLastError());
     return AKE_OK;
 }
 
@@ -1045,13 +1243,13 @@ size_t ake_pcnet_grad_floats(const ake_pcnet* n) { return n ? n->grad_floats : 0
 int64_t ake_pcnet_grad_offset(const ake_pcnet* n, const char* name) {
     if (!n || !name) return -1;
     auto it = n->spec_index.find(name);
-    if (it == n->spec_index.end() || n->grad_off.empty()) return -1;
+    if (it == n->spec_index.end()) return -1;
     return static_cast<int64_t>(n->grad_off[it->second]);
 }
 
 int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int frames, const int64_t* seq_length, const float* key_out,
-                           const float* d_key, const float* d_tonic, const float* d_genre, float* grads_out, void* workspace,
-                           size_t ws_bytes, ake_stream_t stream) {
+                           const float* d_key, const float* d_tonic, const float* d_genre, float* grads_out, int accumulate,
+                           void* workspace, size_t ws_bytes, ake_stream_t stream) {
     AKE_REQUIRE(n && mel && key_out && d_key && d_tonic && grads_out, AKE_ERR_INVALID, "pcnet backward: null argument");
     AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
     AKE_REQUIRE(!n->cfg.genre || d_genre, AKE_ERR_INVALID, "pcnet backward: genre head enabled but d_genre is null");
@@ -1060,7 +1258,7 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     if (rc) return rc;
     AKE_REQUIRE(workspace && ws_bytes >= b.bytes, AKE_ERR_WORKSPACE, "pcnet backward: workspace %zu < %zu bytes", ws_bytes, b.bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    AKE_HIP_CHECK(hipMemsetAsync(grads_out, 0, sizeof(float) * n->grad_floats, s));
+    if (!accumulate) AKE_HIP_CHECK(hipMemsetAsync(grads_out, 0, sizeof(float) * n->grad_floats, s));
     AKE_HIP_CHECK(hipMemsetAsync(b.stats2, 0, sizeof(double) * 3 * n->bn_channels, s));
     Bwd bw{n, b, s, grads_out, batch};
     rc = bw.run(mel, seq_length, d_key, d_tonic, d_genre, key_out);

@@ -104,8 +104,8 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ stats2, const floa
     coef[4 * c + 1] = c1;
     coef[4 * c + 2] = static_cast<float>(-(static_cast<double>(c0) * S1 + static_cast<double>(c1) * S3) / N);
     coef[4 * c + 3] = bstats[3 * c];
-    d_gamma[c] = static_cast<float>(S2);
-    d_beta[c] = static_cast<float>(S1);
+    d_gamma[c] += static_cast<float>(S2);        // += : the flat gradient buffer may be accumulating (accumulate_grad_batches)
+    d_beta[c] += static_cast<float>(S1);
 }
 
 // dz = c0*g1 + c1*(z - mean) + c2 in place on g; same layout / grid as act_bwd_stats_kernel

@@ -60,3 +60,58 @@ def max_over_ranks(value: float, device=None) -> float:
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+# ---- data-parallel training: replicated weights, one all-reduce per optimizer step ----------------
+
+def broadcast_parameters(net, src: int = 0):
+    """Identical weights on every rank by construction: rank ``src``'s float state (one flat buffer on the device) wins."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    if next(net.parameters()).device.type == "cuda":
+        flat, _ = net.flat_parameters()
+        if net._attached:
+            if dist.get_backend() == "gloo":                    # CPU rehearsal of the N > 1 path: stage through the host
+                host = flat.cpu()
+                dist.broadcast(host, src)
+                flat.copy_(host)
+            else:
+                dist.broadcast(flat, src)
+            net.mark_parameters_changed()
+            return
+    with torch.no_grad():
+        for _, v in sorted(net.state_dict(keep_vars=True).items()):
+            dist.broadcast(v.data, src)
+
+
+def _all_reduce_sum(t: torch.Tensor):
+    if t.is_cuda and dist.get_backend() == "gloo":              # rehearsal without RCCL (several ranks on one GPU)
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+def all_reduce_gradients(net) -> float:
+    """SUM the gradients over the ranks and return the factor that turns the sum into the mean (1/world).
+
+    With the parameters in the module's flat device buffer this is ONE collective on ONE 668 KB bucket (default net),
+    issued on the compute stream right after the last weight-gradient kernel -- at that size the ring is latency-bound, so
+    fewer calls beat overlap.  BatchNorm stays local to each rank (torch DDP's default), see DESIGN.md."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 1.0
+    world = dist.get_world_size()
+    if getattr(net, "_attached", False) and net._grads_in_place():
+        _all_reduce_sum(net._flat_grad)
+        return 1.0 / world
+    grads = [p.grad for p in net.parameters() if p.grad is not None]
+    if grads:
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        _all_reduce_sum(flat)
+        flat.mul_(1.0 / world)
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+    return 1.0

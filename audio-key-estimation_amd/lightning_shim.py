@@ -46,12 +46,64 @@ def _to_device(batch, device):
 
 
 class Trainer:
-    """``validate`` / ``test`` loops with the Lightning 1.6 hook order (eval.py:118-129)."""
+    """``fit`` / ``validate`` loops with the Lightning 1.6 hook order (train_model.py:112-124, eval.py:118-129).
+
+    ``fit`` mirrors what ``pl.Trainer(max_epochs, accumulate_grad_batches).fit(model)`` does to the reference module:
+    ``configure_optimizers`` once; per batch ``training_step`` -> ``(loss / accumulate_grad_batches).backward()``; an
+    optimizer step every ``accumulate_grad_batches`` batches and on the last batch of the epoch; the LR scheduler once
+    per epoch; then the validation loop and ``validation_epoch_end``.  Under torch.distributed (one process per GPU)
+    the gradients are all-reduced right before each optimizer step (``distributed.all_reduce_gradients``).
+    Callbacks (EarlyStopping / ModelCheckpoint) are not re-implemented: the module saves its own best checkpoint
+    (models.py:991-993)."""
 
     def __init__(self, max_epochs=1, accumulate_grad_batches=1, logger=None, **_ignored):
         self.max_epochs = max_epochs
         self.accumulate_grad_batches = accumulate_grad_batches
         self.logger = logger or NullLogger()
+        self.train_losses = []          # per training batch (floats), filled at the end of each epoch
+        self.val_results = []
+
+    def fit(self, model, train_dataloaders=None, val_dataloaders=None, max_steps=None):
+        from . import distributed as D
+        self._attach(model)
+        device = next(model.parameters()).device
+        optimizers, schedulers = model.configure_optimizers()
+        opt = optimizers[0]
+        sched = schedulers[0] if schedulers else None
+        acc = max(1, int(self.accumulate_grad_batches))
+        D.broadcast_parameters(model)
+        model.global_step = 0
+        for epoch in range(self.max_epochs):
+            model.train()
+            loader = train_dataloaders if train_dataloaders is not None else model.train_dataloader()
+            n = len(loader)
+            opt.zero_grad()
+            losses = []
+            for i, batch in enumerate(loader):
+                out = model.training_step(_to_device(batch, device), i)
+                (out["loss"] / acc).backward()
+                losses.append(out["loss"].detach())
+                if (i + 1) % acc == 0 or i + 1 == n:
+                    scale = D.all_reduce_gradients(model)
+                    if hasattr(opt, "grad_scale"):
+                        opt.grad_scale = scale
+                    elif scale != 1.0:
+                        for p in model.parameters():
+                            if p.grad is not None:
+                                p.grad.mul_(scale)
+                    opt.step()
+                    opt.zero_grad()
+                    model.global_step += 1
+                    if max_steps is not None and model.global_step >= max_steps:
+                        break
+            self.train_losses += [float(v) for v in torch.stack(losses).cpu()]
+            if sched is not None:
+                sched.step()
+            if val_dataloaders is not None or (getattr(model, "data", None) or {}).get("val") is not None:
+                self.val_results.append(self.validate(model, val_dataloaders)[0])
+            if max_steps is not None and model.global_step >= max_steps:
+                break
+        return self
 
     def _attach(self, model):
         model.trainer = self

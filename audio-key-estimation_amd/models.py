@@ -90,7 +90,9 @@ class PitchClassNetLayer(nn.Module):
 class _TrainStep(torch.autograd.Function):
     """Autograd node for the whole network: forward = ake_pcnet_forward_train_f32, backward = ake_pcnet_backward_f32.
 
-    The parameters are passed as inputs only so that autograd routes their gradients; no torch op touches the activations.
+    The parameters are passed as inputs only so that autograd knows the outputs depend on them; no torch op touches the
+    activations.  When the parameters live in the module's flat device buffer (the normal case) the backward kernels add
+    straight into the flat gradient buffer that every ``p.grad`` is a view of -- nothing is returned to autograd for them.
     """
 
     @staticmethod
@@ -106,14 +108,14 @@ class _TrainStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_key, d_tonic, d_genre=None):
         net = ctx.net
+        if net._grads_in_place():
+            net._backward_raw(ctx.x, ctx.seq, ctx.key, d_key, d_tonic, d_genre, into=net._flat_grad)
+            return (None, None, None) + (None,) * len(ctx.param_meta)
         flat = net._backward_raw(ctx.x, ctx.seq, ctx.key, d_key, d_tonic, d_genre)
         grads = []
         for (name, _), (dtype, shape) in zip(net.named_parameters(), ctx.param_meta):
             off = net._grad_offsets()[name]
-            n = 1
-            for d in shape:
-                n *= d
-            grads.append(flat[off:off + n].view(shape).to(dtype))
+            grads.append(flat[off:off + shape.numel()].view(shape).to(dtype))
         return (None, None, None) + tuple(grads)
 
 
@@ -167,6 +169,10 @@ class PitchClassNet(LightningModule):
         self._h_device = None
         self._h_stamp = None
         self._ws = None
+        self._flat = None            # one float32 device buffer holding every float state_dict entry (layout: ake_pcnet_grad_offset)
+        self._flat_grad = None       # same layout; every p.grad is a view of it
+        self._attached = False       # parameters/buffers are views of _flat
+        self._dirty = 0              # bumped by the raw-pointer writers (fused Adam, running statistics)
 
     # ------------------------------------------------------------------ device handle
     def _float_state(self):
@@ -181,12 +187,34 @@ class PitchClassNet(LightningModule):
         c.max_pool = 1 if _opt_get(self.opt, "max_pool", False) else 0
         return c
 
+    def _layout(self):
+        """[(state_dict key, float offset, count)] of the flat parameter / gradient buffers, from the C ABI."""
+        if getattr(self, "_layout_cache", None) is None or self._layout_cache[0] is not self._h:
+            L = _lib.lib()
+            rows = []
+            for i in range(L.ake_pcnet_num_tensors(self._h)):
+                name, shape, ndim = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+                _lib.check(L.ake_pcnet_tensor_info(self._h, i, C.byref(name), shape, C.byref(ndim)), "ake_pcnet_tensor_info")
+                cnt = 1
+                for d in range(ndim.value):
+                    cnt *= shape[d]
+                rows.append((name.value.decode(), int(L.ake_pcnet_grad_offset(self._h, name.value)), int(cnt)))
+            self.__dict__["_layout_cache"] = (self._h, rows)
+        return self._layout_cache[1]
+
+    def _is_attached(self, state):
+        if self._flat is None or not self._attached:
+            return False
+        base = self._flat.data_ptr()
+        return all(v.dtype == torch.float32 and v.data_ptr() == base + 4 * off for (_, off, _), v in zip(self._layout(), state))
+
     def _sync_weights(self, device):
-        """(Re)build the device handle when parameters changed (optimizer step, load_state_dict, .to())."""
-        state = self._float_state()
-        stamp = (str(device),) + tuple((v._version, v.data_ptr()) for _, v in state)
-        if self._h is not None and stamp == self._h_stamp:
-            return
+        """Make the device handle reflect the current parameters (after an optimizer step, load_state_dict, .to()).
+
+        float32 parameters on the device are MOVED into one flat buffer (the tensors become views of it), so that the
+        packed kernel weights are rebuilt on the device (ake_pcnet_load_from_device_f32) and the fused optimizer / the
+        gradient all-reduce work on one buffer.  Other dtypes (the reference trains in float64, train_model.py:106) keep
+        their own storage and are cast into the flat buffer whenever they change."""
         L = _lib.lib()
         with torch.cuda.device(device):
             if self._h is None or self._h_device != device:
@@ -195,21 +223,75 @@ class PitchClassNet(LightningModule):
                 h = C.c_void_p()
                 _lib.check(L.ake_pcnet_create(C.byref(cfg), C.byref(h)), "ake_pcnet_create")
                 self._h, self._h_device = h, device
-            expected = set()
-            for i in range(L.ake_pcnet_num_tensors(self._h)):
-                name, shape, ndim = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
-                _lib.check(L.ake_pcnet_tensor_info(self._h, i, C.byref(name), shape, C.byref(ndim)), "ake_pcnet_tensor_info")
-                expected.add(name.value.decode())
-            have = {k for k, _ in state}
+                self._flat = self._flat_grad = None
+                self._attached = False
+            layout = self._layout()
+            sd = dict(self._float_state())
+            expected, have = {k for k, _, _ in layout}, set(sd)
             if expected != have:
                 raise _lib.AkeError(f"state_dict keys differ from the device layout: missing {sorted(expected - have)[:4]}, "
                                     f"unexpected {sorted(have - expected)[:4]}")
-            for k, v in state:
-                host = v.detach().to(device="cpu", dtype=torch.float32).contiguous()
-                shape = (C.c_int64 * max(1, host.dim()))(*host.shape)
-                _lib.check(L.ake_pcnet_set_tensor(self._h, k.encode(), host.data_ptr(), shape, host.dim()), f"ake_pcnet_set_tensor({k})")
-            _lib.check(L.ake_pcnet_finalize(self._h), "ake_pcnet_finalize")
-        self._h_stamp = stamp
+            state = [sd[k] for k, _, _ in layout]
+            total = int(L.ake_pcnet_grad_floats(self._h))
+            if not self._is_attached(state):
+                flat = torch.empty(total, dtype=torch.float32, device=device)
+                can_attach = all(v.dtype == torch.float32 and v.device == device for v in state)
+                with torch.no_grad():
+                    for (_, off, cnt), v in zip(layout, state):
+                        flat[off:off + cnt].copy_(v.detach().reshape(-1))
+                        if can_attach:
+                            v.data = flat[off:off + cnt].view(v.shape)
+                self._flat, self._attached = flat, can_attach
+                self._flat_grad = None
+                self._h_stamp = None
+            elif not self._attached:
+                pass
+            stamp = (self._dirty,) + tuple((v._version, v.data_ptr()) for v in state)
+            if stamp == self._h_stamp:
+                return
+            if not self._attached and self._h_stamp is not None:      # staged copy of foreign-dtype parameters
+                with torch.no_grad():
+                    for (_, off, cnt), v in zip(layout, state):
+                        self._flat[off:off + cnt].copy_(v.detach().reshape(-1))
+            _lib.check(L.ake_pcnet_load_from_device_f32(self._h, self._flat.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                       "ake_pcnet_load_from_device_f32")
+            self._h_stamp = stamp
+
+    def _grads_in_place(self):
+        """True when every p.grad is (or can be made) a view of the flat gradient buffer; prepares it for accumulation."""
+        if not self._attached:
+            return False
+        params = dict(self.named_parameters())
+        offs = self._grad_offsets()
+        if self._flat_grad is None:
+            self._flat_grad = torch.zeros_like(self._flat)
+        base = self._flat_grad.data_ptr()
+        none = [n for n, p in params.items() if p.grad is None]
+        ours = all(p.grad is None or p.grad.data_ptr() == base + 4 * offs[n] for n, p in params.items())
+        if not ours or any(not p.requires_grad for p in params.values()):
+            return False
+        if none:
+            if len(none) == len(params):
+                self._flat_grad.zero_()
+            for n in none:
+                p = params[n]
+                view = self._flat_grad[offs[n]:offs[n] + p.numel()].view(p.shape)
+                if len(none) != len(params):
+                    view.zero_()
+                p.grad = view
+        return True
+
+    def flat_parameters(self):
+        """(flat float32 parameter buffer, flat gradient buffer or None) -- what the fused optimizer and the gradient
+        all-reduce operate on.  Valid once the module is on the device (calls prepare())."""
+        self.prepare()
+        if self._attached and self._flat_grad is None:
+            self._grads_in_place()
+        return self._flat, self._flat_grad
+
+    def mark_parameters_changed(self):
+        """Call after writing the flat buffer through a raw pointer (fused optimizer): the next forward repacks the weights."""
+        self._dirty += 1
 
     def _release(self):
         d = self.__dict__                    # plain attributes; avoids nn.Module.__setattr__ at interpreter shutdown
@@ -307,8 +389,32 @@ class PitchClassNet(LightningModule):
             _lib.check(L.ake_pcnet_forward_train_f32(self._h, x.data_ptr(), B, Tn, ptr(seq), key.data_ptr(), tonic.data_ptr(),
                                                      ptr(genre), stats.data_ptr(), ws.data_ptr(), ws.numel(),
                                                      torch.cuda.current_stream().cuda_stream), "ake_pcnet_forward_train_f32")
-        self._update_running_stats(stats)
+            if self._attached:
+                _lib.check(L.ake_pcnet_update_running_stats_f32(self._h, stats.data_ptr(), self._flat.data_ptr(), 0.1,
+                                                                torch.cuda.current_stream().cuda_stream), "ake_pcnet_update_running_stats_f32")
+        if self._attached:
+            self._dirty += 1                                   # eval-mode packs fold the running statistics
+            with torch.no_grad():
+                torch._foreach_add_(self._nbt_tensors(), 1)
+        else:
+            self._update_running_stats(stats)
         return key, tonic, genre
+
+    def _nbt_tensors(self):
+        if getattr(self, "_nbt_cache", None) is None or self._nbt_cache[0] is not self._h:
+            mods = dict(self.named_modules())
+            self.__dict__["_nbt_cache"] = (self._h, [mods[name] for name, _, _ in self._bn_layers()])
+        return [m.num_batches_tracked for m in self._nbt_cache[1]]
+
+    _DEVICE_STATE = ("_h", "_h_device", "_h_stamp", "_ws", "_flat", "_flat_grad", "_layout_cache", "_goff_cache", "_bn_cache", "_nbt_cache")
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle: the device handle and the flat buffers belong to this object only."""
+        d = self.__dict__.copy()
+        for k in self._DEVICE_STATE:
+            d[k] = None
+        d["_attached"] = False
+        return d
 
     def _grad_offsets(self):
         if getattr(self, "_goff_cache", None) is None or self._goff_cache[0] is not self._h:
@@ -318,8 +424,8 @@ class PitchClassNet(LightningModule):
             self.__dict__["_goff_cache"] = (self._h, offs)
         return self._goff_cache[1]
 
-    def _backward_raw(self, x, seq, key, d_key, d_tonic, d_genre):
-        """Flat float32 gradient buffer (state_dict order) for the forward that just ran on (x, seq)."""
+    def _backward_raw(self, x, seq, key, d_key, d_tonic, d_genre, into=None):
+        """Flat float32 gradient buffer (state_dict order) for the forward that just ran on (x, seq); ``into`` accumulates."""
         device = x.device
         B, _, _, Tn = x.shape
         L = _lib.lib()
@@ -327,11 +433,11 @@ class PitchClassNet(LightningModule):
         d_key, d_tonic, d_genre = f32(d_key), f32(d_tonic), f32(d_genre)
         if self.genre and d_genre is None:
             d_genre = torch.zeros((B, 11), dtype=torch.float32, device=device)
-        flat = torch.empty(int(L.ake_pcnet_grad_floats(self._h)), dtype=torch.float32, device=device)
+        flat = into if into is not None else torch.empty(int(L.ake_pcnet_grad_floats(self._h)), dtype=torch.float32, device=device)
         ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(device):
             _lib.check(L.ake_pcnet_backward_f32(self._h, x.data_ptr(), B, Tn, ptr(seq), key.data_ptr(), d_key.data_ptr(), d_tonic.data_ptr(),
-                                                ptr(d_genre), flat.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                                ptr(d_genre), flat.data_ptr(), 1 if into is not None else 0, self._ws.data_ptr(), self._ws.numel(),
                                                 torch.cuda.current_stream().cuda_stream), "ake_pcnet_backward_f32")
         return flat
 
@@ -418,6 +524,9 @@ class PitchClassNet(LightningModule):
     def training_step(self, batch, batch_idx):
         d = self._step(batch, batch_idx, "train")
         d["log"] = {"loss": d["loss"]}
+        acc = getattr(self.trainer, "accumulate_grad_batches", 1) if self.trainer is not None else 1
+        if batch_idx % acc == 0 and (self.global_step + 1) % _opt_get(self.opt, "acc_grad", 8) == 0 and self.logger is not None:
+            self.logger.experiment.add_scalar("train_loss", d["loss"], self.global_step)              # models.py:955-961
         return d
 
     def validation_step(self, batch, batch_idx):
@@ -460,7 +569,15 @@ class PitchClassNet(LightningModule):
         return torch.utils.data.DataLoader(self.data["val"], shuffle=False, batch_size=self.batch_size, drop_last=True)
 
     def configure_optimizers(self):
-        optim = torch.optim.Adam(self.parameters(), betas=(0.9, 0.999), lr=_opt_get(self.opt, "lr", 3e-4),
-                                 weight_decay=_opt_get(self.opt, "reg", 0))
+        """models.py:1017-1027.  On the device the Adam update is one fused HIP kernel over the flat parameter buffer
+        (``FusedAdam`` subclasses torch.optim.Optimizer: param_groups / lr schedulers behave as with torch.optim.Adam);
+        a module that is still on the CPU gets torch.optim.Adam itself."""
+        lr, reg = _opt_get(self.opt, "lr", 3e-4), _opt_get(self.opt, "reg", 0)
+        p0 = next(self.parameters())
+        if p0.device.type == "cuda" and all(p.dtype == torch.float32 for p in self.parameters()):
+            from .optim import FusedAdam
+            optim = FusedAdam(self, betas=(0.9, 0.999), lr=lr, weight_decay=reg)
+        else:
+            optim = torch.optim.Adam(self.parameters(), betas=(0.9, 0.999), lr=lr, weight_decay=reg)
         scheduler = torch.optim.lr_scheduler.ExponentialLR(optim, gamma=_opt_get(self.opt, "gamma", 0.96))
         return [optim], [scheduler]

@@ -114,6 +114,16 @@ int ake_pcnet_tensor_info(const ake_pcnet* net, int index, const char** name, in
 int ake_pcnet_set_tensor(ake_pcnet* net, const char* name, const float* host_data, const int64_t* shape, int ndim);
 /* All tensors set -> fold BatchNorm (running stats, eps 1e-5), repack for the kernels, upload. */
 int ake_pcnet_finalize(ake_pcnet* net);
+/* Device-resident parameters (training: models.py:1017-1027 updates the weights every optimizer step).  params_dev is
+ * ONE flat float32 buffer holding every float entry of the state_dict at ake_pcnet_grad_offset(name)
+ * (ake_pcnet_grad_floats() floats; valid right after ake_pcnet_create).  Rebuilds every packed weight -- eval-mode
+ * BatchNorm folding included, bit-identical to set_tensor + finalize -- with two kernels on `stream`; replaces
+ * set_tensor/finalize for callers whose weights live on the device.  The buffer is only read during the call. */
+int ake_pcnet_load_from_device_f32(ake_pcnet* net, const float* params_dev, ake_stream_t stream);
+/* nn.BatchNorm2d's train-mode side effect, on the flat parameter buffer: running_mean/var <- (1-m)*running + m*(batch mean,
+ * UNBIASED batch variance), from the bn_stats a training forward returned.  Reference default momentum 0.1. */
+int ake_pcnet_update_running_stats_f32(const ake_pcnet* net, const float* bn_stats_dev, float* params_dev, float momentum,
+                                       ake_stream_t stream);
 
 size_t ake_pcnet_workspace_bytes(const ake_pcnet* net, int batch, int frames);
 /*
@@ -146,12 +156,23 @@ int ake_pcnet_forward_train_f32(const ake_pcnet* net, const float* mel_dev, int 
  * convolution outputs and BatchNorm batch statistics it needs.  d_*_dev are dLoss/d(key_out, tonic_out, genre_out); key_out_dev
  * is the forward's key output (for the sigmoid derivative).  grads_out_dev receives dLoss/d(parameter) for every float entry of
  * the state_dict, flat, at ake_pcnet_grad_offset(name) (ake_pcnet_grad_floats() floats in total; running statistics get zeros).
+ * accumulate != 0 adds to grads_out_dev instead of overwriting it (accumulate_grad_batches, train_model.py:118).
  * Built for num_layers <= 2 without --max_pool; otherwise AKE_ERR_UNSUPPORTED. */
 size_t ake_pcnet_grad_floats(const ake_pcnet* net);
 int64_t ake_pcnet_grad_offset(const ake_pcnet* net, const char* name);
 int ake_pcnet_backward_f32(const ake_pcnet* net, const float* mel_dev, int batch, int frames, const int64_t* seq_length_dev,
                            const float* key_out_dev, const float* d_key_dev, const float* d_tonic_dev, const float* d_genre_dev,
-                           float* grads_out_dev, void* workspace, size_t workspace_bytes, ake_stream_t stream);
+                           float* grads_out_dev, int accumulate, void* workspace, size_t workspace_bytes, ake_stream_t stream);
+
+/* Fused Adam over flat buffers, torch.optim.Adam semantics as the reference configures it (models.py:1017-1027:
+ * betas (0.9, 0.999), eps 1e-8, weight_decay = --reg as L2 added to the gradient, bias correction with `step` = 1, 2, ...):
+ *   g = grad * grad_scale + weight_decay * p;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g
+ *   p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps)
+ * trainable_dev (nullable): one byte per element, 0 = leave untouched (running statistics inside the flat buffer).
+ * grad_scale folds the 1/world_size of a summed all-reduce (and 1/accumulate_grad_batches if the caller did not scale the loss). */
+int ake_adam_step_f32(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev,
+                      const unsigned char* trainable_dev, size_t count, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int step, float grad_scale, ake_stream_t stream);
 
 /* Debug tap: copy an intermediate activation of the LAST forward call out of the workspace.
  * name is the reference module path whose output it is (e.g. "model.1.p2p.layer.8"). */

@@ -20,17 +20,49 @@ LRELU_SLOPE = 0.01   # nn.LeakyReLU() default, models.py:197,234,315
 BN_EPS = 1e-5        # nn.BatchNorm2d default, models.py:196,233,314
 
 
+_BN_SINK = None      # set by record_bn_stats(): list of (prefix, batch mean, biased batch var, elements per channel)
+
+
+class record_bn_stats:
+    """Context manager: collect the batch statistics of every train-mode BatchNorm the forward visits, so that a caller
+    can restate nn.BatchNorm2d's side effect (``running <- 0.9*running + 0.1*(mean, unbiased var)``, torch defaults; the
+    reference never overrides momentum, models.py:196,233,314)."""
+
+    def __enter__(self):
+        global _BN_SINK
+        self.rows = _BN_SINK = []
+        return self.rows
+
+    def __exit__(self, *exc):
+        global _BN_SINK
+        _BN_SINK = None
+
+
+def update_running_stats(sd, rows, momentum=0.1):
+    """Apply torch's train-mode running-statistics update to ``sd`` in place for the rows of ``record_bn_stats``."""
+    with torch.no_grad():
+        for prefix, mean, var, count in rows:
+            unbiased = var * count / max(count - 1, 1)
+            sd[prefix + "running_mean"].mul_(1 - momentum).add_(momentum * mean.detach().to(sd[prefix + "running_mean"].dtype))
+            sd[prefix + "running_var"].mul_(1 - momentum).add_(momentum * unbiased.detach().to(sd[prefix + "running_var"].dtype))
+            key = prefix + "num_batches_tracked"
+            if key in sd:
+                sd[key] += 1
+
+
 def _bn(x, sd, prefix, training=False, stats=None):
     """BatchNorm2d, eval mode = running stats (models.py:196 etc.).
 
     ``training=True`` restates train-mode normalisation (batch statistics,
     biased variance) as ``equivariance_test.py:178`` runs the net; running
-    buffers are not updated here.
+    buffers are not updated here (see ``record_bn_stats`` / ``update_running_stats``).
     """
     w, b = sd[prefix + "weight"], sd[prefix + "bias"]
     if training:
         mean = x.mean(dim=(0, 2, 3))
         var = x.var(dim=(0, 2, 3), unbiased=False)
+        if _BN_SINK is not None:
+            _BN_SINK.append((prefix, mean, var, x.numel() // x.shape[1]))
     else:
         mean, var = sd[prefix + "running_mean"], sd[prefix + "running_var"]
     if stats is not None:

@@ -59,3 +59,42 @@ def test_two_rank_sharded_inference_equals_single_process(tmp_path):
     ref = torch.cat([k, t, gn], 1).numpy()
     assert rows.shape == (5, 35) and np.abs(rows - ref).max() < 1e-5
     assert float(np.load(tmp_path / "tmax.npy")) == 2.0
+
+
+def _dp_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import ake_amd.distributed as D
+    D.init_from_env("gloo")
+    torch.manual_seed(rank)                                          # ranks start from different weights
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 2))
+    D.broadcast_parameters(net)                                      # -> rank 0's weights and buffers everywhere
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn((8, 6), generator=g)
+    lo, hi = D.shard_range(8, rank, world)
+    net(x[lo:hi]).square().sum().backward()
+    scale = D.all_reduce_gradients(net)                              # generic (non-flat) branch: grads hold the mean afterwards
+    assert scale == 1.0
+    torch.save({"w": [p.detach().clone() for p in net.parameters()], "g": [p.grad.clone() for p in net.parameters()],
+                "local": [p for p in net.parameters()] and None}, os.path.join(out_dir, f"dp{rank}.pt"))
+
+
+def test_two_rank_gradient_all_reduce_is_the_mean(tmp_path):
+    """Training partitioning of SURVEY.md section 8e on CPU: broadcast, local backward on a shard, summed all-reduce / world."""
+    mp.spawn(_dp_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "dp0.pt"), torch.load(tmp_path / "dp1.pt")
+    for wa, wb in zip(a["w"], b["w"]):
+        assert torch.equal(wa, wb)
+    for ga, gb in zip(a["g"], b["g"]):
+        assert torch.equal(ga, gb)
+    # emulate: same initial weights (rank 0's seed), per-shard gradients, mean
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 2))
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn((8, 6), generator=g)
+    grads = []
+    for lo, hi in ((0, 4), (4, 8)):
+        net.zero_grad()
+        net(x[lo:hi]).square().sum().backward()
+        grads.append([p.grad.clone() for p in net.parameters()])
+    for got, g0, g1 in zip(a["g"], *grads):
+        assert torch.allclose(got, 0.5 * (g0 + g1), atol=1e-6)

@@ -93,3 +93,20 @@ def test_max_pool_quirk(gold_default):
     ka, ta, _ = pcnet_oracle.pcnet_forward(sd, x, seq)
     assert np.abs(tm[1:].numpy() - ta[1:].numpy()).max() == 0
     assert np.abs(tm[0].numpy() - ta[0].numpy()).max() > 1e-6
+
+
+def test_running_stats_restatement_matches_torch_batchnorm():
+    """oracle.update_running_stats == nn.BatchNorm2d's train-mode side effect (momentum 0.1, unbiased variance)."""
+    torch.manual_seed(0)
+    bn = torch.nn.BatchNorm2d(5).double().train()
+    with torch.no_grad():
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0); bn.weight.normal_(); bn.bias.normal_()
+    sd = {"p." + k: v.clone() for k, v in bn.state_dict().items()}
+    x = torch.randn(3, 5, 4, 7, dtype=torch.float64) * 2 + 1
+    y = bn(x)
+    with pcnet_oracle.record_bn_stats() as rows:
+        y2 = pcnet_oracle._bn(x, sd, "p.", training=True)
+    pcnet_oracle.update_running_stats(sd, rows)
+    assert torch.allclose(y, y2, atol=1e-12)
+    for k, v in bn.state_dict().items():
+        assert torch.allclose(sd["p." + k].double(), v.double(), atol=1e-12), k
