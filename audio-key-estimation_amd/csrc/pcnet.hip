@@ -326,7 +326,7 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
     a.w = n->blob_dev + pc.w_off; a.bias = n->blob_dev + pc.b_off; a.cout = pc.cout;
     a.dst = dst; a.dst_coff = dst_coff; a.dst_clip_stride = static_cast<long long>(dst_ctot) * a.H_out * a.T_out;
     a.lrelu = lrelu ? 1 : 0;
-    a.in_affine = in_affine; a.stats = stats; a.accumulate = accumulate ? 1 : 0;
+    a.in_affine = in_affine; a.stats = stats; a.stats_stride = 2 * n->bn_channels; a.accumulate = accumulate ? 1 : 0;
     Tile t;
     MTile mtile;
     static const int mt_env = std::getenv("AKE_MT") ? std::atoi(std::getenv("AKE_MT")) : 3;
@@ -390,7 +390,7 @@ struct Buffers {           // workspace carve
     size_t bytes = 0;
     // training-mode forward only: BatchNorm statistics, raw semitone-conv outputs and the pending-affine table
     // ([C][3] = scale, shift, negative slope) of every buffer that can hold a raw (pre-BatchNorm) tensor
-    double* stats = nullptr;           // [bn_channels][2]
+    double* stats = nullptr;           // [kStatSlots][bn_channels][2]
     float* bstats = nullptr;           // [bn_channels][3] batch mean, biased variance, element count
     std::vector<float*> semi_raw, aff_semi, aff_cat, aff_p2pin;
     // every convolution keeps its own raw output in training mode (the backward pass needs all of them)
@@ -438,7 +438,7 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
     b->map_k = cv.take<float>(B * 12 * b->Tf); b->map_t = cv.take<float>(B * 12 * b->Tf);
     if (c.genre) { b->hid_g = cv.take<float>(2 * hid); b->map_g = cv.take<float>(B * 12 * b->Tf); }
     if (train) {
-        b->stats = cv.take<double>(static_cast<size_t>(n->bn_channels) * 3);
+        b->stats = cv.take<double>(static_cast<size_t>(n->bn_channels) * 2 * kStatSlots);
         b->stats2 = cv.take<double>(static_cast<size_t>(n->bn_channels) * 3);
         b->bstats = cv.take<float>(static_cast<size_t>(n->bn_channels) * 3);
         b->coef = cv.take<float>(static_cast<size_t>(n->bn_channels) * 4);
@@ -948,7 +948,7 @@ struct Fwd {
     void finalize_bn(int bn, double count, float* aff_out) {
         const auto& l = n->bns[bn];
         ake::ProfScope ps("bn_finalize_kernel", s);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((l.C + 63) / 64), dim3(64), 0, s, b.stats + 2 * l.ch_off, count,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((l.C + 63) / 64), dim3(64), 0, s, b.stats + 2 * l.ch_off, 2 * n->bn_channels, count,
                            n->blob_dev + l.gamma_off, n->blob_dev + l.beta_off, aff_out, b.bstats + 3 * l.ch_off, l.C);
         // the element count rides along for the unbiased running variance (written by the host-visible copy below)
     }
@@ -1220,7 +1220,7 @@ int forward_impl(const ake_pcnet* n, bool train, const float* mel, int batch, in
     if (rc) return rc;
     AKE_REQUIRE(workspace && ws_bytes >= b.bytes, AKE_ERR_WORKSPACE, "pcnet: workspace %zu < %zu bytes", ws_bytes, b.bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (train) AKE_HIP_CHECK(hipMemsetAsync(b.stats, 0, sizeof(double) * 2 * n->bn_channels, s));
+    if (train) AKE_HIP_CHECK(hipMemsetAsync(b.stats, 0, sizeof(double) * 2 * n->bn_channels * kStatSlots, s));
     Fwd f{n, b, s, train};
     if ((rc = f.entry(mel, batch))) return rc;
     for (int c0 = 0; c0 < batch && n->cfg.num_layers > 1; c0 += chunk) {

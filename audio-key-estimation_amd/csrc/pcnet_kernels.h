@@ -50,9 +50,14 @@ struct ConvArgs {
     int n_row_tiles, n_time_tiles;
     int Tp;                   // LDS row pitch in floats (multiple of 4, >= TT + KW - 1)
     const float* in_affine;   // [c0+c1][3] (scale, shift, negative slope) applied to every staged input value, or null
-    double* stats;            // [cout][2] += (sum, sum of squares) of the raw outputs, or null
+    double* stats;            // [kStatSlots][..][2] += (sum, sum of squares) of the raw outputs, or null
+    int stats_stride;         // doubles between two slots of `stats` (workgroups spread their atomics over the slots)
     int accumulate;           // 1: dst += result (several data-gradients landing on one tensor)
 };
+
+// Per-channel batch statistics are accumulated with double atomics; thousands of workgroups hitting the same 16 addresses
+// serialise in one L2 channel, so every producer adds into one of kStatSlots copies and bn_finalize_kernel sums them.
+constexpr int kStatSlots = 64;
 
 __device__ __forceinline__ int wrap(int i, int n) {
     i %= n;
@@ -523,8 +528,9 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
             const int n = (ngrp * NT + nt) * 16 + r16;
             const int co = n / TB;
             if (q == 0 && n - co * TB == 0 && co < a.cout) {
-                atomicAdd(a.stats + 2 * co, static_cast<double>(s1));
-                atomicAdd(a.stats + 2 * co + 1, static_cast<double>(s2));
+                double* st = a.stats + static_cast<size_t>((blockIdx.x + 7 * blockIdx.z + wave) & (kStatSlots - 1)) * a.stats_stride;
+                atomicAdd(st + 2 * co, static_cast<double>(s1));
+                atomicAdd(st + 2 * co + 1, static_cast<double>(s2));
             }
         }
     }
@@ -691,12 +697,17 @@ __global__ void time_pool_affine_kernel(const float* __restrict__ src, const flo
 
 // (sum, sumsq) over `count` values per channel -> BatchNorm(train) as an affine triple, plus (batch mean, biased
 // variance, count) for the running-statistics update done by the caller (momentum 0.1, unbiased variance: torch semantics).
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const float* __restrict__ gamma,
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int stats_stride, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ aff, float* __restrict__ batch_stats, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double mean = stats[2 * c] / count;
-    double var = stats[2 * c + 1] / count - mean * mean;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < kStatSlots; ++k) {
+        s1 += stats[static_cast<size_t>(k) * stats_stride + 2 * c];
+        s2 += stats[static_cast<size_t>(k) * stats_stride + 2 * c + 1];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
     if (var < 0) var = 0;
     const double sc = static_cast<double>(gamma[c]) / sqrt(var + 1e-5);
     aff[3 * c] = static_cast<float>(sc);

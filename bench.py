@@ -76,6 +76,67 @@ def cpu_baseline(sd, n_clips=24, batch=8):
                       f"torch CPU ops on {threads} threads, {dt:.1f} s"}
 
 
+def train_main(args):
+    """BASELINE configs[3]: B clips per GPU (log-CQT features resident, as the reference caches them, KeyDataset.py:154-192),
+    one training step = train-mode forward + general_step loss + HIP backward + ONE all-reduce of the flat 668 KB gradient
+    buffer + fused Adam.  Secondary line; the headline metric is the inference line printed without --train."""
+    import ake_amd
+    from ake_amd import distributed as D, synthetic
+    rank, world, local_rank = D.init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    sd = load_fixture_weights()
+    net = ake_amd.PitchClassNet(P, 12, 2, 7, Namespace(genre=True, lr=3e-4, gamma=0.96, acc_grad=1))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    B = args.batch
+    audio, labels = synthetic.make_batch_device(range(rank * B, rank * B + B), dev)
+    mel = ake_amd.cqt_logmag(audio, SR, HOP, n_bins=P, bins_per_octave=36)[:, None].contiguous()   # (B,1,288,76), computed once
+    del audio
+    batch = {"mel": mel, "seq_length": torch.full((B,), T_FRAMES, device=dev), **{k: torch.as_tensor(v).to(dev) for k, v in labels.items()}}
+    D.broadcast_parameters(net)
+    optim = net.configure_optimizers()[0][0]
+    net.train()
+    net.trainer = ake_amd.Trainer(accumulate_grad_batches=1)
+
+    def step(i):
+        optim.zero_grad()
+        net.training_step(batch, i)["loss"].backward()
+        optim.grad_scale = D.all_reduce_gradients(net)
+        optim.step()
+
+    for i in range(max(args.warmup, 1)):
+        step(i)
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    ake_amd._lib.prof_enable("", True)
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    prof_all = ake_amd._lib.prof_results()
+    ake_amd._lib.prof_enable("", False)
+    if rank != 0:
+        return
+    value = B * world * args.steps / dt
+    kernel_ms = {k: round(v[0] / args.steps, 4) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}
+    print(json.dumps({
+        "metric": "clips/s, PitchClassNet training step (fwd + bwd + grad all-reduce + Adam)", "value": round(value, 1), "unit": "clips/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[3]: {B} clips per GPU (288x76 log-CQT resident), default PitchClassNet, local BatchNorm, "
+                               f"one all-reduce of the flat gradient buffer per step, fused Adam lr 3e-4",
+                   "clips_per_gpu": B, "parallelism": f"data-parallel x{world}"},
+        "train_fp32_frac_of_peak": round(3 * 2.0 * NET_MACS_PER_CLIP * value / world / (PEAK_FP32_TFLOPS * 1e12), 4),
+        "kernel_ms_per_step": kernel_ms}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,7 +144,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE configs[3] instead of the headline: one fwd + bwd + gradient all-reduce + fused Adam step per GPU batch")
     args = ap.parse_args()
+    if args.train:
+        return train_main(args)
 
     import ake_amd
     from ake_amd import distributed as D, synthetic
