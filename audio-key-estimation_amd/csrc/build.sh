@@ -14,7 +14,11 @@ for f in common.cpp cqt.hip pcnet.hip pipeline.hip optim.hip; do
   [ -f "$obj" ] || stale=1
   for d in "$f" $HEADERS; do [ "$d" -nt "$obj" ] && stale=1; done
   if [ $stale = 1 ]; then
-    ( $HIPCC $FLAGS -x hip -c "$f" -o "$obj" ) &
+    extra=""
+    # cqt.hip: the SLP vectoriser turns the FIR taps into v_pk_* math fed by ds_read2_b32 gathers (4-way LDS bank
+    # conflicts, measured: half of all LDS cycles); plain ds_read_b128 + scalar FMAs are faster
+    [ "$f" = cqt.hip ] && extra="-fno-slp-vectorize"
+    ( $HIPCC $FLAGS $extra -x hip -c "$f" -o "$obj" ) &
     pids+=($!)
   fi
 done

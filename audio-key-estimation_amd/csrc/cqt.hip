@@ -23,7 +23,9 @@
 // (sample m stored at m + pad, pad = Hh rounded up to 4; len_o = ceil(n/2^o) + 2*pad rounded up to 4, so every
 // row and every 512-output tile starts 16-byte aligned), out [B][n_bins][out_frames] f32.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <numeric>
 #include <vector>
 
@@ -145,6 +147,184 @@ __global__ __launch_bounds__(kDecimThreads) void cqt_decimate_kernel(
     *reinterpret_cast<float4*>(out + clip * out_stride + o0 + 4 * tid) = make_float4(r[0], r[1], r[2], r[3]);
 }
 
+
+// ---- fused decimator cascade ---------------------------------------------------------------------------------------
+// All half-band stages in ONE pass over the audio: a workgroup streams a segment of one clip in chunks of C samples
+// ("ticks"), keeps every level's recent samples in LDS rings (de-interleaved into even / odd samples like the per-stage
+// kernel) and emits, per tick, C/2 samples of level 1, C/4 of level 2, ... -- each level lags the one above by the filter
+// half length, rounded so that every LDS access stays 16-byte aligned (kLagHost).  The audio is read from HBM once; the
+// decimated signals are written once, and for the top levels only where a CQT frame's tap window will read them
+// (a frame every `hop` samples touches ~6 % of the full-rate signal, 12 % of level 1, 25 % of level 2, ...).
+// Arithmetic per output is identical to cqt_decimate_kernel (same operation order -> bit-identical signals).
+constexpr int kCascMax = 7;                                            // stages the fused kernel handles
+constexpr int kCascHist = 32;                                          // ring history in pair units (64 samples)
+constexpr int kLagHost[kCascMax + 1] = {0, 16, 24, 24, 24, 24, 24, 24};
+
+struct CascArgs {
+    const float* x;            // [batch][x_stride] audio
+    long long x_stride;
+    int n;                     // samples per clip
+    float* y[kCascMax + 1];    // level l = 1..n_stage: sample m at y[l][clip * y_stride[l] + m + pad]
+    long long y_stride[kCascMax + 1];
+    int y_count[kCascMax + 1]; // floats stored per clip (sample range [-pad, y_count - pad))
+    int need[kCascMax + 1];    // level l is stored only within `need[l]` full-rate samples of a frame centre (< 0: everywhere)
+    int pad, hop, n_stage;
+    int g0;                    // full-rate frontier before tick 0 (multiple of 512, <= -512)
+    int ticks_total, ticks_per_seg, warm;
+    DecimTaps taps;
+};
+
+// LDS image of level l (an INPUT level, l = 0 .. S-1), in "pairs" (even sample 2h -> ev[h], odd sample 2h+1 -> od[h]):
+//   [0, kCascHist) history carried over from the previous tick, [kCascHist, kCascHist + C/2^(l+1)) this tick's samples.
+template <int C>
+struct CascLayout {
+    static constexpr int pairs(int l) { return (C >> (l + 1)) + kCascHist; }
+    static constexpr int ev(int l) { int o = 0; for (int i = 0; i < l; ++i) o += 2 * pairs(i); return o; }
+    static constexpr int od(int l) { return ev(l) + pairs(l); }
+    static constexpr int total = 2 * (C - (C >> kCascMax)) + 2 * kCascMax * kCascHist;
+};
+
+template <int NODD, int C, int NT, int L>
+__device__ __forceinline__ void cascade_level(const CascArgs& a, float* lds, int tid, int clip, int k, bool owned) {
+    using Lay = CascLayout<C>;
+    constexpr int chunk_out = C >> (L + 1);                          // outputs of level L+1 per tick
+    constexpr int lag_in = L == 0 ? 0 : (L == 1 ? 16 : 24), lag_out = L == 0 ? 16 : 24;   // kLag[L], kLag[L+1]
+    constexpr int E = (2 * lag_out - lag_in) / 2;                    // pair offset of the first new output's centre
+    const float* ev = lds + Lay::ev(L);
+    const float* od = lds + Lay::od(L);
+    const int f_prev = ((a.g0 + k * C) >> (L + 1)) - lag_out;        // first sample of level L+1 produced this tick
+    float* yrow = a.y[L + 1] + clip * a.y_stride[L + 1] + a.pad;
+    const int need = a.need[L + 1];
+    const float hopf = static_cast<float>(a.hop), inv_hop = 1.f / hopf;
+#pragma unroll
+    for (int j0 = 0; j0 < chunk_out / 4; j0 += NT) {
+        const int j = j0 + tid;
+        if (chunk_out / 4 - j0 < NT && j >= chunk_out / 4) break;
+        float O[2 * NODD + 4], Cc[4];
+        const float* po = od + kCascHist + 4 * j - E - NODD;
+#pragma unroll
+        for (int i = 0; i < (2 * NODD + 4) / 4; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(po + 4 * i);
+            O[4 * i] = t.x; O[4 * i + 1] = t.y; O[4 * i + 2] = t.z; O[4 * i + 3] = t.w;
+        }
+        {
+            const float4 c = *reinterpret_cast<const float4*>(ev + kCascHist + 4 * j - E);
+            Cc[0] = c.x; Cc[1] = c.y; Cc[2] = c.z; Cc[3] = c.w;
+        }
+        float r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float acc = a.taps.h0 * Cc[u];
+#pragma unroll
+            for (int q = 0; q < NODD; ++q) acc = fmaf(a.taps.hodd[q], O[u + NODD - 1 - q] + O[u + NODD + q], acc);
+            r[u] = acc;
+        }
+        if (L + 1 < kCascMax && L + 1 < a.n_stage) {
+            float* evn = lds + Lay::ev(L + 1 < kCascMax ? L + 1 : 0) + kCascHist;
+            float* odn = lds + Lay::od(L + 1 < kCascMax ? L + 1 : 0) + kCascHist;
+            *reinterpret_cast<float2*>(evn + 2 * j) = make_float2(r[0], r[2]);
+            *reinterpret_cast<float2*>(odn + 2 * j) = make_float2(r[1], r[3]);
+        }
+        const int m0 = f_prev + 4 * j;
+        if (owned && m0 >= -a.pad && m0 + a.pad < a.y_count[L + 1]) {
+            bool store = true;
+            if (need >= 0) {                                         // distance to the nearest frame centre, full-rate samples
+                const float pos = static_cast<float>(m0 * (1 << (L + 1)));
+                store = fabsf(pos - rintf(pos * inv_hop) * hopf) <= static_cast<float>(need);
+            }
+            if (store) *reinterpret_cast<float4*>(yrow + m0) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    }
+    // carry this level's last kCascHist pairs over to the history slots -- by threads from the top of the block, which have
+    // no task in the deeper (smaller) levels; level L was last read in the previous phase, so there is no reader left
+    if (L >= 1) {
+        constexpr int LP = L - 1;                                    // the level whose consumer ran in the previous phase
+        const int t2 = NT - 1 - tid;
+        if (t2 < 2 * kCascHist / 4) {
+            float* base = lds + (t2 < kCascHist / 4 ? Lay::ev(LP) : Lay::od(LP));
+            const int v = t2 < kCascHist / 4 ? t2 : t2 - kCascHist / 4;
+            const float4 h = *reinterpret_cast<const float4*>(base + (C >> (LP + 1)) + 4 * v);
+            *reinterpret_cast<float4*>(base + 4 * v) = h;
+        }
+    }
+}
+
+template <int NODD, int C, int NT>
+__global__ __launch_bounds__(NT) void cqt_cascade_kernel(CascArgs a) {
+    static_assert(C % 512 == 0 && C >= 1024 && (C / 4) % NT == 0, "chunk");
+    using Lay = CascLayout<C>;
+    __shared__ __attribute__((aligned(16))) float lds[Lay::total];
+    const int tid = threadIdx.x;
+    const int clip = blockIdx.y;
+    const int S = a.n_stage;
+    const int k_own = blockIdx.x * a.ticks_per_seg;
+    const int k_end = k_own + a.ticks_per_seg < a.ticks_total ? k_own + a.ticks_per_seg : a.ticks_total;
+    const int k_start = k_own - a.warm > 0 ? k_own - a.warm : 0;
+    if (k_own >= a.ticks_total) return;
+    for (int i = tid; i < Lay::total; i += NT) lds[i] = 0.f;
+    const float* xs = a.x + clip * a.x_stride;
+
+    constexpr int G = C / 4 / NT;                                     // float4 groups of the audio chunk per thread
+    // Audio through a buffer resource: hardware range checking returns 0 for every dword outside [0, n) -- the zero padding
+    // of the transform's definition -- so the prefetch is branch-free and all G loads are in flight together.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs), 0, a.n * 4, 0x00020000);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    f4u pre[G];
+    auto fetch = [&](int k) {                                          // audio samples [F0(k-1), F0(k))
+        const int s0 = a.g0 + k * C;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int i0 = s0 + 4 * (tid + NT * g);                   // negative -> huge unsigned offset -> out of range -> 0
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, i0 * 4, 0, 0);
+            pre[g] = __builtin_bit_cast(f4u, v);
+        }
+    };
+    fetch(k_start);
+    __syncthreads();
+    for (int k = k_start; k < k_end; ++k) {
+        const bool owned = k >= k_own;
+        if (S == 1 && k > k_start) {                                  // single stage: level 0 is also the deepest level
+            float4 h = {0.f, 0.f, 0.f, 0.f};
+            if (tid < 2 * kCascHist / 4) h = *reinterpret_cast<const float4*>(lds + (tid < kCascHist / 4 ? Lay::ev(0) : Lay::od(0)) + (C >> 1) + 4 * (tid % (kCascHist / 4)));
+            __syncthreads();
+            if (tid < 2 * kCascHist / 4) *reinterpret_cast<float4*>(lds + (tid < kCascHist / 4 ? Lay::ev(0) : Lay::od(0)) + 4 * (tid % (kCascHist / 4))) = h;
+        }
+        {   // level 0: the prefetched chunk (pairs: even sample -> ev, odd -> od)
+            float* ev = lds + Lay::ev(0) + kCascHist;
+            float* od = lds + Lay::od(0) + kCascHist;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int p = 2 * (tid + NT * g);
+                *reinterpret_cast<float2*>(ev + p) = make_float2(pre[g][0], pre[g][2]);
+                *reinterpret_cast<float2*>(od + p) = make_float2(pre[g][1], pre[g][3]);
+            }
+            // ... and the deepest input level's history (its consumer ran in the last phase of the previous tick)
+            if (S > 1 && k > k_start) {
+                const int LP = S - 1;
+                const int t2 = NT - 1 - tid;
+                if (t2 < 2 * kCascHist / 4) {
+                    int evo = 0;
+                    for (int i = 0; i < LP; ++i) evo += 2 * ((C >> (i + 1)) + kCascHist);
+                    const int pairs = (C >> (LP + 1)) + kCascHist;
+                    float* base = lds + evo + (t2 < kCascHist / 4 ? 0 : pairs);
+                    const int v = t2 < kCascHist / 4 ? t2 : t2 - kCascHist / 4;
+                    const float4 h = *reinterpret_cast<const float4*>(base + (C >> (LP + 1)) + 4 * v);
+                    *reinterpret_cast<float4*>(base + 4 * v) = h;
+                }
+            }
+        }
+        if (k + 1 < k_end) fetch(k + 1);                              // next chunk in flight during the whole tick
+        __syncthreads();
+        cascade_level<NODD, C, NT, 0>(a, lds, tid, clip, k, owned);
+        __syncthreads();
+        if (S > 1) { cascade_level<NODD, C, NT, 1>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (S > 2) { cascade_level<NODD, C, NT, 2>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (S > 3) { cascade_level<NODD, C, NT, 3>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (S > 4) { cascade_level<NODD, C, NT, 4>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (S > 5) { cascade_level<NODD, C, NT, 5>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (S > 6) { cascade_level<NODD, C, NT, 6>(a, lds, tid, clip, k, owned); __syncthreads(); }
+    }
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -466,11 +646,43 @@ int ake_cqt_logmag_f32(const ake_cqt_plan* p, const float* audio, int batch, int
     call.count[0] = static_cast<int>(n);
     for (int o = 1; o < p->n_oct; ++o) {
         const int ls = len_store(p, o, n);
-        float* y = c.take<float>(static_cast<size_t>(batch) * ls);
-        call.x[o] = y;
+        call.x[o] = c.take<float>(static_cast<size_t>(batch) * ls);
         call.stride[o] = ls;
         call.lo[o] = -pad_of(p);
         call.count[o] = ls;
+    }
+    static const bool legacy = std::getenv("AKE_CQT_LEGACY") != nullptr;     // per-stage kernels only (bisecting / tests)
+    int fused = (legacy || p->half_len > 23) ? 0 : std::min(p->n_oct - 1, kCascMax);
+    if (fused > 0) {
+        constexpr int C = 4096, NT = 256;
+        CascArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.x = audio; a.x_stride = audio_stride; a.n = static_cast<int>(n);
+        a.pad = pad_of(p); a.hop = p->cfg.hop_length; a.n_stage = fused; a.taps = p->taps;
+        for (int l = 1; l <= fused; ++l) {
+            a.y[l] = const_cast<float*>(call.x[l]);
+            a.y_stride[l] = call.stride[l];
+            a.y_count[l] = call.count[l];
+            // the bank reads, per frame, taps [c - uh, c - uh + 16 * n_blocks) of level l around the frame centre c; a later
+            // per-stage kernel (more than kCascMax stages) needs its input level everywhere
+            const long long need = static_cast<long long>(p->octs[l].uh + 24) << l;
+            a.need[l] = (2 * need >= a.hop || (l == fused && fused < p->n_oct - 1)) ? -1 : static_cast<int>(need);
+        }
+        a.g0 = -512;
+        const long long g1 = n + static_cast<long long>(25 + kLagHost[fused]) * (1ll << fused) + 512;
+        a.ticks_total = static_cast<int>((g1 - a.g0 + C - 1) / C);
+        static const int segs_env = std::getenv("AKE_CQT_SEGS") ? std::atoi(std::getenv("AKE_CQT_SEGS")) : 0;
+        const int segs = std::max(1, std::min(a.ticks_total, segs_env > 0 ? segs_env : 4));
+        a.ticks_per_seg = (a.ticks_total + segs - 1) / segs;
+        a.warm = 3;                                         // >= 64 * 2^7 / C ticks of history before the first owned tick
+        dim3 grid((a.ticks_total + a.ticks_per_seg - 1) / a.ticks_per_seg, batch);
+        ake::ProfScope ps("cqt_cascade_kernel", stream);
+        if (p->half_len == 15) hipLaunchKernelGGL((cqt_cascade_kernel<8, C, NT>), grid, dim3(NT), 0, stream, a);
+        else hipLaunchKernelGGL((cqt_cascade_kernel<12, C, NT>), grid, dim3(NT), 0, stream, a);
+    }
+    for (int o = fused + 1; o < p->n_oct; ++o) {
+        const int ls = call.count[o];
+        float* y = const_cast<float*>(call.x[o]);
         dim3 grid((ls + kDecimOutPerBlock - 1) / kDecimOutPerBlock, batch);
         ake::ProfScope ps("cqt_decimate_kernel", stream);
         const int in_pad = -call.lo[o - 1];

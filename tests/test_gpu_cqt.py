@@ -85,3 +85,41 @@ def test_full_size_batch_properties(plan):
     # and 2 of the 64 against the oracle
     ref = O.FastDirectCQT(SR, HOP, dtype=torch.float64)(audio[[5, 40]].cpu().numpy()).numpy()
     assert rel_err(out[[5, 40]].cpu().numpy(), ref) < TOL
+
+
+_CASCADE_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import ake_amd
+out = {}
+g = torch.Generator().manual_seed(11)
+for name, n, sr, hop, bins, bpo in (("full", 330750, 22050, 4410, 288, 36), ("ragged", 100003, 22050, 4410, 288, 36),
+                                    ("short", 5000, 22050, 4410, 288, 36), ("nine_octaves", 132300, 44100, 4410, 324, 36),
+                                    ("hop512", 40000, 22050, 512, 84, 12)):
+    y = (torch.rand((3, n), generator=g) * 2 - 1).cuda()
+    out[name] = ake_amd.cqt_logmag(y, sr, hop, n_bins=bins, bins_per_octave=bpo).cpu().numpy()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_fused_cascade_bit_identical_to_per_stage_kernels(tmp_path):
+    """The one-pass streaming decimator (ring buffers, segment warm-up, sparse stores of the top levels) must hand the
+    filter bank exactly the samples the plain one-kernel-per-stage cascade does: same arithmetic order -> equal bits.
+    (AKE_CQT_LEGACY is read once per process, hence the two child processes; they run one after the other.)"""
+    import os, subprocess, sys
+    script = tmp_path / "cascade.py"
+    script.write_text(_CASCADE_SCRIPT)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("fused", "legacy"):
+        env = dict(os.environ)
+        env.pop("AKE_CQT_LEGACY", None)
+        if mode == "legacy":
+            env["AKE_CQT_LEGACY"] = "1"
+        path = tmp_path / f"{mode}.npz"
+        subprocess.run([sys.executable, str(script), repo, str(path)], check=True, env=env, timeout=600)
+        res[mode] = np.load(path)
+    for k in res["fused"].files:
+        a, b = res["fused"][k], res["legacy"][k]
+        assert a.shape == b.shape and np.isfinite(a).all()
+        assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
