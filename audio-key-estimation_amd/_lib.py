@@ -19,7 +19,7 @@ class AkeError(RuntimeError):
 
 class CqtConfig(C.Structure):
     _fields_ = [("sample_rate", C.c_int), ("hop_length", C.c_int), ("n_bins", C.c_int), ("bins_per_octave", C.c_int),
-                ("fmin", C.c_double), ("q_mode", C.c_int), ("decim_half_len", C.c_int), ("decim_beta", C.c_double)]
+                ("fmin", C.c_double), ("q_mode", C.c_int), ("decim_half_len", C.c_int), ("decim_beta", C.c_double), ("engine", C.c_int)]
 
 
 class PcnetConfig(C.Structure):

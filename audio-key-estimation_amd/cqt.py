@@ -27,12 +27,12 @@ class CQTPlan:
     """Filter tables for one (sample rate, hop, bins) on one device; reusable across calls."""
 
     def __init__(self, sr: int, hop_length: int, n_bins: int = 288, bins_per_octave: int = 36, fmin: float = 0.0,
-                 q_mode: int = 0, device=None):
+                 q_mode: int = 0, device=None, engine: int = 0):
         if not torch.cuda.is_available():
             raise _lib.AkeError("the CQT front end needs a HIP device; there is no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.sr, self.hop_length, self.n_bins, self.bins_per_octave = int(sr), int(hop_length), int(n_bins), int(bins_per_octave)
-        cfg = _lib.CqtConfig(int(sr), int(hop_length), int(n_bins), int(bins_per_octave), float(fmin or 0.0), int(q_mode), 0, 0.0)
+        cfg = _lib.CqtConfig(int(sr), int(hop_length), int(n_bins), int(bins_per_octave), float(fmin or 0.0), int(q_mode), 0, 0.0, int(engine))
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().ake_cqt_plan_create(C.byref(cfg), C.byref(self._h)), "ake_cqt_plan_create")

@@ -60,6 +60,19 @@ struct DecimTaps {
     int half_len;
 };
 
+// engine 3 (bf16x3 filter bank), see cqt_bank_bf16_kernel
+struct BankCall2 {
+    const unsigned int* xw[kMaxOct];     // per level: one word per sample, (bf16 hi << 16) | bf16 lo, sample m at xw[m + pad]
+    long long stride[kMaxOct];
+    int pad;
+};
+
+struct OctDesc2 {
+    int k0, n_bins, n_tiles, uh, n_blk;              // n_blk: 32-tap blocks
+    int blk_lo[kMaxTiles], blk_hi[kMaxTiles];
+    long long table_off, phase_stride;               // in 16-byte units: [phase][blk][tile][hi|lo][64 lanes] x 8 bf16
+};
+
 struct BankCall {
     const float* x[kMaxOct];   // per octave: sample m at x[m - lo]
     long long stride[kMaxOct];
@@ -80,6 +93,12 @@ struct ake_cqt_plan {
     OctDesc* octs_dev = nullptr;
     float* table_dev = nullptr;
     size_t table_floats = 0;
+    int engine = 1;                      // resolved ake_cqt_config::engine (1, 2 or 3)
+    std::vector<OctDesc2> octs2;         // engine 3: split-bf16 phase tables
+    OctDesc2* octs2_dev = nullptr;
+    uint4* table2_dev = nullptr;
+    int ppad = 0;                        // pad of the split planes (covers every tap window)
+    size_t bank2_lds = 0;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -168,11 +187,38 @@ struct CascArgs {
     long long y_stride[kCascMax + 1];
     int y_count[kCascMax + 1]; // floats stored per clip (sample range [-pad, y_count - pad))
     int need[kCascMax + 1];    // level l is stored only within `need[l]` full-rate samples of a frame centre (< 0: everywhere)
+    // split-bf16 copies for the bf16x3 filter bank (engine 3): value = hi + lo, both bf16, level 0 (the audio) included;
+    // sample m at ph[l][clip * p_stride[l] + m + ppad] (hi and lo interleaved in one word, so that any tap window is a
+    // dword-aligned vector load: 2-byte aligned 16-byte loads are split into 2-byte requests by the texture addresser,
+    // measured 125 cache accesses per wave load).  null = not wanted.  The pads [-ppad, -pad) and
+    // [p_count - ppad - ..., ) around the produced range are zero-filled so that the bank never checks bounds.
+    unsigned int* ph[kCascMax + 1];      // one 32-bit word per sample: (bf16 hi << 16) | bf16 lo
+    long long p_stride[kCascMax + 1];
+    int p_count[kCascMax + 1];
+    int ppad;
     int pad, hop, n_stage;
     int g0;                    // full-rate frontier before tick 0 (multiple of 512, <= -512)
     int ticks_total, ticks_per_seg, warm;
     DecimTaps taps;
 };
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// 4 consecutive samples -> 4 words (bf16 hi << 16 | bf16 lo): hi = bf16(v) (RNE, v_cvt_pk_bf16_f32), lo = bf16(v - hi);
+// v - (hi + lo) <= 2^-17 |v|
+__device__ __forceinline__ void store_split4(unsigned int* pw, long long idx, float r0, float r1, float r2, float r3) {
+    const f32x2 a = {r0, r1}, b = {r2, r3};
+    const bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
+    const f32x2 la = a - __builtin_convertvector(ha, f32x2), lb = b - __builtin_convertvector(hb, f32x2);
+    const bf16x2 qa = __builtin_convertvector(la, bf16x2), qb = __builtin_convertvector(lb, bf16x2);
+    const unsigned int h01 = __builtin_bit_cast(unsigned int, ha), h23 = __builtin_bit_cast(unsigned int, hb);
+    const unsigned int l01 = __builtin_bit_cast(unsigned int, qa), l23 = __builtin_bit_cast(unsigned int, qb);
+    // perm(a, b, sel): bytes 0-3 index b, 4-7 index a
+    const uint4 w = make_uint4(__builtin_amdgcn_perm(h01, l01, 0x05040100), __builtin_amdgcn_perm(h01, l01, 0x07060302),
+                               __builtin_amdgcn_perm(h23, l23, 0x05040100), __builtin_amdgcn_perm(h23, l23, 0x07060302));
+    *reinterpret_cast<uint4*>(pw + idx) = w;
+}
 
 // LDS image of level l (an INPUT level, l = 0 .. S-1), in "pairs" (even sample 2h -> ev[h], odd sample 2h+1 -> od[h]):
 //   [0, kCascHist) history carried over from the previous tick, [kCascHist, kCascHist + C/2^(l+1)) this tick's samples.
@@ -193,7 +239,7 @@ __device__ __forceinline__ void cascade_level(const CascArgs& a, float* lds, int
     const float* ev = lds + Lay::ev(L);
     const float* od = lds + Lay::od(L);
     const int f_prev = ((a.g0 + k * C) >> (L + 1)) - lag_out;        // first sample of level L+1 produced this tick
-    float* yrow = a.y[L + 1] + clip * a.y_stride[L + 1] + a.pad;
+    float* yrow = a.y[L + 1] ? a.y[L + 1] + clip * a.y_stride[L + 1] + a.pad : nullptr;
     const int need = a.need[L + 1];
     const float hopf = static_cast<float>(a.hop), inv_hop = 1.f / hopf;
 #pragma unroll
@@ -232,7 +278,10 @@ __device__ __forceinline__ void cascade_level(const CascArgs& a, float* lds, int
                 const float pos = static_cast<float>(m0 * (1 << (L + 1)));
                 store = fabsf(pos - rintf(pos * inv_hop) * hopf) <= static_cast<float>(need);
             }
-            if (store) *reinterpret_cast<float4*>(yrow + m0) = make_float4(r[0], r[1], r[2], r[3]);
+            if (store) {
+                if (a.y[L + 1]) *reinterpret_cast<float4*>(yrow + m0) = make_float4(r[0], r[1], r[2], r[3]);
+                if (a.ph[L + 1]) store_split4(a.ph[L + 1], clip * a.p_stride[L + 1] + m0 + a.ppad, r[0], r[1], r[2], r[3]);
+            }
         }
     }
     // carry this level's last kCascHist pairs over to the history slots -- by threads from the top of the block, which have
@@ -280,6 +329,18 @@ __global__ __launch_bounds__(NT) void cqt_cascade_kernel(CascArgs a) {
         }
     };
     fetch(k_start);
+    if (a.ph[0] || a.ph[1]) {   // zero the pads of the split signals outside the produced range [-pad, y_count - pad) (first / last segment)
+        const bool first = blockIdx.x == 0, last = k_end == a.ticks_total;
+        for (int l = 0; l <= S; ++l) {
+            if (!a.ph[l]) continue;
+            const int lo_end = l == 0 ? 0 : -a.pad;                                   // produced range starts here
+            const int hi_beg = l == 0 ? (a.n + 3) / 4 * 4 : a.y_count[l] - a.pad;     // ... and ends here (level 0: audio, rounded up)
+            unsigned int* h = a.ph[l] + clip * a.p_stride[l];
+            if (first) for (int i = 4 * tid; i < lo_end + a.ppad; i += 4 * NT) *reinterpret_cast<uint4*>(h + i) = make_uint4(0, 0, 0, 0);
+            if (last) for (int i = hi_beg + a.ppad + 4 * tid; i < a.p_count[l]; i += 4 * NT) *reinterpret_cast<uint4*>(h + i) = make_uint4(0, 0, 0, 0);
+        }
+    }
+    const float hopf0 = static_cast<float>(a.hop), inv_hop0 = 1.f / hopf0;
     __syncthreads();
     for (int k = k_start; k < k_end; ++k) {
         const bool owned = k >= k_own;
@@ -297,6 +358,17 @@ __global__ __launch_bounds__(NT) void cqt_cascade_kernel(CascArgs a) {
                 const int p = 2 * (tid + NT * g);
                 *reinterpret_cast<float2*>(ev + p) = make_float2(pre[g][0], pre[g][2]);
                 *reinterpret_cast<float2*>(od + p) = make_float2(pre[g][1], pre[g][3]);
+                if (a.ph[0] && owned) {                               // split copy of the audio where the top octave's windows read it
+                    const int i0 = a.g0 + k * C + 4 * (tid + NT * g);
+                    if (i0 >= 0 && i0 < a.n) {
+                        bool store = true;
+                        if (a.need[0] >= 0) {
+                            const float pos = static_cast<float>(i0);
+                            store = fabsf(pos - rintf(pos * inv_hop0) * hopf0) <= static_cast<float>(a.need[0]);
+                        }
+                        if (store) store_split4(a.ph[0], clip * a.p_stride[0] + i0 + a.ppad, pre[g][0], pre[g][1], pre[g][2], pre[g][3]);
+                    }
+                }
             }
             // ... and the deepest input level's history (its consumer ran in the last phase of the previous tick)
             if (S > 1 && k > k_start) {
@@ -410,6 +482,101 @@ __global__ __launch_bounds__(256) void cqt_bank_kernel(
     }
 }
 
+// ---- filter bank on bf16 MFMA with split operands ("bf16x3") -----------------------------------------------------------
+// x = xh + xl and w = wh + wl (each bf16, residual <= 2^-17 relative); acc += xh*wh + xl*wh + xh*wl on
+// v_mfma_f32_16x16x32_bf16 (f32 accumulation): 3 MFMAs of 16 cycles per 32 taps and N-tile instead of 8 f32 MFMAs of 32
+// cycles, at ~1e-5 relative accuracy (the multirate design itself is specified to 1.6e-4).
+// Workgroup = (frame t, octave o, 256 clips): the whole phase table of (o, t) is staged in LDS ONCE (<= 92 KB) and shared
+// by 16 waves of one 16-clip M-tile each.  A operand: lane (row r = clip, q) holds taps 32*blk + 8q .. +7 of its clip =
+// two dword-aligned 16-byte loads of interleaved (hi, lo) words, de-interleaved with 8 v_perm_b32 (the signals are padded,
+// no bounds checks).
+constexpr int kBank2Chunk = 9;          // 32-tap blocks of the phase table resident in LDS at a time
+typedef unsigned int u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4b __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(1024) void cqt_bank_bf16_kernel(
+    BankCall2 call, const OctDesc2* __restrict__ octs, const uint4* __restrict__ table,
+    int batch, int hop, int hop_twos, float* __restrict__ out, long long out_clip_stride, int n_bins_total) {
+    extern __shared__ __attribute__((aligned(16))) uint4 ldsW[];
+    const int t = blockIdx.x;
+    const int o = blockIdx.y;
+    const OctDesc2 g = octs[o];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int clip_raw = blockIdx.z * 256 + wave * 16 + r16;
+    const int clip = clip_raw < batch ? clip_raw : batch - 1;       // idle rows redo the last clip (never stored)
+    const long long c = static_cast<long long>(t) * hop;
+    const int c_int = static_cast<int>(c >> o);
+    const int ph = static_cast<int>(c & ((1ll << o) - 1));
+    const int sh = hop_twos < o ? hop_twos : o;
+    const uint4* __restrict__ w = table + g.table_off + static_cast<long long>(ph >> sh) * g.phase_stride;
+    const long long base = clip * call.stride[o] + (c_int - g.uh + call.pad) + 8 * q;
+    const unsigned int* __restrict__ xw = call.xw[o] + base;
+    f32x4b acc[kMaxTiles];
+#pragma unroll
+    for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4b{0.f, 0.f, 0.f, 0.f};
+    const bool idle = blockIdx.z * 256 + wave * 16 >= batch;        // whole M-tile beyond the batch: only helps staging
+    for (int b0 = 0; b0 < g.n_blk; b0 += kBank2Chunk) {             // the phase table in chunks of <= 9 blocks (92 KB of LDS)
+        const int nbc = g.n_blk - b0 < kBank2Chunk ? g.n_blk - b0 : kBank2Chunk;
+        // every A fragment of the chunk is requested before anything else: 2 x 16 B per lane and block, all in flight together
+        // (a wave that prefetches one block ahead keeps 2 KB in flight -- the kernel then runs at the HBM latency, not bandwidth)
+        u32x4u xa[kBank2Chunk], xb[kBank2Chunk];
+#pragma unroll
+        for (int bi = 0; bi < kBank2Chunk; ++bi) {
+            const int blk = b0 + (bi < nbc ? bi : nbc - 1);
+            xa[bi] = *reinterpret_cast<const u32x4u*>(xw + 32 * blk);
+            xb[bi] = *reinterpret_cast<const u32x4u*>(xw + 32 * blk + 4);
+        }
+        if (b0) __syncthreads();
+        {
+            const uint4* src = w + static_cast<long long>(b0) * (kMaxTiles * 2 * 64);
+            const int total = nbc * kMaxTiles * 2 * 64;
+            for (int i = threadIdx.x; i < total; i += 1024) ldsW[i] = src[i];
+        }
+        __syncthreads();
+        if (idle) continue;
+#pragma unroll
+        for (int bi = 0; bi < kBank2Chunk; ++bi) {
+            if (bi < nbc) {
+                const int blk = b0 + bi;
+                // de-interleave 8 words into the hi and the lo operand (v_perm_b32: bytes 0-3 index the 2nd source, 4-7 the 1st)
+                const u32x4u va = xa[bi], vb = xb[bi];
+                const u32x4u hv = {__builtin_amdgcn_perm(va[1], va[0], 0x07060302), __builtin_amdgcn_perm(va[3], va[2], 0x07060302),
+                                   __builtin_amdgcn_perm(vb[1], vb[0], 0x07060302), __builtin_amdgcn_perm(vb[3], vb[2], 0x07060302)};
+                const u32x4u lv = {__builtin_amdgcn_perm(va[1], va[0], 0x05040100), __builtin_amdgcn_perm(va[3], va[2], 0x05040100),
+                                   __builtin_amdgcn_perm(vb[1], vb[0], 0x05040100), __builtin_amdgcn_perm(vb[3], vb[2], 0x05040100)};
+                const bf16x8 ch = __builtin_bit_cast(bf16x8, hv), cl = __builtin_bit_cast(bf16x8, lv);
+#pragma unroll
+                for (int j = 0; j < kMaxTiles; ++j) {
+                    if (j < g.n_tiles && blk >= g.blk_lo[j] && blk <= g.blk_hi[j]) {
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, ldsW[((bi * kMaxTiles + j) * 2 + 0) * 64 + lane]);
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, ldsW[((bi * kMaxTiles + j) * 2 + 1) * 64 + lane]);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch, bh, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cl, bh, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch, bl, acc[j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (idle) return;
+#pragma unroll
+    for (int j = 0; j < kMaxTiles; ++j) {
+        const int b = kTileBins * j + (r16 >> 1);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float v2 = acc[j][reg] * acc[j][reg];
+            const float m2 = v2 + __shfl_xor(v2, 1);
+            const int cl2 = blockIdx.z * 256 + wave * 16 + 4 * q + reg;
+            // KeyDataset.py:497-499 is literally log(1 + |C|); v_sqrt_f32 / v_log_f32 (1 ulp class) instead of libm's log1pf
+            if ((r16 & 1) == 0 && j < g.n_tiles && b < g.n_bins && cl2 < batch)
+                out[cl2 * out_clip_stride + static_cast<long long>(t) * n_bins_total + g.k0 + b] = __logf(1.f + __builtin_amdgcn_sqrtf(m2));
+        }
+    }
+}
+
 // [clip][frame][bin] scratch -> [clip][bin][out_frames] (the reference layout), zero-filling frames >= T
 // (KeyDataset.py:245 padding).  32x32 LDS tile transpose: coalesced on both sides.
 __global__ __launch_bounds__(256) void cqt_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int T,
@@ -469,6 +636,11 @@ int pad_of(const ake_cqt_plan* p) { return p->half_len + 1; }   // Hh % 4 == 3  
 int len_store(const ake_cqt_plan* p, int o, int64_t n) {   // floats stored per clip for octave o >= 1 (multiple of 4)
     const int64_t l = (n + (1ll << o) - 1) >> o;
     return (static_cast<int>(l) + 2 * pad_of(p) + 3) / 4 * 4;
+}
+
+int plane_len(const ake_cqt_plan* p, int l, int64_t n) {   // split words per clip of level l (multiple of 8)
+    const int64_t ln = (n + (1ll << l) - 1) >> l;
+    return (static_cast<int>(ln) + 2 * pad_of(p) + 2 * p->ppad + 8 + 7) / 8 * 8;
 }
 
 }  // namespace
@@ -601,6 +773,95 @@ int ake_cqt_plan_create(const ake_cqt_config* cfg_in, ake_cqt_plan** out) {
         ake_cqt_plan_destroy(p);
         return AKE_ERR_HIP;
     }
+    // ---- engine ----
+    {
+        int want = cfg.engine;
+        if (const char* e = std::getenv("AKE_CQT_ENGINE")) want = std::atoi(e);
+        const bool can_fuse = p->half_len <= 23;
+        const bool can_bf16 = can_fuse && n_oct >= 2 && n_oct - 1 <= kCascMax;
+        if (want == 3 && !can_bf16) { ake::set_error("cqt: engine 3 needs 2..%d octaves and decim_half_len <= 23", kCascMax + 1); ake_cqt_plan_destroy(p); return AKE_ERR_UNSUPPORTED; }
+        if (want == 2 && !can_fuse) { ake::set_error("cqt: engine 2 needs decim_half_len <= 23"); ake_cqt_plan_destroy(p); return AKE_ERR_UNSUPPORTED; }
+        p->engine = (want >= 1 && want <= 3) ? want : (can_bf16 ? 3 : (can_fuse ? 2 : 1));
+        p->cfg.engine = p->engine;
+    }
+    if (p->engine == 3) {
+        auto bf16_rne = [](float v) -> uint16_t {
+            uint32_t u;
+            std::memcpy(&u, &v, 4);
+            u += 0x7FFFu + ((u >> 16) & 1u);
+            return static_cast<uint16_t>(u >> 16);
+        };
+        auto bf16_f32 = [](uint16_t h) { uint32_t u = static_cast<uint32_t>(h) << 16; float f; std::memcpy(&f, &u, 4); return f; };
+        std::vector<uint16_t> t2;
+        int ppad = 0;
+        for (int o = 0; o < n_oct; ++o) {
+            const OctDesc& g1 = p->octs[o];
+            const int dec = 1 << o;
+            const int sh = std::min(p->hop_twos, o);
+            const int nph = dec >> sh;
+            OctDesc2 g;
+            std::memset(&g, 0, sizeof(g));
+            g.k0 = g1.k0; g.n_bins = g1.n_bins; g.n_tiles = g1.n_tiles; g.uh = g1.uh;
+            g.n_blk = (2 * g.uh + 1 + 31) / 32;
+            auto uh_of = [&](int k) { return static_cast<int>(std::ceil(-std::floor(-len[k] / 2.0) / dec)) + 1; };
+            for (int j = 0; j < g.n_tiles; ++j) {
+                const int uh_j = uh_of(g.k0 + kTileBins * j);
+                g.blk_lo[j] = (g.uh - uh_j) / 32;
+                g.blk_hi[j] = std::min(g.n_blk - 1, (g.uh + uh_j) / 32);
+            }
+            ppad = std::max(ppad, std::max(g.uh, 32 * g.n_blk - g.uh));
+            const size_t per_phase = static_cast<size_t>(g.n_blk) * kMaxTiles * 2 * 64 * 8;      // uint16 entries
+            g.phase_stride = static_cast<long long>(per_phase / 8);
+            g.table_off = static_cast<long long>(t2.size() / 8);
+            t2.resize(t2.size() + static_cast<size_t>(nph) * per_phase, 0);
+            for (int pi = 0; pi < nph; ++pi) {
+                const double ph = static_cast<double>(pi << sh);
+                uint16_t* dst = t2.data() + static_cast<size_t>(g.table_off) * 8 + static_cast<size_t>(pi) * per_phase;
+                for (int b = 0; b < bpo; ++b) {
+                    const int k = g.k0 + b;
+                    const int j = b / kTileBins;
+                    const double lo = std::floor(-len[k] / 2.0);
+                    const double L = std::floor(len[k] / 2.0) - lo;
+                    const double scale = dec * std::sqrt(len[k]) / (L / 2.0) / cascade_gain(freq[k], o);
+                    for (int tap = 0; tap < 32 * g.n_blk; ++tap) {
+                        const int u = tap - g.uh;
+                        const double pos = static_cast<double>(dec) * u - ph;
+                        if (!(pos >= lo && pos <= lo + L)) continue;
+                        const double win = 0.5 - 0.5 * std::cos(2.0 * M_PI * (pos - lo) / L);
+                        const double arg = 2.0 * M_PI * freq[k] * pos / sr;
+                        const int blk = tap / 32, qq = (tap % 32) / 8, e = tap % 8;      // MFMA k index 8*qq + e
+                        const float vals[2] = {static_cast<float>(scale * win * std::cos(arg)), static_cast<float>(-scale * win * std::sin(arg))};
+                        for (int ri = 0; ri < 2; ++ri) {
+                            const int lane_i = qq * 16 + 2 * (b % kTileBins) + ri;
+                            const uint16_t hi = bf16_rne(vals[ri]);
+                            const uint16_t lo16 = bf16_rne(vals[ri] - bf16_f32(hi));
+                            const size_t f = ((static_cast<size_t>(blk) * kMaxTiles + j) * 2) * 64;
+                            dst[(f + lane_i) * 8 + e] = hi;
+                            dst[(f + 64 + lane_i) * 8 + e] = lo16;
+                        }
+                    }
+                }
+            }
+            p->octs2.push_back(g);
+            p->bank2_lds = std::max(p->bank2_lds, static_cast<size_t>(std::min(g.n_blk, kBank2Chunk)) * kMaxTiles * 2 * 64 * 16);
+        }
+        p->ppad = (ppad + 8 + 7) / 8 * 8;
+        const char* what = "hipMalloc(table)";
+        hipError_t e2 = hipMalloc(&p->table2_dev, t2.size() * sizeof(uint16_t));
+        if (e2 == hipSuccess) { what = "hipMalloc(octs)"; e2 = hipMalloc(&p->octs2_dev, p->octs2.size() * sizeof(OctDesc2)); }
+        if (e2 == hipSuccess) { what = "hipMemcpy(table)"; e2 = hipMemcpy(p->table2_dev, t2.data(), t2.size() * sizeof(uint16_t), hipMemcpyHostToDevice); }
+        if (e2 == hipSuccess) { what = "hipMemcpy(octs)"; e2 = hipMemcpy(p->octs2_dev, p->octs2.data(), p->octs2.size() * sizeof(OctDesc2), hipMemcpyHostToDevice); }
+        if (e2 == hipSuccess) {
+            what = "hipFuncSetAttribute(max dynamic LDS)";
+            e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(cqt_bank_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(p->bank2_lds));
+        }
+        if (e2 != hipSuccess) {
+            ake::set_error("cqt plan (bf16 tables, %zu B of LDS per workgroup): %s failed: %s", p->bank2_lds, what, hipGetErrorString(e2));
+            ake_cqt_plan_destroy(p);
+            return AKE_ERR_HIP;
+        }
+    }
     *out = p;
     return AKE_OK;
 }
@@ -609,6 +870,8 @@ void ake_cqt_plan_destroy(ake_cqt_plan* p) {
     if (!p) return;
     if (p->table_dev) (void)hipFree(p->table_dev);
     if (p->octs_dev) (void)hipFree(p->octs_dev);
+    if (p->table2_dev) (void)hipFree(p->table2_dev);
+    if (p->octs2_dev) (void)hipFree(p->octs2_dev);
     delete p;
 }
 
@@ -622,7 +885,11 @@ int64_t ake_cqt_num_frames(const ake_cqt_plan* p, int64_t n_samples) {
 size_t ake_cqt_workspace_bytes(const ake_cqt_plan* p, int batch, int64_t n_samples) {
     if (!p || batch <= 0 || n_samples <= 0) return 0;
     ake::Carver c(nullptr, 0);
-    for (int o = 1; o < p->n_oct; ++o) c.take<float>(static_cast<size_t>(batch) * len_store(p, o, n_samples));
+    if (p->engine == 3) {
+        for (int l = 0; l < p->n_oct; ++l) c.take<unsigned int>(static_cast<size_t>(batch) * plane_len(p, l, n_samples));   // split-bf16 level signals
+    } else {
+        for (int o = 1; o < p->n_oct; ++o) c.take<float>(static_cast<size_t>(batch) * len_store(p, o, n_samples));
+    }
     c.take<float>(static_cast<size_t>(batch) * (1 + n_samples / p->cfg.hop_length) * p->cfg.n_bins);   // [clip][frame][bin] scratch
     return ake::align_up(c.off, 256);
 }
@@ -637,37 +904,14 @@ int ake_cqt_logmag_f32(const ake_cqt_plan* p, const float* audio, int batch, int
     AKE_REQUIRE(ws_bytes >= ake_cqt_workspace_bytes(p, batch, n) && (workspace || p->n_oct == 1), AKE_ERR_WORKSPACE, "cqt: workspace too small");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
 
-    BankCall call;
-    std::memset(&call, 0, sizeof(call));
     ake::Carver c(workspace, ws_bytes);
-    call.x[0] = audio;
-    call.stride[0] = audio_stride;
-    call.lo[0] = 0;
-    call.count[0] = static_cast<int>(n);
-    for (int o = 1; o < p->n_oct; ++o) {
-        const int ls = len_store(p, o, n);
-        call.x[o] = c.take<float>(static_cast<size_t>(batch) * ls);
-        call.stride[o] = ls;
-        call.lo[o] = -pad_of(p);
-        call.count[o] = ls;
-    }
-    static const bool legacy = std::getenv("AKE_CQT_LEGACY") != nullptr;     // per-stage kernels only (bisecting / tests)
-    int fused = (legacy || p->half_len > 23) ? 0 : std::min(p->n_oct - 1, kCascMax);
-    if (fused > 0) {
-        constexpr int C = 4096, NT = 256;
-        CascArgs a;
+    float* scratch = nullptr;
+    constexpr int C = 4096, NT = 256;
+    auto fill_cascade = [&](CascArgs& a, int fused) {
         std::memset(&a, 0, sizeof(a));
         a.x = audio; a.x_stride = audio_stride; a.n = static_cast<int>(n);
         a.pad = pad_of(p); a.hop = p->cfg.hop_length; a.n_stage = fused; a.taps = p->taps;
-        for (int l = 1; l <= fused; ++l) {
-            a.y[l] = const_cast<float*>(call.x[l]);
-            a.y_stride[l] = call.stride[l];
-            a.y_count[l] = call.count[l];
-            // the bank reads, per frame, taps [c - uh, c - uh + 16 * n_blocks) of level l around the frame centre c; a later
-            // per-stage kernel (more than kCascMax stages) needs its input level everywhere
-            const long long need = static_cast<long long>(p->octs[l].uh + 24) << l;
-            a.need[l] = (2 * need >= a.hop || (l == fused && fused < p->n_oct - 1)) ? -1 : static_cast<int>(need);
-        }
+        for (int l = 1; l <= fused; ++l) a.y_count[l] = len_store(p, l, n);
         a.g0 = -512;
         const long long g1 = n + static_cast<long long>(25 + kLagHost[fused]) * (1ll << fused) + 512;
         a.ticks_total = static_cast<int>((g1 - a.g0 + C - 1) / C);
@@ -675,26 +919,78 @@ int ake_cqt_logmag_f32(const ake_cqt_plan* p, const float* audio, int batch, int
         const int segs = std::max(1, std::min(a.ticks_total, segs_env > 0 ? segs_env : 4));
         a.ticks_per_seg = (a.ticks_total + segs - 1) / segs;
         a.warm = 3;                                         // >= 64 * 2^7 / C ticks of history before the first owned tick
+    };
+    auto launch_cascade = [&](const CascArgs& a) {
         dim3 grid((a.ticks_total + a.ticks_per_seg - 1) / a.ticks_per_seg, batch);
         ake::ProfScope ps("cqt_cascade_kernel", stream);
         if (p->half_len == 15) hipLaunchKernelGGL((cqt_cascade_kernel<8, C, NT>), grid, dim3(NT), 0, stream, a);
         else hipLaunchKernelGGL((cqt_cascade_kernel<12, C, NT>), grid, dim3(NT), 0, stream, a);
-    }
-    for (int o = fused + 1; o < p->n_oct; ++o) {
-        const int ls = call.count[o];
-        float* y = const_cast<float*>(call.x[o]);
-        dim3 grid((ls + kDecimOutPerBlock - 1) / kDecimOutPerBlock, batch);
-        ake::ProfScope ps("cqt_decimate_kernel", stream);
-        const int in_pad = -call.lo[o - 1];
+    };
+    if (p->engine == 3) {
+        BankCall2 call2;
+        std::memset(&call2, 0, sizeof(call2));
+        CascArgs a;
+        fill_cascade(a, p->n_oct - 1);
+        a.ppad = p->ppad;
+        call2.pad = p->ppad;
+        for (int l = 0; l < p->n_oct; ++l) {
+            const int pl = plane_len(p, l, n);
+            a.ph[l] = c.take<unsigned int>(static_cast<size_t>(batch) * pl);
+            a.p_stride[l] = pl; a.p_count[l] = pl;
+            call2.xw[l] = a.ph[l]; call2.stride[l] = pl;
+            // taps [c - uh, c - uh + 32 * n_blk) of level l around every frame centre c
+            const OctDesc2& g = p->octs2[l];
+            const long long need = static_cast<long long>(std::max(g.uh, 32 * g.n_blk - g.uh) + 8) << l;
+            a.need[l] = 2 * need >= a.hop ? -1 : static_cast<int>(need);
+        }
+        launch_cascade(a);
+        scratch = c.take<float>(static_cast<size_t>(batch) * T * p->cfg.n_bins);
+        dim3 grid(static_cast<unsigned>(T), p->n_oct, (batch + 255) / 256);
+        ake::ProfScope ps("cqt_bank_bf16_kernel", stream);
+        hipLaunchKernelGGL(cqt_bank_bf16_kernel, grid, dim3(1024), p->bank2_lds, stream, call2, p->octs2_dev, p->table2_dev, batch,
+                           p->cfg.hop_length, p->hop_twos, scratch, static_cast<long long>(T) * p->cfg.n_bins, p->cfg.n_bins);
+    } else {
+        BankCall call;
+        std::memset(&call, 0, sizeof(call));
+        call.x[0] = audio;
+        call.stride[0] = audio_stride;
+        call.lo[0] = 0;
+        call.count[0] = static_cast<int>(n);
+        for (int o = 1; o < p->n_oct; ++o) {
+            const int ls = len_store(p, o, n);
+            call.x[o] = c.take<float>(static_cast<size_t>(batch) * ls);
+            call.stride[o] = ls;
+            call.lo[o] = -pad_of(p);
+            call.count[o] = ls;
+        }
+        const int fused = p->engine == 2 ? std::min(p->n_oct - 1, kCascMax) : 0;
+        if (fused > 0) {
+            CascArgs a;
+            fill_cascade(a, fused);
+            for (int l = 1; l <= fused; ++l) {
+                a.y[l] = const_cast<float*>(call.x[l]);
+                a.y_stride[l] = call.stride[l];
+                // the bank reads, per frame, taps [c - uh, c - uh + 16 * n_blocks) of level l around the frame centre c; a later
+                // per-stage kernel (more than kCascMax stages) needs its input level everywhere
+                const long long need = static_cast<long long>(p->octs[l].uh + 24) << l;
+                a.need[l] = (2 * need >= a.hop || (l == fused && fused < p->n_oct - 1)) ? -1 : static_cast<int>(need);
+            }
+            launch_cascade(a);
+        }
+        for (int o = fused + 1; o < p->n_oct; ++o) {
+            const int ls = call.count[o];
+            float* y = const_cast<float*>(call.x[o]);
+            dim3 grid((ls + kDecimOutPerBlock - 1) / kDecimOutPerBlock, batch);
+            ake::ProfScope ps("cqt_decimate_kernel", stream);
+            const int in_pad = -call.lo[o - 1];
 #define AKE_DECIM(N_) hipLaunchKernelGGL((cqt_decimate_kernel<N_>), grid, dim3(kDecimThreads), 0, stream, call.x[o - 1], \
                                          call.stride[o - 1], in_pad, call.count[o - 1], y, static_cast<long long>(ls), pad_of(p), ls, p->taps)
-        if (p->half_len == 15) AKE_DECIM(8);
-        else if (p->half_len == 23) AKE_DECIM(12);
-        else AKE_DECIM(16);
+            if (p->half_len == 15) AKE_DECIM(8);
+            else if (p->half_len == 23) AKE_DECIM(12);
+            else AKE_DECIM(16);
 #undef AKE_DECIM
-    }
-    float* scratch = c.take<float>(static_cast<size_t>(batch) * T * p->cfg.n_bins);
-    {
+        }
+        scratch = c.take<float>(static_cast<size_t>(batch) * T * p->cfg.n_bins);
         dim3 grid(static_cast<unsigned>(T), p->n_oct, (batch + 63) / 64);
         ake::ProfScope ps("cqt_bank_kernel", stream);
         hipLaunchKernelGGL(cqt_bank_kernel, grid, dim3(256), 0, stream, call, p->octs_dev, p->table_dev, batch,

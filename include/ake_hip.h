@@ -57,6 +57,9 @@ typedef struct ake_cqt_config {
     int q_mode;           /* 0: Q = (r^2+1)/(r^2-1) (librosa >= 0.10); 1: Q = 1/(r-1) (<= 0.9) */
     int decim_half_len;   /* half length of the half-band decimator; <=0 selects 23 (47 taps) */
     double decim_beta;    /* Kaiser beta of the decimator; <=0 selects 8.0 */
+    int engine;           /* 0: fastest available; 1: one kernel per decimation stage + f32 filter bank (first version, kept as
+                             the in-library cross-check); 2: fused decimator cascade + f32 bank (bit-identical to 1);
+                             3: fused cascade writing split-bf16 level signals + bf16x3 MFMA bank (needs <= 8 octaves) */
 } ake_cqt_config;
 
 /* hop = round(sample_rate / frames_per_second) (KeyDataset.py:485), n_bins = 36 * octaves. */
