@@ -107,6 +107,45 @@ struct ake_cqt_plan {
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+// 4 consecutive outputs of the half-band decimator from the de-interleaved input: P[i] = (odd sample 2i, 2i+1 of the window),
+// i.e. O[j] = P[j/2][j%2] is the odd-sample stream starting NODD samples before output 0's centre; Cc = the 4 centre samples.
+//   r[u] = h0*Cc[u] + sum_q hodd[q] * (O[u+NODD-1-q] + O[u+NODD+q])
+// written for v_pk_add_f32 / v_pk_fma_f32: two taps (q, q+1) per instruction.  For even u the pairs (q even) are
+// (swap(P[(u+NODD-2-q)/2]) + P[(u+NODD+q)/2]) * (hodd[q], hodd[q+1]); for odd u the same with q odd, plus the taps q = 0 and
+// q = NODD-1 on their own.  Both decimator kernels use this one function, so their outputs are bit-identical.
+template <int NODD>
+__device__ __forceinline__ void halfband4(const f32x2v (&P)[NODD + 2], const float (&Cc)[4], const DecimTaps& taps, float (&r)[4]) {
+    static_assert(NODD % 2 == 0, "tap pairs");
+#pragma unroll
+    for (int u = 0; u < 4; u += 2) {                                  // even outputs
+        f32x2v acc = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < NODD; q += 2) {
+            const f32x2v lo = P[(u + NODD - 2 - q) / 2], hi = P[(u + NODD + q) / 2];
+            const f32x2v sum = __builtin_shufflevector(lo, lo, 1, 0) + hi;
+            const f32x2v h = {taps.hodd[q], taps.hodd[q + 1]};
+            acc = __builtin_elementwise_fma(h, sum, acc);
+        }
+        r[u] = fmaf(taps.h0, Cc[u], acc[0] + acc[1]);
+    }
+#pragma unroll
+    for (int u = 1; u < 4; u += 2) {                                  // odd outputs
+        f32x2v acc = {0.f, 0.f};
+#pragma unroll
+        for (int q = 1; q < NODD - 1; q += 2) {
+            const f32x2v lo = P[(u + NODD - 2 - q) / 2], hi = P[(u + NODD + q) / 2];
+            const f32x2v sum = __builtin_shufflevector(lo, lo, 1, 0) + hi;
+            const f32x2v h = {taps.hodd[q], taps.hodd[q + 1]};
+            acc = __builtin_elementwise_fma(h, sum, acc);
+        }
+        float tail = taps.hodd[0] * (P[(u + NODD - 1) / 2][(u + NODD - 1) % 2] + P[(u + NODD) / 2][(u + NODD) % 2]);
+        tail = fmaf(taps.hodd[NODD - 1], P[u / 2][u % 2] + P[(u + 2 * NODD - 1) / 2][(u + 2 * NODD - 1) % 2], tail);
+        r[u] = fmaf(taps.h0, Cc[u], (acc[0] + acc[1]) + tail);
+    }
+}
+
 // y_out[m] = h0*y[2m] + sum_{j odd} h[j]*(y[2m-j] + y[2m+j]);  input sample s lives at in[s + in_pad], output sample m
 // at out[m + out_pad].  One workgroup = 512 consecutive output indices of one clip.  Requires Hh % 4 == 3 and
 // out_pad = Hh + 1 (checked by the host): then the first input the tile needs sits at local position 1 of a 16-byte
@@ -144,25 +183,20 @@ __global__ __launch_bounds__(kDecimThreads) void cqt_decimate_kernel(
     // outputs 4*tid .. 4*tid+3 of the tile: centre of output r at even slot 4*tid + r + NODD, taps at odd slots 4*tid + r + i
     const int tid = threadIdx.x;
     if (o0 + 4 * tid >= out_count) return;
-    float O[2 * NODD + 4], C[4];
+    f32x2v P[NODD + 2];
+    float C[4];
     {
         const float4* po = reinterpret_cast<const float4*>(od + 4 * tid);
 #pragma unroll
         for (int i = 0; i < (2 * NODD + 4) / 4; ++i) {
             const float4 t = po[i];
-            O[4 * i] = t.x; O[4 * i + 1] = t.y; O[4 * i + 2] = t.z; O[4 * i + 3] = t.w;
+            P[2 * i] = f32x2v{t.x, t.y}; P[2 * i + 1] = f32x2v{t.z, t.w};
         }
         const float4 c = *reinterpret_cast<const float4*>(ev + 4 * tid + NODD);
         C[0] = c.x; C[1] = c.y; C[2] = c.z; C[3] = c.w;
     }
     float r[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float acc = taps.h0 * C[k];
-#pragma unroll
-        for (int q = 0; q < NODD; ++q) acc = fmaf(taps.hodd[q], O[k + NODD - 1 - q] + O[k + NODD + q], acc);
-        r[k] = acc;
-    }
+    halfband4<NODD>(P, C, taps, r);
     *reinterpret_cast<float4*>(out + clip * out_stride + o0 + 4 * tid) = make_float4(r[0], r[1], r[2], r[3]);
 }
 
@@ -246,25 +280,20 @@ __device__ __forceinline__ void cascade_level(const CascArgs& a, float* lds, int
     for (int j0 = 0; j0 < chunk_out / 4; j0 += NT) {
         const int j = j0 + tid;
         if (chunk_out / 4 - j0 < NT && j >= chunk_out / 4) break;
-        float O[2 * NODD + 4], Cc[4];
+        f32x2v P[NODD + 2];
+        float Cc[4];
         const float* po = od + kCascHist + 4 * j - E - NODD;
 #pragma unroll
         for (int i = 0; i < (2 * NODD + 4) / 4; ++i) {
             const float4 t = *reinterpret_cast<const float4*>(po + 4 * i);
-            O[4 * i] = t.x; O[4 * i + 1] = t.y; O[4 * i + 2] = t.z; O[4 * i + 3] = t.w;
+            P[2 * i] = f32x2v{t.x, t.y}; P[2 * i + 1] = f32x2v{t.z, t.w};
         }
         {
             const float4 c = *reinterpret_cast<const float4*>(ev + kCascHist + 4 * j - E);
             Cc[0] = c.x; Cc[1] = c.y; Cc[2] = c.z; Cc[3] = c.w;
         }
         float r[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float acc = a.taps.h0 * Cc[u];
-#pragma unroll
-            for (int q = 0; q < NODD; ++q) acc = fmaf(a.taps.hodd[q], O[u + NODD - 1 - q] + O[u + NODD + q], acc);
-            r[u] = acc;
-        }
+        halfband4<NODD>(P, Cc, a.taps, r);
         if (L + 1 < kCascMax && L + 1 < a.n_stage) {
             float* evn = lds + Lay::ev(L + 1 < kCascMax ? L + 1 : 0) + kCascHist;
             float* odn = lds + Lay::od(L + 1 < kCascMax ? L + 1 : 0) + kCascHist;

@@ -205,7 +205,7 @@ def main():
     launches_per_step = p2p_n / args.steps if args.steps else 0
     p2p_flops = 2.0 * P2P_MACS_PER_CLIP * B * args.steps              # all p2p launches of this rank
     achieved = p2p_flops / (p2p_ms * 1e-3) / 1e12 if p2p_ms > 0 else None
-    cqt_ms = sum(prof_all.get(k, (0.0, 0))[0] for k in ("cqt_cascade_kernel", "cqt_decimate_kernel", "cqt_bank_kernel", "cqt_transpose_kernel"))
+    cqt_ms = sum(prof_all.get(k, (0.0, 0))[0] for k in prof_all if k.startswith("cqt_"))
     cqt_gbs = CQT_BYTES_PER_CLIP * B * args.steps / (cqt_ms * 1e-3) / 1e9 if cqt_ms > 0 else None
     kernel_ms = {k: round(v[0] / args.steps, 4) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}
     line = {
@@ -222,7 +222,7 @@ def main():
                      "frac": round(achieved / PEAK_FP32_TFLOPS, 4) if achieved else None, "traffic": None,
                      "avg_launch_ms": round(p2p_ms / p2p_n, 4) if p2p_n else None, "launches_per_step": launches_per_step,
                      "algorithmic_flops_per_clip": 2 * P2P_MACS_PER_CLIP},
-        "roofline_cqt": {"bound": "hbm", "kernels": "cqt_cascade_kernel (7 half-band stages fused) + cqt_bank_kernel + cqt_transpose_kernel", "achieved": round(cqt_gbs, 1) if cqt_gbs else None,
+        "roofline_cqt": {"bound": "hbm", "kernels": " + ".join(sorted(k for k in prof_all if k.startswith("cqt_"))), "achieved": round(cqt_gbs, 1) if cqt_gbs else None,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(cqt_gbs / PEAK_HBM_GBS, 4) if cqt_gbs else None,
                          "traffic": None, "algorithmic_bytes_per_clip": CQT_BYTES_PER_CLIP,
                          "stage_ms_per_step": round(cqt_ms / args.steps, 4)},
