@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void cqt_bank_kernel(
 // by 16 waves of one 16-clip M-tile each.  A operand: lane (row r = clip, q) holds taps 32*blk + 8q .. +7 of its clip =
 // two dword-aligned 16-byte loads of interleaved (hi, lo) words, de-interleaved with 8 v_perm_b32 (the signals are padded,
 // no bounds checks).
-constexpr int kBank2Chunk = 9;          // 32-tap blocks of the phase table resident in LDS at a time
+constexpr int kBank2Chunk = 5;          // 32-tap blocks of the phase table resident in LDS at a time (51 KB: two workgroups per CU)
 typedef unsigned int u32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4b __attribute__((ext_vector_type(4)));
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(1024) void cqt_bank_bf16_kernel(
 #pragma unroll
     for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4b{0.f, 0.f, 0.f, 0.f};
     const bool idle = blockIdx.z * 256 + wave * 16 >= batch;        // whole M-tile beyond the batch: only helps staging
-    for (int b0 = 0; b0 < g.n_blk; b0 += kBank2Chunk) {             // the phase table in chunks of <= 9 blocks (92 KB of LDS)
+    for (int b0 = 0; b0 < g.n_blk; b0 += kBank2Chunk) {             // the phase table in chunks of kBank2Chunk blocks
         const int nbc = g.n_blk - b0 < kBank2Chunk ? g.n_blk - b0 : kBank2Chunk;
         // every A fragment of the chunk is requested before anything else: 2 x 16 B per lane and block, all in flight together
         // (a wave that prefetches one block ahead keeps 2 KB in flight -- the kernel then runs at the HBM latency, not bandwidth)

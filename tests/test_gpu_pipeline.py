@@ -88,6 +88,7 @@ def test_kernel_timer_reports_the_launched_kernels(net):
     est(audio)
     res = ake_amd._lib.prof_results()
     ake_amd._lib.prof_enable("", False)
-    assert {"cqt_bank_kernel", "cqt_decimate_kernel", "conv_mfma_kernel/p2p", "conv_mfma_kernel/pc2pc", "head_pool_kernel"} <= set(res)
-    assert res["conv_mfma_kernel/p2p"][1] == 3 and res["cqt_decimate_kernel"][1] == 7
+    assert {"cqt_bank_bf16_kernel", "cqt_cascade_kernel", "cqt_transpose_kernel", "conv_mfma_kernel/p2p", "conv_mfma_kernel/pc2pc",
+            "head_pool_kernel"} <= set(res)
+    assert res["conv_mfma_kernel/p2p"][1] == 3 and res["cqt_cascade_kernel"][1] == 1       # 7 decimation stages, one launch
     assert all(ms > 0 for ms, _ in res.values())
