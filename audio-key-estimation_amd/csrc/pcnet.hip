@@ -279,17 +279,24 @@ bool choose_tile(bool fullrows, int cin, int H, int KH, int T_out, int TB, int K
     return true;
 }
 
-int launch_mfma(const PackedConv& pc, const MfmaArgs& a, int MT, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-#define AKE_MFMA(KU_, NT_) hipLaunchKernelGGL((conv_mfma_kernel<KU_, NT_, 3>), grid, block, lds, s, a); return AKE_OK
-    if (pc.ku == 8 && pc.nt == 1 && MT == 6) { hipLaunchKernelGGL((conv_mfma_kernel<8, 1, 6>), grid, block, lds, s, a); return AKE_OK; }
-    if (pc.ku == 8 && pc.nt == 1 && MT == 4) { hipLaunchKernelGGL((conv_mfma_kernel<8, 1, 4>), grid, block, lds, s, a); return AKE_OK; }
-    if (pc.ku == 8 && pc.nt == 1) { AKE_MFMA(8, 1); }
-    if (pc.ku == 8 && pc.nt == 2) { AKE_MFMA(8, 2); }
-    if (pc.ku == 12 && pc.nt == 1) { AKE_MFMA(12, 1); }
-    if (pc.ku == 24 && pc.nt == 1) { AKE_MFMA(24, 1); }
+template <bool TRAIN>
+int launch_mfma_t(const PackedConv& pc, const MfmaArgs& a, int MT, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+#define AKE_MFMA(KU_, NT_, MT_) hipLaunchKernelGGL((conv_mfma_kernel<KU_, NT_, MT_, TRAIN>), grid, block, lds, s, a); return AKE_OK
+    if (pc.ku == 8 && pc.nt == 1 && MT == 6) { AKE_MFMA(8, 1, 6); }
+    if (pc.ku == 8 && pc.nt == 1 && MT == 4) { AKE_MFMA(8, 1, 4); }
+    if (pc.ku == 8 && pc.nt == 1) { AKE_MFMA(8, 1, 3); }
+    if (pc.ku == 8 && pc.nt == 2) { AKE_MFMA(8, 2, 3); }
+    if (pc.ku == 12 && pc.nt == 1) { AKE_MFMA(12, 1, 3); }
+    if (pc.ku == 24 && pc.nt == 1) { AKE_MFMA(24, 1, 3); }
 #undef AKE_MFMA
     ake::set_error("conv: no MFMA kernel for KU=%d NT=%d", pc.ku, pc.nt);
     return AKE_ERR_UNSUPPORTED;
+}
+
+// inference launches carry none of the training-mode code (pending BatchNorm on load, statistics, accumulation)
+int launch_mfma(const PackedConv& pc, const MfmaArgs& a, int MT, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+    const bool train = a.c.in_affine || a.c.stats || a.c.accumulate;
+    return train ? launch_mfma_t<true>(pc, a, MT, grid, block, lds, s) : launch_mfma_t<false>(pc, a, MT, grid, block, lds, s);
 }
 
 struct Src {

@@ -273,7 +273,7 @@ struct MfmaArgs {
                           //    reduced through LDS
 };
 
-template <int KU, int NT, int MT>
+template <int KU, int NT, int MT, bool TRAIN = false>   // TRAIN: in_affine on load, statistics epilogue, accumulate (training fwd + data gradients)
 __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ConvArgs& a = ma.c;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
                     row += row < 0 ? a.H : 0;
                     row -= row >= a.H ? a.H : 0;
                     float asc = 1.f, ash = 0.f, ang = 1.f;                // BatchNorm + LeakyReLU of the producer, applied on load
-                    if (a.in_affine) { asc = a.in_affine[3 * cs]; ash = a.in_affine[3 * cs + 1]; ang = a.in_affine[3 * cs + 2]; }
+                    if (TRAIN && a.in_affine) { asc = a.in_affine[3 * cs]; ash = a.in_affine[3 * cs + 1]; ang = a.in_affine[3 * cs + 2]; }
                     const float* srow;
                     if (cs < a.c0) srow = s0 + (static_cast<long long>(cs) * a.H + row) * a.T_in;
                     else {
@@ -400,8 +400,12 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
                                 ok = ti >= 0 && ti < a.T_in;
                             }
                             if (ok) {
-                                float x = fmaf(srow[ti], asc, ash);
-                                v[u][h] = x > 0.f ? x : x * ang;          // zero padding stays zero: it pads the activation
+                                if (TRAIN) {
+                                    const float x = fmaf(srow[ti], asc, ash);
+                                    v[u][h] = x > 0.f ? x : x * ang;      // zero padding stays zero: it pads the activation
+                                } else {
+                                    v[u][h] = srow[ti];
+                                }
                             }
                         }
                     }
@@ -509,16 +513,16 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
                 const int tl = TB * j + tau;
                 if (ok_m && co < a.cout && tl < tt_here) {
                     float v = acc[mt][nt][reg] + a.bias[co];
-                    if (a.stats) { st1[nt] += v; st2[nt] = fmaf(v, v, st2[nt]); }
+                    if (TRAIN && a.stats) { st1[nt] += v; st2[nt] = fmaf(v, v, st2[nt]); }
                     if (a.lrelu) v = v > 0.f ? v : v * kSlope;
                     float* dp = d + ((a.dst_coff + co) * a.H_out + (y0 + r)) * row_elems + tl;
-                    *dp = a.accumulate ? *dp + v : v;
+                    *dp = (TRAIN && a.accumulate) ? *dp + v : v;
                 }
             }
             if (++j == J) { j = 0; ++r; }
         }
     }
-    if (a.stats) {   // per-channel batch statistics: lanes of one channel = TB adjacent columns x 4 row groups
+    if (TRAIN && a.stats) {   // per-channel batch statistics: lanes of one channel = TB adjacent columns x 4 row groups
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             float s1 = st1[nt], s2 = st2[nt];

@@ -46,6 +46,18 @@ PEAK_FP32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 counter passes (tools/pmc_traffic.py; FETCH_SIZE x2 on gfx950, see
+    DESIGN.md "Measurement").  bench.py cannot collect PMC counters itself (they need the profiler around the process), so the
+    line carries the numbers of the newest profile in profiles/ that was taken with this same command and batch size."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, {}
+    with open(files[-1]) as f:
+        return os.path.basename(files[-1]), json.load(f)["kernels"]
+
+
 def load_fixture_weights():
     gold = np.load(os.path.join(REPO, "tests", "golden", "pcnet_default.npz"))
     return {k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("sd/")}
@@ -208,6 +220,12 @@ def main():
     cqt_ms = sum(prof_all.get(k, (0.0, 0))[0] for k in prof_all if k.startswith("cqt_"))
     cqt_gbs = CQT_BYTES_PER_CLIP * B * args.steps / (cqt_ms * 1e-3) / 1e9 if cqt_ms > 0 else None
     kernel_ms = {k: round(v[0] / args.steps, 4) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}
+    traffic_src, traffic = pmc_traffic()
+    p2p_traffic = cqt_traffic = None
+    if B == 256 and traffic:
+        p2p_rows = [v for k, v in traffic.items() if k.startswith("conv_mfma_kernel<8, 1, 3>") and v["hbm_bytes"] > 2e8]
+        p2p_traffic = p2p_rows[0]["hbm_bytes"] if p2p_rows else None
+        cqt_traffic = sum(v["hbm_bytes"] for k, v in traffic.items() if k.startswith("cqt_")) or None
     line = {
         "metric": "clips/s (15 s @ 22.05 kHz), HIP CQT + PitchClassNet forward",
         "value": round(value, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -219,12 +237,14 @@ def main():
                    "parallelism": f"clip-sharded x{world}, no data-path collective"},
         "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel<7,8,1,3> (pitch conv 7x7 circular as f32-MFMA implicit GEMM, x3 per chunk)",
                      "achieved": round(achieved, 3) if achieved else None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_FP32_TFLOPS, 4) if achieved else None, "traffic": None,
+                     "frac": round(achieved / PEAK_FP32_TFLOPS, 4) if achieved else None, "traffic": p2p_traffic,
+                     "traffic_source": f"profiles/{traffic_src}: mean HBM bytes per launch of the 3 pitch convolutions, rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE" if p2p_traffic else None,
+                     "algorithmic_bytes_per_launch": B * (8 + 8) * P * T_FRAMES * 4,
                      "avg_launch_ms": round(p2p_ms / p2p_n, 4) if p2p_n else None, "launches_per_step": launches_per_step,
                      "algorithmic_flops_per_clip": 2 * P2P_MACS_PER_CLIP},
         "roofline_cqt": {"bound": "hbm", "kernels": " + ".join(sorted(k for k in prof_all if k.startswith("cqt_"))), "achieved": round(cqt_gbs, 1) if cqt_gbs else None,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(cqt_gbs / PEAK_HBM_GBS, 4) if cqt_gbs else None,
-                         "traffic": None, "algorithmic_bytes_per_clip": CQT_BYTES_PER_CLIP,
+                         "traffic": cqt_traffic, "algorithmic_bytes_per_step": CQT_BYTES_PER_CLIP * B, "algorithmic_bytes_per_clip": CQT_BYTES_PER_CLIP,
                          "stage_ms_per_step": round(cqt_ms / args.steps, 4)},
         "kernel_ms_per_step": kernel_ms,
         "net_fp32_frac_of_peak": round(2.0 * NET_MACS_PER_CLIP * value / world / (PEAK_FP32_TFLOPS * 1e12), 4),

@@ -13,7 +13,7 @@ def main(stats_csv, bench_log, out_md):
     with open(stats_csv) as f:
         for r in csv.DictReader(f):
             n = r["Name"]
-            if "ake_k::" in n or n.startswith("cqt_") or "fill_i64" in n:
+            if "ake_k::" in n or "cqt_" in n.split("(")[0] or "fill_i64" in n or "adam_step" in n:
                 short = n.replace("void ", "").replace("ake_k::", "").split("(")[0]
                 rows.append((short, int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
                              float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
