@@ -264,7 +264,7 @@ struct CascLayout {
     static constexpr int total = 2 * (C - (C >> kCascMax)) + 2 * kCascMax * kCascHist;
 };
 
-template <int NODD, int C, int NT, int L>
+template <int NODD, int C, int NT, int L, bool SPLIT>
 __device__ __forceinline__ void cascade_level(const CascArgs& a, float* lds, int tid, int clip, int k, bool owned) {
     using Lay = CascLayout<C>;
     constexpr int chunk_out = C >> (L + 1);                          // outputs of level L+1 per tick
@@ -308,8 +308,8 @@ __device__ __forceinline__ void cascade_level(const CascArgs& a, float* lds, int
                 store = fabsf(pos - rintf(pos * inv_hop) * hopf) <= static_cast<float>(need);
             }
             if (store) {
-                if (a.y[L + 1]) *reinterpret_cast<float4*>(yrow + m0) = make_float4(r[0], r[1], r[2], r[3]);
-                if (a.ph[L + 1]) store_split4(a.ph[L + 1], clip * a.p_stride[L + 1] + m0 + a.ppad, r[0], r[1], r[2], r[3]);
+                if (!SPLIT) *reinterpret_cast<float4*>(yrow + m0) = make_float4(r[0], r[1], r[2], r[3]);
+                else store_split4(a.ph[L + 1], clip * a.p_stride[L + 1] + m0 + a.ppad, r[0], r[1], r[2], r[3]);
             }
         }
     }
@@ -327,7 +327,7 @@ __device__ __forceinline__ void cascade_level(const CascArgs& a, float* lds, int
     }
 }
 
-template <int NODD, int C, int NT>
+template <int NODD, int C, int NT, bool SPLIT>
 __global__ __launch_bounds__(NT) void cqt_cascade_kernel(CascArgs a) {
     static_assert(C % 512 == 0 && C >= 1024 && (C / 4) % NT == 0, "chunk");
     using Lay = CascLayout<C>;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(NT) void cqt_cascade_kernel(CascArgs a) {
         }
     };
     fetch(k_start);
-    if (a.ph[0] || a.ph[1]) {   // zero the pads of the split signals outside the produced range [-pad, y_count - pad) (first / last segment)
+    if (SPLIT) {   // zero the pads of the split signals outside the produced range [-pad, y_count - pad) (first / last segment)
         const bool first = blockIdx.x == 0, last = k_end == a.ticks_total;
         for (int l = 0; l <= S; ++l) {
             if (!a.ph[l]) continue;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NT) void cqt_cascade_kernel(CascArgs a) {
                 const int p = 2 * (tid + NT * g);
                 *reinterpret_cast<float2*>(ev + p) = make_float2(pre[g][0], pre[g][2]);
                 *reinterpret_cast<float2*>(od + p) = make_float2(pre[g][1], pre[g][3]);
-                if (a.ph[0] && owned) {                               // split copy of the audio where the top octave's windows read it
+                if (SPLIT && owned) {                                 // split copy of the audio where the top octave's windows read it
                     const int i0 = a.g0 + k * C + 4 * (tid + NT * g);
                     if (i0 >= 0 && i0 < a.n) {
                         bool store = true;
@@ -416,14 +416,14 @@ __global__ __launch_bounds__(NT) void cqt_cascade_kernel(CascArgs a) {
         }
         if (k + 1 < k_end) fetch(k + 1);                              // next chunk in flight during the whole tick
         __syncthreads();
-        cascade_level<NODD, C, NT, 0>(a, lds, tid, clip, k, owned);
+        cascade_level<NODD, C, NT, 0, SPLIT>(a, lds, tid, clip, k, owned);
         __syncthreads();
-        if (S > 1) { cascade_level<NODD, C, NT, 1>(a, lds, tid, clip, k, owned); __syncthreads(); }
-        if (S > 2) { cascade_level<NODD, C, NT, 2>(a, lds, tid, clip, k, owned); __syncthreads(); }
-        if (S > 3) { cascade_level<NODD, C, NT, 3>(a, lds, tid, clip, k, owned); __syncthreads(); }
-        if (S > 4) { cascade_level<NODD, C, NT, 4>(a, lds, tid, clip, k, owned); __syncthreads(); }
-        if (S > 5) { cascade_level<NODD, C, NT, 5>(a, lds, tid, clip, k, owned); __syncthreads(); }
-        if (S > 6) { cascade_level<NODD, C, NT, 6>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (S > 1) { cascade_level<NODD, C, NT, 1, SPLIT>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (S > 2) { cascade_level<NODD, C, NT, 2, SPLIT>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (S > 3) { cascade_level<NODD, C, NT, 3, SPLIT>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (S > 4) { cascade_level<NODD, C, NT, 4, SPLIT>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (S > 5) { cascade_level<NODD, C, NT, 5, SPLIT>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (S > 6) { cascade_level<NODD, C, NT, 6, SPLIT>(a, lds, tid, clip, k, owned); __syncthreads(); }
     }
 }
 
@@ -952,8 +952,11 @@ int ake_cqt_logmag_f32(const ake_cqt_plan* p, const float* audio, int batch, int
     auto launch_cascade = [&](const CascArgs& a) {
         dim3 grid((a.ticks_total + a.ticks_per_seg - 1) / a.ticks_per_seg, batch);
         ake::ProfScope ps("cqt_cascade_kernel", stream);
-        if (p->half_len == 15) hipLaunchKernelGGL((cqt_cascade_kernel<8, C, NT>), grid, dim3(NT), 0, stream, a);
-        else hipLaunchKernelGGL((cqt_cascade_kernel<12, C, NT>), grid, dim3(NT), 0, stream, a);
+        const bool split = a.ph[0] != nullptr;
+        if (p->half_len == 15 && split) hipLaunchKernelGGL((cqt_cascade_kernel<8, C, NT, true>), grid, dim3(NT), 0, stream, a);
+        else if (p->half_len == 15) hipLaunchKernelGGL((cqt_cascade_kernel<8, C, NT, false>), grid, dim3(NT), 0, stream, a);
+        else if (split) hipLaunchKernelGGL((cqt_cascade_kernel<12, C, NT, true>), grid, dim3(NT), 0, stream, a);
+        else hipLaunchKernelGGL((cqt_cascade_kernel<12, C, NT, false>), grid, dim3(NT), 0, stream, a);
     };
     if (p->engine == 3) {
         BankCall2 call2;
