@@ -405,6 +405,7 @@ struct Buffers {           // workspace carve
     std::vector<float*> hst[3], aff_hst[3];                            // [head][hidden conv]
     // backward
     double* stats2 = nullptr;          // [bn_channels][3]  (sum g1, sum g1*zhat, sum (z - mean))
+    float* gslots = nullptr;           // [kGradSlots][grad_floats] partial weight gradients (backward)
     float* coef = nullptr;             // [bn_channels][4]  (c0, c1, c2, mean)
     float* g_map[3] = {nullptr, nullptr, nullptr};
     float *g_hid = nullptr, *g_pcf = nullptr, *g_fold0 = nullptr;
@@ -447,6 +448,7 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
     if (train) {
         b->stats = cv.take<double>(static_cast<size_t>(n->bn_channels) * 2 * kStatSlots);
         b->stats2 = cv.take<double>(static_cast<size_t>(n->bn_channels) * 3);
+        b->gslots = cv.take<float>(static_cast<size_t>(kGradSlots) * n->grad_floats);
         b->bstats = cv.take<float>(static_cast<size_t>(n->bn_channels) * 3);
         b->coef = cv.take<float>(static_cast<size_t>(n->bn_channels) * 4);
         for (auto* v : {&b->semi_raw, &b->aff_semi, &b->aff_cat, &b->aff_p2pin, &b->g_pc, &b->g_cat, &b->g_semi, &b->g_p, &b->g_pin, &b->g_psix})
@@ -1265,11 +1267,16 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     if (rc) return rc;
     AKE_REQUIRE(workspace && ws_bytes >= b.bytes, AKE_ERR_WORKSPACE, "pcnet backward: workspace %zu < %zu bytes", ws_bytes, b.bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!accumulate) AKE_HIP_CHECK(hipMemsetAsync(grads_out, 0, sizeof(float) * n->grad_floats, s));
+    AKE_HIP_CHECK(hipMemsetAsync(b.gslots, 0, sizeof(float) * n->grad_floats * kGradSlots, s));
     AKE_HIP_CHECK(hipMemsetAsync(b.stats2, 0, sizeof(double) * 3 * n->bn_channels, s));
-    Bwd bw{n, b, s, grads_out, batch};
+    Bwd bw{n, b, s, b.gslots, batch};
     rc = bw.run(mel, seq_length, d_key, d_tonic, d_genre, key_out);
     if (rc) return rc;
+    {
+        ake::ProfScope ps("grad_reduce_kernel", s);
+        hipLaunchKernelGGL(grad_reduce_kernel, dim3(static_cast<unsigned>((n->grad_floats + 255) / 256)), dim3(256), 0, s, b.gslots, grads_out,
+                           static_cast<long long>(n->grad_floats), accumulate ? 1 : 0);
+    }
     AKE_HIP_CHECK(hipGetLastError());
     return AKE_OK;
 }

@@ -12,7 +12,7 @@ struct Bwd {
     const ake_pcnet* n;
     Buffers& b;
     hipStream_t s;
-    float* grads;        // flat gradient buffer (device)
+    float* grads;        // slot 0 of the workspace's gradient slots ([kGradSlots][grad_floats]); run() is followed by grad_reduce_kernel
     int B;
 
     float* grad_of(const std::string& key) const { return grads + n->grad_off[n->spec_index.at(key)]; }
@@ -63,7 +63,7 @@ struct Bwd {
         a.cout = pc.cout;
         a.dst = const_cast<float*>(dz); a.dst_coff = dz_coff; a.dst_clip_stride = static_cast<long long>(dz_ctot) * a.H_out * a.T_out;
         a.in_affine = in_aff;
-        wa.dW = dW; wa.KH = pc.kh; wa.KW = pc.kw;
+        wa.dW = dW; wa.slot_stride = static_cast<long long>(n->grad_floats); wa.KH = pc.kh; wa.KW = pc.kw;
         const int KK = pc.kh * pc.kw;
         const int MTC = (pc.cout + 15) / 16, NTK = (KK + 15) / 16;
         // tile: rows x frames such that the patch of 8 channels + the dz tile fit the LDS budget
@@ -108,7 +108,7 @@ struct Bwd {
 
     void bias_grad(const float* dz, int ctot, int coff, int C, int HT, float* db) {
         ake::ProfScope ps("channel_sum_kernel", s);
-        hipLaunchKernelGGL(channel_sum_kernel, dim3(C, B), dim3(256), 0, s, dz, db, ctot, coff, HT);
+        hipLaunchKernelGGL(channel_sum_kernel, dim3(C, B), dim3(256), 0, s, dz, db, static_cast<long long>(n->grad_floats), ctot, coff, HT);
     }
 
     // A stack of `nconv` convolutions (conv -> BN -> LReLU each).  g holds ga w.r.t. the last activation on entry and is
@@ -241,7 +241,8 @@ struct Bwd {
         {
             ake::ProfScope ps("up_sixth_bwd_weight_kernel", s);
             hipLaunchKernelGGL(up_sixth_bwd_weight_kernel, dim3(d.prev_pc * d.prev_pc * 3, B), dim3(64), 0, s, b.g_psix[1], b.cat[1],
-                               static_cast<long long>(ctot) * 12 * Ti, b.aff_cat[1], grad_of("model.1.up_sixth.weight"), d.prev_pc, Ti);
+                               static_cast<long long>(ctot) * 12 * Ti, b.aff_cat[1], grad_of("model.1.up_sixth.weight"),
+                               static_cast<long long>(n->grad_floats), d.prev_pc, Ti);
         }
         {
             const long long total = static_cast<long long>(B) * d.prev_pc * 12 * Ti;
@@ -284,7 +285,10 @@ struct Bwd {
         bn_block_backward(m + "pool_semi_b", g, b.semi_raw[layer], b.aff_semi[layer], C, 0, (P / 3) * Tn);
         {
             ake::ProfScope ps("semi_bwd_weight_kernel", s);
-            hipLaunchKernelGGL(semi_bwd_weight_kernel, dim3(C * C * 9, B), dim3(64), 0, s, g, x, x_aff, grad_of(m + "pool_semi.weight"), C, P, Tn);
+            const size_t lds = std::max<size_t>(static_cast<size_t>(4) * (C * Tn + 3 * C * (Tn + 2)), 4 * 9 * 64) * sizeof(float);
+            AKE_REQUIRE(C <= 8 && lds <= kLdsBudget, AKE_ERR_UNSUPPORTED, "backward: pool_semi weight gradient handles <= 8 channels and %zu B of LDS (got %zu: too many frames)", kLdsBudget, lds);
+            hipLaunchKernelGGL(semi_bwd_weight_kernel, dim3((P / 3 + kSemiRows - 1) / kSemiRows, B), dim3(256), lds, s, g, x, x_aff,
+                               grad_of(m + "pool_semi.weight"), static_cast<long long>(n->grad_floats), C, P, Tn);
         }
         if (ga_x) {
             const long long total = static_cast<long long>(B) * C * P * Tn;

@@ -14,6 +14,25 @@
 
 namespace ake_k {
 
+// Weight gradients are reductions over (clip, position) finished with float atomics.  Thousands of workgroups adding into the
+// same few cache lines serialise in L2 (measured: 1.6 ms for 2.4 M atomics on 18 lines), so every writer adds into one of
+// kGradSlots copies of the flat gradient buffer and grad_reduce_kernel sums the copies into the caller's buffer.
+constexpr int kGradSlots = 16;
+
+__device__ __forceinline__ float* grad_slot(float* base, long long slot_stride) {
+    return base + static_cast<long long>((blockIdx.x + 3 * blockIdx.y + 5 * blockIdx.z) & (kGradSlots - 1)) * slot_stride;
+}
+
+// out[i] (+)= sum over slots
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restrict__ slots, float* __restrict__ out, long long n, int accumulate) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kGradSlots; ++k) s += slots[k * n + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
 // ---- masked temporal mean + sigmoid, backward (models.py:754-804) -----------------------------------------------
 struct PoolHeadBwdArgs {
     const float* d_out[3];    // dL/d(key_out, tonic_out, genre_out)  [B][rows]
@@ -118,7 +137,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
 }
 
 // sum over (clip, positions) of one channel slice -> bias gradient of a convolution without BatchNorm
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int ctot, int coff, int HT) {
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, long long slot_stride, int ctot, int coff,
+                                                          int HT) {
     const int c = blockIdx.x, clip = blockIdx.y;
     const long long base = (static_cast<long long>(clip) * ctot + coff + c) * HT;
     float s = 0.f;
@@ -128,7 +148,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out + c, r[0] + r[1] + r[2] + r[3]);
+    if (threadIdx.x == 0) atomicAdd(grad_slot(out, slot_stride) + c, r[0] + r[1] + r[2] + r[3]);
 }
 
 // ---- pooling / fold / repeat routing -------------------------------------------------------------------------------
@@ -223,23 +243,68 @@ __global__ void semi_bwd_data_kernel(const float* __restrict__ dz, const float* 
     ga[i] = acc;
 }
 
-// weight: dW[co][ci][dy][dx] += sum_{s,t} dz[co][s][t] * act(x[ci][3s+dy][(t+dx-1) mod T]);  grid (C*C*9 / 64.., B), wave-reduced
-__global__ __launch_bounds__(64) void semi_bwd_weight_kernel(const float* __restrict__ dz, const float* __restrict__ x,
-                                                             const float* __restrict__ x_aff, float* __restrict__ dW, int C, int H, int T) {
-    const int widx = blockIdx.x;                 // (co, ci, dy, dx)
+// weight: dW[co][ci][dy][dx] += sum_{s,t} dz[co][s][t] * act(x[ci][3s+dy][(t+dx-1) mod T])
+// Workgroup = (clip, group of kSemiRows output rows), 256 threads = 4 waves; wave w takes rows w, w+4, ...: it stages the
+// dz row of every output channel and the three activated input rows of every input channel in its own LDS slice (with
+// the circular time halo), then lane (co, ci) accumulates its 9 taps over the frames.  One atomic per weight and workgroup.
+constexpr int kSemiRows = 48;
+
+__global__ __launch_bounds__(256) void semi_bwd_weight_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                              const float* __restrict__ x_aff, float* __restrict__ dW, long long slot_stride, int C,
+                                                              int H, int T) {
+    extern __shared__ float semi_lds[];
     const int clip = blockIdx.y;
-    const int dx = widx % 3, dy = (widx / 3) % 3, ci = (widx / 9) % C, co = widx / (9 * C);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = H / 3;
-    const float* d = dz + (static_cast<long long>(clip) * C + co) * S * T;
-    const float* xs = x + (static_cast<long long>(clip) * C + ci) * H * T;
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < S * T; i += 64) {
-        const int s = i / T, t = i - s * T;
-        acc = fmaf(d[i], affine_act(xs[(3 * s + dy) * T + wrap(t + dx - 1, T)], x_aff, ci), acc);
-    }
+    const int Tp = T + 2;
+    float* ldz = semi_lds + wave * (C * T + 3 * C * Tp);      // [co][T]
+    float* lx = ldz + C * T;                                  // [ci][3][T + 2]   (index 0 <-> frame -1)
+    const int pairs = C * C;
+    const int co = lane / C, ci = lane - co * C;
+    float acc[9];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (threadIdx.x == 0) atomicAdd(dW + widx, acc);
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    const int s_end = min(S, static_cast<int>(blockIdx.x + 1) * kSemiRows);
+    for (int srow = blockIdx.x * kSemiRows + wave; srow < s_end; srow += 4) {
+        for (int i = lane; i < C * T; i += 64) {
+            const int c = i / T, t = i - c * T;
+            ldz[i] = dz[((static_cast<long long>(clip) * C + c) * S + srow) * T + t];
+        }
+        for (int i = lane; i < 3 * C * Tp; i += 64) {
+            const int c = i / (3 * Tp), r = (i - c * 3 * Tp) / Tp, tj = i - c * 3 * Tp - r * Tp;
+            int t = tj - 1;
+            t += t < 0 ? T : 0;
+            t -= t >= T ? T : 0;
+            lx[i] = affine_act(x[((static_cast<long long>(clip) * C + c) * H + 3 * srow + r) * T + t], x_aff, c);
+        }
+        // a wave's LDS slice is private: no workgroup barrier, the waitcnt the compiler inserts for the reads is enough
+        if (lane < pairs) {
+            const float* dr = ldz + co * T;
+            const float* xr = lx + ci * 3 * Tp;
+            for (int t = 0; t < T; ++t) {
+                const float d = dr[t];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) acc[dy * 3 + dx] = fmaf(d, xr[dy * Tp + t + dx], acc[dy * 3 + dx]);
+            }
+        }
+    }
+    // one atomic per weight and WORKGROUP: 4096 adders on the 18 cache lines of dW serialise in L2 (measured 1.6 ms when
+    // every wave added its own partial sums)
+    __syncthreads();
+    float* red = semi_lds;                                        // [4 waves][9][64]
+    if (lane < pairs) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) red[(wave * 9 + k) * 64 + lane] = acc[k];
+    }
+    __syncthreads();
+    if (wave == 0 && lane < pairs) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            atomicAdd(grad_slot(dW, slot_stride) + (co * C + ci) * 9 + k, (red[k * 64 + lane] + red[(9 + k) * 64 + lane]) + (red[(18 + k) * 64 + lane] + red[(27 + k) * 64 + lane]));
+    }
 }
 
 // ---- up_sixth (ConvTranspose2d (3,1)/(3,1)) backward -----------------------------------------------------------------
@@ -263,7 +328,8 @@ __global__ void up_sixth_bwd_data_kernel(const float* __restrict__ dz, const flo
 
 // weight: dW[ci][co][j] += sum_{p,t} dz[co][3p+j][t] * act(x[ci][p][t])     grid (C*C*3, B)
 __global__ __launch_bounds__(64) void up_sixth_bwd_weight_kernel(const float* __restrict__ dz, const float* __restrict__ x, long long x_clip_stride,
-                                                                 const float* __restrict__ x_aff, float* __restrict__ dW, int C, int T) {
+                                                                 const float* __restrict__ x_aff, float* __restrict__ dW, long long slot_stride, int C,
+                                                                 int T) {
     const int widx = blockIdx.x;                 // (ci, co, j)
     const int clip = blockIdx.y;
     const int j = widx % 3, co = (widx / 3) % C, ci = widx / (3 * C);
@@ -276,7 +342,7 @@ __global__ __launch_bounds__(64) void up_sixth_bwd_weight_kernel(const float* __
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (threadIdx.x == 0) atomicAdd(dW + widx, acc);
+    if (threadIdx.x == 0) atomicAdd(grad_slot(dW, slot_stride) + widx, acc);
 }
 
 // ---- convolution weight gradient on f32 MFMA --------------------------------------------------------------------------
@@ -288,7 +354,8 @@ __global__ __launch_bounds__(64) void up_sixth_bwd_weight_kernel(const float* __
 // atomics once per (clip group, chunk).
 struct WgradArgs {
     ConvArgs c;               // forward geometry; c.dst = dz (read), c.dst_coff / dst_clip_stride address it; c.w unused
-    float* dW;                // [cout][cin][KH][KW] (+=)
+    float* dW;                // [cout][cin][KH][KW] (+=), slot 0
+    long long slot_stride;    // floats between gradient slots
     int KH, KW;
     int rt_per_block;         // row tiles per workgroup
 };
@@ -397,6 +464,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs wa) {
             }
         }
         // ---- flush: D[row = co 4q+reg][col = tap c16] ----
+        float* const dWs = grad_slot(wa.dW, wa.slot_stride);
         if (wave < cc) {
             const int ci = c_lo + wave;
 #pragma unroll
@@ -407,7 +475,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs wa) {
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const int co = 16 * m + 4 * q + reg;
-                        if (co < a.cout && kk < KK) atomicAdd(wa.dW + (static_cast<long long>(co) * cin + ci) * KK + kk, acc[m][nt][reg]);
+                        if (co < a.cout && kk < KK) atomicAdd(dWs + (static_cast<long long>(co) * cin + ci) * KK + kk, acc[m][nt][reg]);
                     }
                 }
         }

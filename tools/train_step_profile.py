@@ -30,4 +30,4 @@ print("forward only (autograd node) ms: %.2f" % (1e3 * (t1 - t0)))
 pr = cProfile.Profile(); pr.enable()
 for i in range(5): step(i)
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
