@@ -31,6 +31,7 @@ namespace {
 
 constexpr double kBnEps = 1e-5;          // nn.BatchNorm2d default
 constexpr size_t kLdsBudget = 64 * 1024; // dynamic LDS per workgroup we allow ourselves
+constexpr size_t kBfFragsPerConv = 14 * 2 * 64;   // uint4 entries of split-bf16 weight fragments per 8->8 pitch convolution
 
 struct TensorSpec {
     std::string name;
@@ -49,6 +50,7 @@ struct PackedConv {          // device-resident folded + packed convolution
     // f32-MFMA fragment layout [ci][dy][s][ntile][64 lanes] (Toeplitz over TB frames), see pcnet_kernels.h
     int tb = 0, ku = 0, ntiles = 0, nt = 1;
     size_t f_off = 0;
+    long long bf_off = -1;         // 16-byte offset of the bf16x3 fragments in ake_pcnet::bf_frags_dev (8 -> 8 channel 7x7 pitch convs), or -1
 };
 
 struct LayerDims {
@@ -104,6 +106,8 @@ struct ake_pcnet {
     int32_t* run_off_dev = nullptr;    // per training BatchNorm channel (BnLayer::ch_off order): flat offsets of running_mean, running_var
     float* folded_dev = nullptr;
     bool tracing = false;
+    uint4* bf_frags_dev = nullptr;     // split-bf16 weight fragments of conv_p2p_bf16_kernel, rebuilt from the eval packs on the device
+    size_t bf_frags_count = 0;         // uint4 entries
 };
 
 namespace {
@@ -311,9 +315,11 @@ struct ConvGeom {            // explicit geometry for the data-gradient convolut
 // conv (12 x k, rows circular), 2 genre conv (kh in {1,2}, rows valid).
 int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int batch, int H, int T_in, bool same_time,
              bool lrelu, float* dst, int dst_ctot, int dst_coff, hipStream_t s, const char* name,
-             const float* in_affine = nullptr, double* stats = nullptr, const ConvGeom* geom = nullptr, bool accumulate = false) {
+             const float* in_affine = nullptr, double* stats = nullptr, const ConvGeom* geom = nullptr, bool accumulate = false,
+             unsigned short* cl_h = nullptr, unsigned short* cl_l = nullptr) {
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
+    a.cl_h = cl_h; a.cl_l = cl_l;
     AKE_REQUIRE(pc.kw == 7, AKE_ERR_UNSUPPORTED, "conv: kernel width %d not built (only 7)", pc.kw);
     AKE_REQUIRE(src.c0 + src.c1 == pc.cin, AKE_ERR_STATE, "conv %s: cin mismatch", name);
     a.src0 = src.p0; a.c0 = src.c0; a.src1 = src.p1; a.c1 = src.c1; a.h1 = src.h1 > 0 ? src.h1 : 1;
@@ -362,6 +368,45 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
     dim3 grid(t.n_row_tiles * t.n_time_tiles, pc.ntiles / pc.nt, batch), block(t.threads);
     ake::ProfScope ps(name, s);
     return launch_mfma(pc, ma, MT, grid, block, t.lds, s);
+}
+
+// does inference run layer i's Pitch2Pitch stack on the bf16 kernel (everything but its first conv)?
+bool p2p_uses_bf16(const ake_pcnet* n, int i) {
+    static const bool f32_only = std::getenv("AKE_P2P_F32") != nullptr;
+    const auto& c = n->cfg;
+    if (f32_only || i < 1 || c.conv_layers < 2 || n->dims[i].out_p != 8) return false;
+    for (int j = 1; j < c.conv_layers; ++j)
+        if (n->p2p[i][j].bf_off < 0) return false;
+    return true;
+}
+
+// 8 -> 8 channel 7x7 pitch convolution on bf16 MFMA (conv_p2p_bf16_kernel): channels-last split planes in, planes or NCHW f32 out
+int run_p2p_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const unsigned short* xl, int batch, int H, int T,
+                 float* dst_nchw, int dst_ctot, unsigned short* oh, unsigned short* ol, hipStream_t s, const char* name) {
+    P2pBfArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.xh = xh; a.xl = xl; a.bfrag = n->bf_frags_dev + pc.bf_off; a.bias = n->blob_dev + pc.b_off;
+    a.dst = dst_nchw; a.dst_clip_stride = static_cast<long long>(dst_ctot) * H * T; a.dst_coff = 0;
+    a.oh = oh; a.ol = ol;
+    a.H = H; a.T = T;
+    a.J = (T + 1) / 2;
+    a.Tp = 2 * a.J + 6;
+    a.R = std::max(1, std::min(H, 8 * 3 * 16 / a.J));
+    auto lds_of = [&](int R) { return (static_cast<size_t>(2) * (R + 6) * a.Tp + kBfFragsPerConv) * sizeof(uint4); };
+    while (a.R > 1 && lds_of(a.R) > 76 * 1024) --a.R;
+    AKE_REQUIRE(lds_of(a.R) <= 150 * 1024, AKE_ERR_UNSUPPORTED, "conv %s: %d frames do not fit the bf16 kernel's LDS patch", name, T);
+    a.n_row_tiles = (H + a.R - 1) / a.R;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    dim3 grid(a.n_row_tiles, 1, batch), block(512);
+    ake::ProfScope ps(name, s);
+    if (oh) hipLaunchKernelGGL(conv_p2p_bf16_kernel<true>, grid, block, lds_of(a.R), s, a);
+    else hipLaunchKernelGGL(conv_p2p_bf16_kernel<false>, grid, block, lds_of(a.R), s, a);
+    return AKE_OK;
 }
 
 int run_semi(const ake_pcnet* n, const PackedConv& pc, const float* src, int batch, int H, int Tn, float* dst,
@@ -593,7 +638,7 @@ void ake_pcnet_destroy(ake_pcnet* n) {
     if (!n) return;
     if (n->blob_dev) (void)hipFree(n->blob_dev);
     for (void* p : {static_cast<void*>(n->map_dev), static_cast<void*>(n->fold_ch_dev), static_cast<void*>(n->fold_bn_dev),
-                    static_cast<void*>(n->run_off_dev), static_cast<void*>(n->folded_dev)})
+                    static_cast<void*>(n->run_off_dev), static_cast<void*>(n->folded_dev), static_cast<void*>(n->bf_frags_dev)})
         if (p) (void)hipFree(p);
     delete n;
 }
@@ -849,6 +894,32 @@ int build_fold_tables(ake_pcnet* n) {
     return AKE_OK;
 }
 
+// Inference runs the 8 -> 8 channel 7x7 pitch convolutions (every conv of a Pitch2Pitch stack but the first) on bf16 MFMA
+// with split operands; their weight fragments are derived on the device from the eval packs, after every (re)pack.
+int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
+    size_t count = 0;
+    for (auto& layer : n->p2p)
+        for (size_t j = 0; j < layer.size(); ++j) {
+            PackedConv& pc = layer[j];
+            pc.bf_off = -1;
+            if (j >= 1 && pc.cin == 8 && pc.cout == 8 && pc.kh == 7 && pc.kw == 7 && pc.co == 8) { pc.bf_off = static_cast<long long>(count); count += kBfFragsPerConv; }
+        }
+    if (count == 0) return AKE_OK;
+    if (n->bf_frags_count != count) {
+        if (n->bf_frags_dev) { (void)hipFree(n->bf_frags_dev); n->bf_frags_dev = nullptr; }
+        AKE_HIP_CHECK(hipMalloc(&n->bf_frags_dev, count * sizeof(uint4)));
+        n->bf_frags_count = count;
+    }
+    for (const auto& layer : n->p2p)
+        for (const PackedConv& pc : layer)
+            if (pc.bf_off >= 0) {
+                ake::ProfScope ps("pack_p2p_bf16_kernel", s);
+                hipLaunchKernelGGL(pack_p2p_bf16_kernel, dim3((14 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc.w_off, n->bf_frags_dev + pc.bf_off);
+            }
+    AKE_HIP_CHECK(hipGetLastError());
+    return AKE_OK;
+}
+
 }  // namespace
 
 int ake_pcnet_finalize(ake_pcnet* n) {
@@ -867,6 +938,8 @@ int ake_pcnet_finalize(ake_pcnet* n) {
     AKE_REQUIRE(n->blob.size() == n->map_host.size(), AKE_ERR_STATE, "finalize: blob layout changed between builds");
     if (!n->blob_dev) AKE_HIP_CHECK(hipMalloc(&n->blob_dev, n->blob.size() * sizeof(float)));
     AKE_HIP_CHECK(hipMemcpy(n->blob_dev, n->blob.data(), n->blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    if ((rc = rebuild_bf16_frags(n, nullptr))) return rc;
+    AKE_HIP_CHECK(hipStreamSynchronize(nullptr));
     n->finalized = true;
     return AKE_OK;
 }
@@ -897,6 +970,10 @@ int ake_pcnet_load_from_device_f32(ake_pcnet* n, const float* params_dev, ake_st
         hipLaunchKernelGGL(gather_blob_kernel, dim3((NB + 255) / 256), dim3(256), 0, s, params_dev, n->folded_dev, n->map_dev, n->blob_dev, NB);
     }
     AKE_HIP_CHECK(hipGetLastError());
+    {
+        const int rc2 = rebuild_bf16_frags(n, s);
+        if (rc2) return rc2;
+    }
     n->finalized = true;
     return AKE_OK;
 }
@@ -1106,9 +1183,29 @@ struct Fwd {
             const float* in_aff = train ? b.aff_p2pin[i] : nullptr;
             float* out = nullptr;
             float* out_aff = nullptr;
+            // inference: every conv of the stack but the first is 8 -> 8 channels and runs on bf16 MFMA with split operands; the
+            // activations between them are channels-last split planes that live in the same ping-pong buffers (32 B per position
+            // either way: 8 f32 channels, or 8 bf16 hi + 8 bf16 lo)
+            const bool bf = !train && p2p_uses_bf16(n, i);
+            const size_t plane = static_cast<size_t>(B) * P * Ti * 8;                 // bf16 elements per plane
             for (int j = 0; j < c.conv_layers; ++j) {
                 out = train ? b.pst[i][j] : ((j & 1) ? b.pb[i] : b.pa[i]);
                 out_aff = !train ? nullptr : b.aff_pst[i][j];
+                if (bf) {
+                    unsigned short* oh = reinterpret_cast<unsigned short*>(out);
+                    const bool last_conv = j == c.conv_layers - 1;
+                    if (j == 0) {
+                        if ((rc = run_conv(n, n->p2p[i][0], 0, sdesc, B, P, Ti, true, true, out, d.out_p, 0, s, "conv_mfma_kernel/p2p", nullptr, nullptr,
+                                           nullptr, false, oh, oh + plane)))
+                            return rc;
+                    } else {
+                        const unsigned short* xh = reinterpret_cast<const unsigned short*>(((j - 1) & 1) ? b.pb[i] : b.pa[i]);
+                        if ((rc = run_p2p_bf16(n, n->p2p[i][j], xh, xh + plane, B, P, Ti, last_conv ? out : nullptr, d.out_p, last_conv ? nullptr : oh,
+                                               last_conv ? nullptr : oh + plane, s, "conv_p2p_bf16_kernel")))
+                            return rc;
+                    }
+                    continue;
+                }
                 if ((rc = conv(n->p2p[i][j], train ? n->p2p_t[i][j] : n->p2p[i][j], m + "p2p.layer." + std::to_string(3 * j + 1), 0, sdesc,
                                in_aff, B, P, Ti, true, out, d.out_p, 0, out_aff, "conv_mfma_kernel/p2p")))
                     return rc;
@@ -1294,7 +1391,9 @@ int ake_pcnet_forward_train_f32(const ake_pcnet* n, const float* mel, int batch,
 }
 
 // ---- debug taps ---------------------------------------------------------------------------
-static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frames, const void* ws, float** p, int64_t shape[4]) {
+static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frames, const void* ws, float** p, int64_t shape[4],
+                      int* channels_last = nullptr) {
+    if (channels_last) *channels_last = 0;
     AKE_REQUIRE(n && name, AKE_ERR_INVALID, "tap: null argument");
     AKE_REQUIRE(batch <= n->chunk_clips, AKE_ERR_INVALID, "tap: batch %d exceeds the chunk size %d", batch, n->chunk_clips);
     Buffers b;
@@ -1336,6 +1435,8 @@ static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frame
             }
             if (i >= 1 && nm == m + "p2p.layer." + std::to_string(3 * j + 2)) {
                 if (j < last_j - 1) break;
+                // inference keeps the stack's intermediate activations as channels-last split-bf16 planes (conv_p2p_bf16_kernel)
+                if (j < last_j && p2p_uses_bf16(n, i) && channels_last) *channels_last = 1;
                 return set((j & 1) ? b.pb[i] : b.pa[i], d.out_p, P, Ti);
             }
         }
@@ -1361,8 +1462,17 @@ int ake_pcnet_tap_copy(const ake_pcnet* n, const char* name, int batch, int fram
     AKE_REQUIRE(workspace && out_dev, AKE_ERR_INVALID, "tap_copy: null argument");
     float* p = nullptr;
     int64_t shape[4];
-    int rc = tap_lookup(n, name, batch, frames, workspace, &p, shape);
+    int cl = 0;
+    int rc = tap_lookup(n, name, batch, frames, workspace, &p, shape, &cl);
     if (rc) return rc;
+    if (cl) {
+        const long long total = shape[0] * shape[1] * shape[2] * shape[3];
+        const unsigned short* h = reinterpret_cast<const unsigned short*>(p);
+        hipLaunchKernelGGL(cl_to_nchw_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), h,
+                           h + total, out_dev, static_cast<int>(shape[2]), static_cast<int>(shape[3]), total);
+        AKE_HIP_CHECK(hipGetLastError());
+        return AKE_OK;
+    }
     AKE_HIP_CHECK(hipMemcpyAsync(out_dev, p, sizeof(float) * shape[0] * shape[1] * shape[2] * shape[3], hipMemcpyDeviceToDevice,
                                  static_cast<hipStream_t>(stream)));
     return AKE_OK;

@@ -41,6 +41,9 @@ P = 36 * OCTAVES
 # SURVEY.md section 8d / DESIGN.md "Measurement"
 CQT_BYTES_PER_CLIP = N_SAMPLES * 4 + P * T_FRAMES * 4                  # 1 410 552
 P2P_MACS_PER_CLIP = (5 * 8 + 8 * 8 + 8 * 8) * 49 * P * T_FRAMES        # 180 166 656 (three 7x7 convs: 5->8, 8->8, 8->8)
+P2P0_MACS_PER_CLIP = 5 * 8 * 49 * P * T_FRAMES                        # 42 896 832: first conv of the stack (f32 MFMA kernel)
+P2PBF_MACS_PER_CLIP = 8 * 8 * 49 * P * T_FRAMES                       # 68 634 931: each 8->8 conv (bf16x3 MFMA kernel)
+PEAK_BF16_TFLOPS = 2500.0
 NET_MACS_PER_CLIP = 277_395_712
 PEAK_FP32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
@@ -88,13 +91,22 @@ def cpu_baseline(sd, n_clips=24, batch=8):
                       f"torch CPU ops on {threads} threads, {dt:.1f} s"}
 
 
+def init_ranks(D):
+    """(rank, world, local_rank).  AKE_REHEARSE_ONE_GPU=1 runs the N > 1 code path on a one-GPU box: every rank uses cuda:0
+    and the collectives go through gloo (RCCL needs one GPU per rank) -- a functional rehearsal, never a measurement."""
+    if os.environ.get("AKE_REHEARSE_ONE_GPU"):
+        rank, world, _ = D.init_from_env("gloo")
+        return rank, world, 0
+    return D.init_from_env()
+
+
 def train_main(args):
     """BASELINE configs[3]: B clips per GPU (log-CQT features resident, as the reference caches them, KeyDataset.py:154-192),
     one training step = train-mode forward + general_step loss + HIP backward + ONE all-reduce of the flat 668 KB gradient
     buffer + fused Adam.  Secondary line; the headline metric is the inference line printed without --train."""
     import ake_amd
     from ake_amd import distributed as D, synthetic
-    rank, world, local_rank = D.init_from_env()
+    rank, world, local_rank = init_ranks(D)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -165,7 +177,7 @@ def main():
     import ake_amd
     from ake_amd import distributed as D, synthetic
 
-    rank, world, local_rank = D.init_from_env()
+    rank, world, local_rank = init_ranks(D)
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
@@ -215,33 +227,46 @@ def main():
     value = clips / dt
     p2p_ms, p2p_n = prof.get("conv_mfma_kernel/p2p", (0.0, 0))
     launches_per_step = p2p_n / args.steps if args.steps else 0
-    p2p_flops = 2.0 * P2P_MACS_PER_CLIP * B * args.steps              # all p2p launches of this rank
+    p2p_flops = 2.0 * P2P0_MACS_PER_CLIP * B * args.steps             # the f32-MFMA launches of the pitch stack (first conv)
     achieved = p2p_flops / (p2p_ms * 1e-3) / 1e12 if p2p_ms > 0 else None
+    bf_ms, bf_n = prof_all.get("conv_p2p_bf16_kernel", (0.0, 0))
+    bf_tflops = 2.0 * P2PBF_MACS_PER_CLIP * B * bf_n / (bf_ms * 1e-3) / 1e12 if bf_ms > 0 else None
     cqt_ms = sum(prof_all.get(k, (0.0, 0))[0] for k in prof_all if k.startswith("cqt_"))
     cqt_gbs = CQT_BYTES_PER_CLIP * B * args.steps / (cqt_ms * 1e-3) / 1e9 if cqt_ms > 0 else None
     kernel_ms = {k: round(v[0] / args.steps, 4) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}
     traffic_src, traffic = pmc_traffic()
-    p2p_traffic = cqt_traffic = None
+    p2p_traffic = cqt_traffic = bf_traffic = None
     if B == 256 and traffic:
-        p2p_rows = [v for k, v in traffic.items() if k.startswith("conv_mfma_kernel<8, 1, 3>") and v["hbm_bytes"] > 2e8]
+        p2p_rows = [v for k, v in traffic.items() if k.startswith("conv_mfma_kernel<8, 1, 3") and v["hbm_bytes"] > 2e8]
         p2p_traffic = p2p_rows[0]["hbm_bytes"] if p2p_rows else None
+        bf_rows = [v for k, v in traffic.items() if k.startswith("conv_p2p_bf16_kernel")]
+        bf_traffic = round(sum(v["hbm_bytes"] * v["dispatches"] for v in bf_rows) / max(1, sum(v["dispatches"] for v in bf_rows))) if bf_rows else None
         cqt_traffic = sum(v["hbm_bytes"] for k, v in traffic.items() if k.startswith("cqt_")) or None
     line = {
         "metric": "clips/s (15 s @ 22.05 kHz), HIP CQT + PitchClassNet forward",
         "value": round(value, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (8->8 pitch convs and the CQT bank as 3-term split-bf16 MFMA with f32 accumulation, ~1e-5 rel.)", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: batch={B} synthetic 15 s sine-mix clips per GPU, HIP CQT (288 bins, hop 4410) "
                                f"+ default PitchClassNet inference (genre head on), audio resident in HBM",
                    "clips_per_gpu": B, "n_samples": N_SAMPLES, "frames": T_FRAMES, "weights": "tests/golden/pcnet_default.npz (seeded)",
                    "parallelism": f"clip-sharded x{world}, no data-path collective"},
-        "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel<7,8,1,3> (pitch conv 7x7 circular as f32-MFMA implicit GEMM, x3 per chunk)",
+        "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel<8,1,3> on the first pitch conv (7x7 circular, 5 -> 8 channels, f32-MFMA implicit GEMM): "
+                               "the largest single launch of the step",
                      "achieved": round(achieved, 3) if achieved else None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_FP32_TFLOPS, 4) if achieved else None, "traffic": p2p_traffic,
-                     "traffic_source": f"profiles/{traffic_src}: mean HBM bytes per launch of the 3 pitch convolutions, rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE" if p2p_traffic else None,
-                     "algorithmic_bytes_per_launch": B * (8 + 8) * P * T_FRAMES * 4,
+                     "traffic_source": f"profiles/{traffic_src}: HBM bytes of that launch, rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE" if p2p_traffic else None,
+                     "algorithmic_bytes_per_launch": B * (1 + 8) * P * T_FRAMES * 4,
                      "avg_launch_ms": round(p2p_ms / p2p_n, 4) if p2p_n else None, "launches_per_step": launches_per_step,
-                     "algorithmic_flops_per_clip": 2 * P2P_MACS_PER_CLIP},
+                     "algorithmic_flops_per_clip": 2 * P2P0_MACS_PER_CLIP},
+        "roofline_p2p_bf16": {"bound": "mfma", "kernel": "conv_p2p_bf16_kernel (7x7 circular, 8 -> 8 channels, split-bf16 operands: 3 bf16 MFMA products per "
+                                                        "algorithmic MAC, f32 accumulate), 2 launches per step",
+                              "achieved": round(bf_tflops, 2) if bf_tflops else None, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(3 * bf_tflops / PEAK_BF16_TFLOPS, 4) if bf_tflops else None,
+                              "frac_note": "3 x achieved / peak: every algorithmic MAC costs three bf16 MFMA MACs",
+                              "traffic": bf_traffic, "algorithmic_bytes_per_launch": B * (8 + 8) * P * T_FRAMES * 4,
+                              "avg_launch_ms": round(bf_ms / bf_n, 4) if bf_n else None,
+                              "algorithmic_flops_per_clip_per_launch": 2 * P2PBF_MACS_PER_CLIP},
         "roofline_cqt": {"bound": "hbm", "kernels": " + ".join(sorted(k for k in prof_all if k.startswith("cqt_"))), "achieved": round(cqt_gbs, 1) if cqt_gbs else None,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(cqt_gbs / PEAK_HBM_GBS, 4) if cqt_gbs else None,
                          "traffic": cqt_traffic, "algorithmic_bytes_per_step": CQT_BYTES_PER_CLIP * B, "algorithmic_bytes_per_clip": CQT_BYTES_PER_CLIP,
