@@ -371,12 +371,23 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
 }
 
 // does inference run layer i's Pitch2Pitch stack on the bf16 kernel (everything but its first conv)?
-bool p2p_uses_bf16(const ake_pcnet* n, int i) {
+// (the bf16 kernels keep all frames of their row tile in one LDS patch: long clips fall back to the time-tiled f32 kernel)
+bool p2p_uses_bf16(const ake_pcnet* n, int i, int T) {
     static const bool f32_only = std::getenv("AKE_P2P_F32") != nullptr;
     const auto& c = n->cfg;
-    if (f32_only || i < 1 || c.conv_layers < 2 || n->dims[i].out_p != 8) return false;
+    if (f32_only || i < 1 || c.conv_layers < 2 || n->dims[i].out_p != 8 || T > 146) return false;
     for (int j = 1; j < c.conv_layers; ++j)
         if (n->p2p[i][j].bf_off < 0) return false;
+    return true;
+}
+
+// does inference run layer i's PitchClass2PitchClass stack on conv_pc_bf16_kernel?
+constexpr int kPcBf16MaxFrames = 120;
+bool pc2pc_uses_bf16(const ake_pcnet* n, int i, int T) {
+    static const bool f32_only = std::getenv("AKE_PC_F32") != nullptr;
+    if (f32_only || n->pc2pc[i].empty() || T > kPcBf16MaxFrames) return false;
+    for (const PackedConv& pc : n->pc2pc[i])
+        if (pc.bf_off < 0 || pc.cout != 16) return false;
     return true;
 }
 
@@ -406,6 +417,50 @@ int run_p2p_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short*
     ake::ProfScope ps(name, s);
     if (oh) hipLaunchKernelGGL(conv_p2p_bf16_kernel<true>, grid, block, lds_of(a.R), s, a);
     else hipLaunchKernelGGL(conv_p2p_bf16_kernel<false>, grid, block, lds_of(a.R), s, a);
+    return AKE_OK;
+}
+
+static const bool g_pc_f32_only = std::getenv("AKE_PC_F32") != nullptr;
+
+// NCHW f32 [clip][C][12][T] -> channels-last split planes [clip][12][T][16] (hi plane, then lo plane, at `planes`)
+int run_nchw_to_cl16(const float* src, int C, int batch, int T, unsigned short* planes, hipStream_t s) {
+    const long long npos = static_cast<long long>(batch) * 12 * T;
+    ake::ProfScope ps("nchw_to_cl16_kernel", s);
+    hipLaunchKernelGGL(nchw_to_cl16_kernel, dim3(static_cast<unsigned>((npos + 255) / 256)), dim3(256), 0, s, src, static_cast<long long>(C) * 12 * T, C, T,
+                       planes, planes + npos * 16, npos);
+    return AKE_OK;
+}
+
+// pitch-class convolution on bf16 MFMA (conv_pc_bf16_kernel): channels-last planes in; planes (cout == 16) or NCHW f32 out
+int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* planes_in, int batch, int T_in, bool same_time, bool lrelu,
+                float* dst_nchw, unsigned short* planes_out, hipStream_t s, const char* name) {
+    PcBfArgs a;
+    std::memset(&a, 0, sizeof(a));
+    const long long npos_in = static_cast<long long>(batch) * 12 * T_in;
+    a.xh = planes_in; a.xl = planes_in + npos_in * 16;
+    a.bfrag = n->bf_frags_dev + pc.bf_off; a.bias = n->blob_dev + pc.b_off;
+    a.T_in = T_in; a.T_out = same_time ? T_in : T_in - pc.kw + 1; a.pad_l = same_time ? pc.kw / 2 : 0;
+    AKE_REQUIRE(a.T_out > 0, AKE_ERR_INVALID, "conv %s: %d frames is too short for the valid head convolutions", name, T_in);
+    a.Tp = a.T_out + 8;
+    a.cout = pc.cout; a.lrelu = lrelu ? 1 : 0;
+    a.dst = dst_nchw; a.dst_clip_stride = static_cast<long long>(pc.cout) * 12 * a.T_out;
+    if (planes_out) { a.oh = planes_out; a.ol = planes_out + static_cast<long long>(batch) * 12 * a.T_out * 16; }
+    const size_t lds = static_cast<size_t>(2) * 12 * a.Tp * 2 * sizeof(uint4);
+    AKE_REQUIRE(lds <= 150 * 1024, AKE_ERR_UNSUPPORTED, "conv %s: %d frames do not fit the bf16 kernel's LDS patch", name, T_in);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    const int tiles = (12 * a.T_out + 15) / 16;
+    const int waves = std::min(8, (tiles + 3) / 4);
+    dim3 grid((tiles + waves * 4 - 1) / (waves * 4), 1, batch), block(waves * 64);
+    ake::ProfScope ps(name, s);
+    if (pc.cout == 16 && planes_out) hipLaunchKernelGGL((conv_pc_bf16_kernel<1, true>), grid, block, lds, s, a);
+    else if (pc.cout == 16) hipLaunchKernelGGL((conv_pc_bf16_kernel<1, false>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((conv_pc_bf16_kernel<2, false>), grid, block, lds, s, a);
     return AKE_OK;
 }
 
@@ -451,6 +506,7 @@ struct Buffers {           // workspace carve
     // backward
     double* stats2 = nullptr;          // [bn_channels][3]  (sum g1, sum g1*zhat, sum (z - mean))
     float* gslots = nullptr;           // [kGradSlots][grad_floats] partial weight gradients (backward)
+    unsigned short* feat_cl = nullptr; // [2 planes][B][12][Tf][16]
     float* coef = nullptr;             // [bn_channels][4]  (c0, c1, c2, mean)
     float* g_map[3] = {nullptr, nullptr, nullptr};
     float *g_hid = nullptr, *g_pcf = nullptr, *g_fold0 = nullptr;
@@ -488,6 +544,7 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
     b->pcf = cv.take<float>(B * n->final_ch * 12 * b->Tf);
     const size_t hid = B * 2 * n->final_ch * 12 * b->Tf;
     b->hid_k = cv.take<float>(2 * hid); b->hid_t = cv.take<float>(2 * hid);
+    b->feat_cl = cv.take<unsigned short>(B * 12 * b->Tf * 16 * 2);     // channels-last split copy of the head input (bf16 head convs)
     b->map_k = cv.take<float>(B * 12 * b->Tf); b->map_t = cv.take<float>(B * 12 * b->Tf);
     if (c.genre) { b->hid_g = cv.take<float>(2 * hid); b->map_g = cv.take<float>(B * 12 * b->Tf); }
     if (train) {
@@ -896,6 +953,8 @@ int build_fold_tables(ake_pcnet* n) {
 
 // Inference runs the 8 -> 8 channel 7x7 pitch convolutions (every conv of a Pitch2Pitch stack but the first) on bf16 MFMA
 // with split operands; their weight fragments are derived on the device from the eval packs, after every (re)pack.
+bool pc_bf16_eligible(const PackedConv& pc) { return pc.kh == 12 && pc.kw == 7 && pc.cin <= 16 && (pc.cout == 16 || pc.cout == 32); }
+
 int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
     size_t count = 0;
     for (auto& layer : n->p2p)
@@ -904,18 +963,32 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
             pc.bf_off = -1;
             if (j >= 1 && pc.cin == 8 && pc.cout == 8 && pc.kh == 7 && pc.kw == 7 && pc.co == 8) { pc.bf_off = static_cast<long long>(count); count += kBfFragsPerConv; }
         }
+    std::vector<PackedConv*> pcs;                             // pitch-class convolutions: the PitchClass2PitchClass stacks and the heads' first conv
+    for (auto& layer : n->pc2pc)
+        for (PackedConv& pc : layer) pcs.push_back(&pc);
+    if (!n->head_key.empty()) pcs.push_back(&n->head_key[0]);
+    if (!n->head_tonic.empty()) pcs.push_back(&n->head_tonic[0]);
+    for (PackedConv* pc : pcs) {
+        pc->bf_off = -1;
+        if (pc_bf16_eligible(*pc)) { pc->bf_off = static_cast<long long>(count); count += static_cast<size_t>(48) * (pc->cout / 16) * 2 * 64; }
+    }
     if (count == 0) return AKE_OK;
     if (n->bf_frags_count != count) {
         if (n->bf_frags_dev) { (void)hipFree(n->bf_frags_dev); n->bf_frags_dev = nullptr; }
         AKE_HIP_CHECK(hipMalloc(&n->bf_frags_dev, count * sizeof(uint4)));
         n->bf_frags_count = count;
     }
+    ake::ProfScope ps("pack_bf16_kernels", s);
     for (const auto& layer : n->p2p)
         for (const PackedConv& pc : layer)
-            if (pc.bf_off >= 0) {
-                ake::ProfScope ps("pack_p2p_bf16_kernel", s);
+            if (pc.bf_off >= 0)
                 hipLaunchKernelGGL(pack_p2p_bf16_kernel, dim3((14 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc.w_off, n->bf_frags_dev + pc.bf_off);
-            }
+    for (const PackedConv* pc : pcs)
+        if (pc->bf_off >= 0) {
+            const int NT = pc->cout / 16;
+            hipLaunchKernelGGL(pack_pc_bf16_kernel, dim3((48 * NT * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off, n->bf_frags_dev + pc->bf_off,
+                               pc->cin, pc->cout, pc->co, NT);
+        }
     AKE_HIP_CHECK(hipGetLastError());
     return AKE_OK;
 }
@@ -1186,7 +1259,7 @@ struct Fwd {
             // inference: every conv of the stack but the first is 8 -> 8 channels and runs on bf16 MFMA with split operands; the
             // activations between them are channels-last split planes that live in the same ping-pong buffers (32 B per position
             // either way: 8 f32 channels, or 8 bf16 hi + 8 bf16 lo)
-            const bool bf = !train && p2p_uses_bf16(n, i);
+            const bool bf = !train && p2p_uses_bf16(n, i, Ti);
             const size_t plane = static_cast<size_t>(B) * P * Ti * 8;                 // bf16 elements per plane
             for (int j = 0; j < c.conv_layers; ++j) {
                 out = train ? b.pst[i][j] : ((j & 1) ? b.pb[i] : b.pa[i]);
@@ -1256,9 +1329,22 @@ struct Fwd {
         const std::string m = "model." + std::to_string(i) + ".pc2pc.layer.";
         float* pdst = nullptr;
         float* pdst_aff = nullptr;
+        // inference, 16-channel stacks: bf16 MFMA with split operands; the stack's input is converted to channels-last planes once,
+        // the intermediate activations stay in that format (same 64 B per position as 16 f32 channels: the ping-pong buffers are
+        // reused), the last convolution writes NCHW f32 for the pooling / heads
+        const bool pc_bf = !train && pc2pc_uses_bf16(n, i, Ti);
+        if (pc_bf) run_nchw_to_cl16(psrc, cin, B, Ti, reinterpret_cast<unsigned short*>(b.pcb[i]), s);
         for (int j = 0; j < c.conv_layers; ++j) {
             pdst = train ? b.pcst[i][j] : ((j & 1) ? b.pcb[i] : b.pca[i]);
             pdst_aff = !train ? nullptr : b.aff_pcst[i][j];
+            if (pc_bf) {
+                const bool last_conv = j == c.conv_layers - 1;
+                const unsigned short* in = reinterpret_cast<const unsigned short*>((j & 1) ? b.pca[i] : b.pcb[i]);
+                if ((rc = run_pc_bf16(n, n->pc2pc[i][j], in, B, Ti, true, true, last_conv ? pdst : nullptr,
+                                      last_conv ? nullptr : reinterpret_cast<unsigned short*>(pdst), s, "conv_pc_bf16_kernel/pc2pc")))
+                    return rc;
+                continue;
+            }
             if ((rc = conv(n->pc2pc[i][j], train ? n->pc2pc_t[i][j] : n->pc2pc[i][j], m + std::to_string(3 * j + 1), 1,
                            Src{psrc, cin, nullptr, 0, 0}, psrc_aff, B, 12, Ti, true, pdst, cout, 0, pdst_aff,
                            L == 1 ? "conv_mfma_kernel/pc2pc0" : "conv_mfma_kernel/pc2pc")))
@@ -1278,6 +1364,12 @@ struct Fwd {
                             {&n->head_tonic, &n->head_tonic_t, b.hid_t, b.map_t, 1, "tonic_classifier"},
                             {&n->head_genre, &n->head_genre_t, b.hid_g, b.map_g, 2, "genre_classifier"}};
         int Tm = Tf;
+        // key / tonic heads: the first convolution (16 -> 32 channels, most of a head's work) on the bf16 kernel; both read the same
+        // channels-last copy of the features
+        const bool head_bf = !train && !g_pc_f32_only && L > 1 && n->final_ch == 16 && c.head_layers >= 2 && n->head_key[0].bf_off >= 0 &&
+                             n->head_tonic[0].bf_off >= 0 && Tf <= kPcBf16MaxFrames;
+        unsigned short* feat_cl = b.feat_cl;
+        if (head_bf) run_nchw_to_cl16(feat, n->final_ch, B, Tf, feat_cl, s);
         for (int h = 0; h < (c.genre ? 3 : 2); ++h) {
             const float* src = feat;
             const float* src_aff = feat_aff;
@@ -1288,6 +1380,11 @@ struct Fwd {
                 const bool lastj = j == c.head_layers - 1;
                 float* dst = lastj ? heads[h].map : (train ? b.hst[h][j] : heads[h].hid + (j & 1) * hid_half);
                 float* aff = (!train || lastj) ? nullptr : b.aff_hst[h][j];
+                if (head_bf && h < 2 && j == 0) {
+                    if ((rc = run_pc_bf16(n, pe, feat_cl, B, Tcur, false, true, dst, nullptr, s, "conv_pc_bf16_kernel/head"))) return rc;
+                    src = dst; src_aff = aff; hc = pe.cout; Tcur -= c.kernel_size - 1;
+                    continue;
+                }
                 if ((rc = conv(pe, train ? (*heads[h].ct)[j] : pe, lastj ? "" : std::string(heads[h].nm) + "." + std::to_string(3 * j + 1),
                                heads[h].kind, Src{src, hc, nullptr, 0, 0}, src_aff, B, 12, Tcur, false, dst, pe.cout, 0, aff,
                                h == 2 ? "conv_mfma_kernel/genre_head" : "conv_mfma_kernel/head")))
@@ -1431,12 +1528,13 @@ static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frame
                 const bool to_cat = i == 0 && L > 1;             // layer 0's last conv writes into cat[1]
                 if (to_cat && j == last_j) break;                // strided inside the concat buffer: use "model.1.cat"
                 if (j < last_j - (to_cat ? 2 : 1)) break;
+                if (j < last_j && i == L - 1 && pc2pc_uses_bf16(n, i, Ti) && channels_last) *channels_last = 1;
                 return set((j & 1) ? b.pcb[i] : b.pca[i], i == 0 ? c.n_filters : d.out_pc, 12, Ti);
             }
             if (i >= 1 && nm == m + "p2p.layer." + std::to_string(3 * j + 2)) {
                 if (j < last_j - 1) break;
                 // inference keeps the stack's intermediate activations as channels-last split-bf16 planes (conv_p2p_bf16_kernel)
-                if (j < last_j && p2p_uses_bf16(n, i) && channels_last) *channels_last = 1;
+                if (j < last_j && p2p_uses_bf16(n, i, Ti) && channels_last) *channels_last = 1;
                 return set((j & 1) ? b.pb[i] : b.pa[i], d.out_p, P, Ti);
             }
         }
@@ -1469,7 +1567,7 @@ int ake_pcnet_tap_copy(const ake_pcnet* n, const char* name, int batch, int fram
         const long long total = shape[0] * shape[1] * shape[2] * shape[3];
         const unsigned short* h = reinterpret_cast<const unsigned short*>(p);
         hipLaunchKernelGGL(cl_to_nchw_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), h,
-                           h + total, out_dev, static_cast<int>(shape[2]), static_cast<int>(shape[3]), total);
+                           h + total, out_dev, static_cast<int>(shape[1]), static_cast<int>(shape[2]), static_cast<int>(shape[3]), total);
         AKE_HIP_CHECK(hipGetLastError());
         return AKE_OK;
     }

@@ -680,18 +680,203 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
     }
 }
 
-// debug taps: channels-last split planes [clip][H][T][8] -> NCHW f32 [clip][8][H][T]
-__global__ void cl_to_nchw_kernel(const unsigned short* __restrict__ xh, const unsigned short* __restrict__ xl, float* __restrict__ out, int H, int T,
-                                  long long total) {
+// ==========================================================================================
+// Equivariant pitch-class convolution (12 x 7 kernel, rows circular over the 12 pitch classes, time zero-padded or valid;
+// models.py:36-47) on bf16 MFMA with split operands -- the PitchClass2PitchClass stacks and the first convolution of the
+// key / tonic heads.  Same idea as conv_p2p_bf16_kernel: channels-last activations [clip][12][T][16] as bf16 hi / lo planes,
+//   m = (pitch class y, frame t)       A[m][k] = X[(y + dy) mod 12][t + dx - pad][ci]
+//   n = output channel (NT tiles of 16)  B[k][n] = w[co][ci][dy][dx]
+//   k-step = (dy, tap pair p): lane q holds tap dx = 2p + (q >> 1), channels 8 (q & 1) .. +7   -> 12 x 4 = 48 k-steps (dx = 7 is
+//   a zero tap), three MFMAs per k-step, M-tile and N-tile.  The whole clip (12 rows, all frames) is one LDS patch; the weight
+//   fragments (96 KB per N-tile) stream from L2 one k-step ahead.
+// ==========================================================================================
+struct PcBfArgs {
+    const unsigned short* xh;     // [clip][12][T_in][16]
+    const unsigned short* xl;
+    const uint4* bfrag;           // [48 k-steps][NT][hi|lo][64 lanes] x 8 bf16
+    const float* bias;            // [cout]
+    float* dst;                   // NCHW f32 [clip][dst_ctot][12][T_out] (OUT_CL == false)
+    long long dst_clip_stride;
+    unsigned short* oh;           // channels-last planes [clip][12][T_out][16] (OUT_CL == true, cout == 16)
+    unsigned short* ol;
+    int T_in, T_out, pad_l, Tp, cout, lrelu;
+};
+
+template <int NT, bool OUT_CL>
+__global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+    const int clip = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int Tp = a.Tp;
+    constexpr int MT = 4;
+    const int Mtot = 12 * a.T_out;
+    uint4* const pH = lds4;                                  // [12][Tp][2 halves of 8 channels]
+    uint4* const pL = lds4 + 12 * Tp * 2;
+    {   // patch frame f <-> input frame f - pad_l, zeros outside [0, T_in)
+        const long long cbase = static_cast<long long>(clip) * 12 * a.T_in * 2;
+        const uint4* gh = reinterpret_cast<const uint4*>(a.xh) + cbase;
+        const uint4* gl = reinterpret_cast<const uint4*>(a.xl) + cbase;
+        const int n16 = 12 * Tp * 2;
+        for (int i = threadIdx.x; i < n16; i += blockDim.x) {
+            const int half = i & 1, pos = i >> 1;
+            const int row = pos / Tp, f = pos - row * Tp;
+            const int t = f - a.pad_l;
+            uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+            if (t >= 0 && t < a.T_in) {
+                const long long g = (static_cast<long long>(row) * a.T_in + t) * 2 + half;
+                vh = gh[g]; vl = gl[g];
+            }
+            pH[i] = vh; pL[i] = vl;
+        }
+    }
+    __syncthreads();
+    const int tile0 = (blockIdx.x * nw + wave) * MT;          // first M-tile of this wave
+    if (tile0 * 16 >= Mtot) return;
+    int ay[MT], at[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = (tile0 + mt) * 16 + r16;
+        if (m >= Mtot) m = Mtot - 1;
+        ay[mt] = m / a.T_out;
+        at[mt] = m - ay[mt] * a.T_out;
+    }
+    typedef float f32x4c __attribute__((ext_vector_type(4)));
+    f32x4c acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4c{0.f, 0.f, 0.f, 0.f};
+    const uint4* __restrict__ bg = a.bfrag + lane;
+    uint4 nbh[NT], nbl[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { nbh[nt] = bg[(nt * 2 + 0) * 64]; nbl[nt] = bg[(nt * 2 + 1) * 64]; }
+    const int dxq = q >> 1, half = q & 1;
+    for (int dy = 0; dy < 12; ++dy) {
+        int rowoff[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int row = ay[mt] + dy;
+            row -= row >= 12 ? 12 : 0;
+            rowoff[mt] = ((row * Tp + at[mt] + dxq) << 1) + half;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int ks = dy * 4 + p;
+            bf16x8c bh[NT], bl[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { bh[nt] = __builtin_bit_cast(bf16x8c, nbh[nt]); bl[nt] = __builtin_bit_cast(bf16x8c, nbl[nt]); }
+            const int kn = ks + 1 < 48 ? ks + 1 : ks;                 // next k-step's weights, in flight during this one's MFMAs
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { nbh[nt] = bg[((kn * NT + nt) * 2 + 0) * 64]; nbl[nt] = bg[((kn * NT + nt) * 2 + 1) * 64]; }
+            bf16x8c ah[MT], al[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                ah[mt] = __builtin_bit_cast(bf16x8c, pH[rowoff[mt] + 4 * p]);
+                al[mt] = __builtin_bit_cast(bf16x8c, pL[rowoff[mt] + 4 * p]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: D[row m = 4q + i][col = co within the N-tile] ----
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = nt * 16 + r16;
+        const float bias = co < a.cout ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m0 = (tile0 + mt) * 16 + 4 * q;
+            int y = m0 / a.T_out, t = m0 - y * a.T_out;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (m0 + i < Mtot && co < a.cout) {
+                    float v = acc[mt][nt][i] + bias;
+                    if (a.lrelu) v = v > 0.f ? v : v * kSlope;
+                    if (OUT_CL) {
+                        const long long idx = ((static_cast<long long>(clip) * 12 + y) * a.T_out + t) * 16 + co;
+                        const unsigned int hb = bf16_bits(v);
+                        a.oh[idx] = static_cast<unsigned short>(hb);
+                        a.ol[idx] = static_cast<unsigned short>(bf16_bits(v - __uint_as_float(hb << 16)));
+                    } else {
+                        a.dst[clip * a.dst_clip_stride + (static_cast<long long>(co) * 12 + y) * a.T_out + t] = v;
+                    }
+                }
+                if (++t == a.T_out) { t = 0; ++y; }
+            }
+        }
+    }
+}
+
+// weight fragments of conv_pc_bf16_kernel from the VALU-layout eval pack [co group of CO][ci][12][7][CO]: one thread per (k-step, N-tile, lane)
+__global__ void pack_pc_bf16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin, int cout, int CO, int NT) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 48 * NT * 64) return;
+    const int lane = i & 63, nt = (i >> 6) % NT, ks = i / (64 * NT);
+    const int dy = ks >> 2, p = ks & 3;
+    const int co = nt * 16 + (lane & 15), qq = lane >> 4;
+    const int dx = 2 * p + (qq >> 1), c8 = 8 * (qq & 1);
+    unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+    for (int e = 0; e < 8; ++e) {
+        const int ci = c8 + e;
+        float v = 0.f;
+        if (dx < 7 && ci < cin && co < cout) v = w[((((co / CO) * cin + ci) * 12 + dy) * 7 + dx) * CO + (co % CO)];
+        const unsigned int hb = bf16_bits(v);
+        const unsigned int lb = bf16_bits(v - __uint_as_float(hb << 16));
+        hi[e >> 1] |= hb << (16 * (e & 1));
+        lo[e >> 1] |= lb << (16 * (e & 1));
+    }
+    out[((ks * NT + nt) * 2 + 0) * 64 + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    out[((ks * NT + nt) * 2 + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+// NCHW f32 [clip][C][12][T] (C <= 16) -> channels-last split planes [clip][12][T][16], channels >= C zero
+__global__ void nchw_to_cl16_kernel(const float* __restrict__ src, long long src_clip_stride, int C, int T, unsigned short* __restrict__ xh,
+                                    unsigned short* __restrict__ xl, long long npos) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;      // (clip, row, t)
+    if (i >= npos) return;
+    const int t = static_cast<int>(i % T);
+    const long long r = i / T;
+    const int y = static_cast<int>(r % 12);
+    const long long clip = r / 12;
+    const float* s = src + clip * src_clip_stride + static_cast<long long>(y) * T + t;
+    unsigned int hi[8], lo[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { hi[k] = 0; lo[k] = 0; }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float v = c < C ? s[static_cast<long long>(c) * 12 * T] : 0.f;
+        const unsigned int hb = bf16_bits(v);
+        hi[c >> 1] |= hb << (16 * (c & 1));
+        lo[c >> 1] |= bf16_bits(v - __uint_as_float(hb << 16)) << (16 * (c & 1));
+    }
+    uint4* oh = reinterpret_cast<uint4*>(xh) + i * 2;
+    uint4* ol = reinterpret_cast<uint4*>(xl) + i * 2;
+    oh[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); oh[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+    ol[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]); ol[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+}
+
+// debug taps: channels-last split planes [clip][H][T][C] -> NCHW f32 [clip][C][H][T]
+__global__ void cl_to_nchw_kernel(const unsigned short* __restrict__ xh, const unsigned short* __restrict__ xl, float* __restrict__ out, int C, int H,
+                                  int T, long long total) {
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int t = static_cast<int>(i % T);
     long long r = i / T;
     const int y = static_cast<int>(r % H);
     r /= H;
-    const int c = static_cast<int>(r % 8);
-    const long long clip = r / 8;
-    const long long src = ((clip * H + y) * T + t) * 8 + c;
+    const int c = static_cast<int>(r % C);
+    const long long clip = r / C;
+    const long long src = ((clip * H + y) * T + t) * C + c;
     out[i] = __uint_as_float(static_cast<unsigned int>(xh[src]) << 16) + __uint_as_float(static_cast<unsigned int>(xl[src]) << 16);
 }
 
