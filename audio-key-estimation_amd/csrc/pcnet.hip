@@ -315,11 +315,9 @@ struct ConvGeom {            // explicit geometry for the data-gradient convolut
 // conv (12 x k, rows circular), 2 genre conv (kh in {1,2}, rows valid).
 int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int batch, int H, int T_in, bool same_time,
              bool lrelu, float* dst, int dst_ctot, int dst_coff, hipStream_t s, const char* name,
-             const float* in_affine = nullptr, double* stats = nullptr, const ConvGeom* geom = nullptr, bool accumulate = false,
-             unsigned short* cl_h = nullptr, unsigned short* cl_l = nullptr) {
+             const float* in_affine = nullptr, double* stats = nullptr, const ConvGeom* geom = nullptr, bool accumulate = false) {
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.cl_h = cl_h; a.cl_l = cl_l;
     AKE_REQUIRE(pc.kw == 7, AKE_ERR_UNSUPPORTED, "conv: kernel width %d not built (only 7)", pc.kw);
     AKE_REQUIRE(src.c0 + src.c1 == pc.cin, AKE_ERR_STATE, "conv %s: cin mismatch", name);
     a.src0 = src.p0; a.c0 = src.c0; a.src1 = src.p1; a.c1 = src.c1; a.h1 = src.h1 > 0 ? src.h1 : 1;
@@ -376,7 +374,7 @@ bool p2p_uses_bf16(const ake_pcnet* n, int i, int T) {
     static const bool f32_only = std::getenv("AKE_P2P_F32") != nullptr;
     const auto& c = n->cfg;
     if (f32_only || i < 1 || c.conv_layers < 2 || n->dims[i].out_p != 8 || T > 146) return false;
-    for (int j = 1; j < c.conv_layers; ++j)
+    for (int j = 0; j < c.conv_layers; ++j)
         if (n->p2p[i][j].bf_off < 0) return false;
     return true;
 }
@@ -961,7 +959,7 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
         for (size_t j = 0; j < layer.size(); ++j) {
             PackedConv& pc = layer[j];
             pc.bf_off = -1;
-            if (j >= 1 && pc.cin == 8 && pc.cout == 8 && pc.kh == 7 && pc.kw == 7 && pc.co == 8) { pc.bf_off = static_cast<long long>(count); count += kBfFragsPerConv; }
+            if (pc.cin <= 8 && pc.cout == 8 && pc.kh == 7 && pc.kw == 7 && pc.co == 8) { pc.bf_off = static_cast<long long>(count); count += kBfFragsPerConv; }
         }
     std::vector<PackedConv*> pcs;                             // pitch-class convolutions: the PitchClass2PitchClass stacks and the heads' first conv
     for (auto& layer : n->pc2pc)
@@ -982,7 +980,7 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
     for (const auto& layer : n->p2p)
         for (const PackedConv& pc : layer)
             if (pc.bf_off >= 0)
-                hipLaunchKernelGGL(pack_p2p_bf16_kernel, dim3((14 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc.w_off, n->bf_frags_dev + pc.bf_off);
+                hipLaunchKernelGGL(pack_p2p_bf16_kernel, dim3((14 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc.w_off, n->bf_frags_dev + pc.bf_off, pc.cin);
     for (const PackedConv* pc : pcs)
         if (pc->bf_off >= 0) {
             const int NT = pc->cout / 16;
@@ -1267,9 +1265,15 @@ struct Fwd {
                 if (bf) {
                     unsigned short* oh = reinterpret_cast<unsigned short*>(out);
                     const bool last_conv = j == c.conv_layers - 1;
-                    if (j == 0) {
-                        if ((rc = run_conv(n, n->p2p[i][0], 0, sdesc, B, P, Ti, true, true, out, d.out_p, 0, s, "conv_mfma_kernel/p2p", nullptr, nullptr,
-                                           nullptr, false, oh, oh + plane)))
+                    if (j == 0) {   // the stack's input (pitch stream | repeated up_sixth output) as channels-last planes, parked in the OTHER buffer
+                        unsigned short* ih = reinterpret_cast<unsigned short*>(b.pb[i]);
+                        const long long npos = static_cast<long long>(B) * P * Ti;
+                        {
+                            ake::ProfScope ps("p2p_input_cl8_kernel", s);
+                            hipLaunchKernelGGL(p2p_input_cl8_kernel, dim3(static_cast<unsigned>((npos + 255) / 256)), dim3(256), 0, s, sdesc.p0, sdesc.c0,
+                                               sdesc.p1, sdesc.c1, sdesc.h1 > 0 ? sdesc.h1 : 1, P, Ti, ih, ih + plane, npos);
+                        }
+                        if ((rc = run_p2p_bf16(n, n->p2p[i][0], ih, ih + plane, B, P, Ti, nullptr, d.out_p, oh, oh + plane, s, "conv_p2p_bf16_kernel")))
                             return rc;
                     } else {
                         const unsigned short* xh = reinterpret_cast<const unsigned short*>(((j - 1) & 1) ? b.pb[i] : b.pa[i]);

@@ -52,10 +52,6 @@ struct ConvArgs {
     const float* in_affine;   // [c0+c1][3] (scale, shift, negative slope) applied to every staged input value, or null
     double* stats;            // [kStatSlots][..][2] += (sum, sum of squares) of the raw outputs, or null
     int stats_stride;         // doubles between two slots of `stats` (workgroups spread their atomics over the slots)
-    // optional: write the result as channels-last split-bf16 planes [clip][H_out][T_out][8] (hi / lo, value = hi + lo to 2^-17)
-    // instead of `dst` -- the input format of conv_p2p_bf16_kernel.  cout must be 8.
-    unsigned short* cl_h;
-    unsigned short* cl_l;
     int accumulate;           // 1: dst += result (several data-gradients landing on one tensor)
 };
 
@@ -525,15 +521,8 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
                     float v = acc[mt][nt][reg] + a.bias[co];
                     if (TRAIN && a.stats) { st1[nt] += v; st2[nt] = fmaf(v, v, st2[nt]); }
                     if (a.lrelu) v = v > 0.f ? v : v * kSlope;
-                    if (!TRAIN && a.cl_h) {
-                        const long long idx = ((static_cast<long long>(clip) * a.H_out + (y0 + r)) * a.T_out + t0 + tl) * 8 + co;
-                        const unsigned int hb = bf16_bits(v);
-                        a.cl_h[idx] = static_cast<unsigned short>(hb);
-                        a.cl_l[idx] = static_cast<unsigned short>(bf16_bits(v - __uint_as_float(hb << 16)));
-                    } else {
-                        float* dp = d + ((a.dst_coff + co) * a.H_out + (y0 + r)) * row_elems + tl;
-                        *dp = (TRAIN && a.accumulate) ? *dp + v : v;
-                    }
+                    float* dp = d + ((a.dst_coff + co) * a.H_out + (y0 + r)) * row_elems + tl;
+                    *dp = (TRAIN && a.accumulate) ? *dp + v : v;
                 }
             }
             if (++j == J) { j = 0; ++r; }
@@ -865,6 +854,28 @@ __global__ void nchw_to_cl16_kernel(const float* __restrict__ src, long long src
     ol[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]); ol[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
 }
 
+// Input of a Pitch2Pitch stack as channels-last split planes [clip][H][T][8]: channels [0, c0) = the pitch stream p [clip][c0][H][T],
+// channels [c0, c0 + c1) = the up_sixth output [clip][c1][h1][T] repeated over the octaves (row % h1: PitchClass2Pitch, models.py:140-143),
+// the rest zero -- what torch.cat((p, pc2p(up_sixth(pc))), 1) materialises in the reference (models.py:378-383).
+__global__ void p2p_input_cl8_kernel(const float* __restrict__ p, int c0, const float* __restrict__ u, int c1, int h1, int H, int T,
+                                     unsigned short* __restrict__ xh, unsigned short* __restrict__ xl, long long npos) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;      // (clip, row, t)
+    if (i >= npos) return;
+    const int t = static_cast<int>(i % T);
+    const long long r = i / T;
+    const int y = static_cast<int>(r % H);
+    const long long clip = r / H;
+    unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+    for (int c = 0; c < c0 + c1 && c < 8; ++c) {
+        const float v = c < c0 ? p[((clip * c0 + c) * H + y) * T + t] : u[((clip * c1 + (c - c0)) * h1 + (y % h1)) * T + t];
+        const unsigned int hb = bf16_bits(v);
+        hi[c >> 1] |= hb << (16 * (c & 1));
+        lo[c >> 1] |= bf16_bits(v - __uint_as_float(hb << 16)) << (16 * (c & 1));
+    }
+    reinterpret_cast<uint4*>(xh)[i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    reinterpret_cast<uint4*>(xl)[i] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
 // debug taps: channels-last split planes [clip][H][T][C] -> NCHW f32 [clip][C][H][T]
 __global__ void cl_to_nchw_kernel(const unsigned short* __restrict__ xh, const unsigned short* __restrict__ xl, float* __restrict__ out, int C, int H,
                                   int T, long long total) {
@@ -880,9 +891,10 @@ __global__ void cl_to_nchw_kernel(const unsigned short* __restrict__ xh, const u
     out[i] = __uint_as_float(static_cast<unsigned int>(xh[src]) << 16) + __uint_as_float(static_cast<unsigned int>(xl[src]) << 16);
 }
 
-// B fragments of conv_p2p_bf16_kernel from the VALU-layout eval pack [ci][dy][dx][8 co] (BatchNorm already folded):
+// B fragments of conv_p2p_bf16_kernel from the VALU-layout eval pack [ci < cin][dy][dx][8 co] (BatchNorm already folded; input
+// channels >= cin get zero weights):
 // one thread per (k-step, lane, element).
-__global__ void pack_p2p_bf16_kernel(const float* __restrict__ w, uint4* __restrict__ out) {
+__global__ void pack_p2p_bf16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (ks, lane)
     if (i >= 14 * 64) return;
     const int ks = i / 64, lane = i - ks * 64;
@@ -893,7 +905,7 @@ __global__ void pack_p2p_bf16_kernel(const float* __restrict__ w, uint4* __restr
     unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
     for (int ci = 0; ci < 8; ++ci) {
         float v = 0.f;
-        if (dx >= 0 && dx < 7) v = w[((ci * 7 + dy) * 7 + dx) * 8 + co];
+        if (dx >= 0 && dx < 7 && ci < cin) v = w[((ci * 7 + dy) * 7 + dx) * 8 + co];
         const unsigned int hb = bf16_bits(v);
         const unsigned int lb = bf16_bits(v - __uint_as_float(hb << 16));
         hi[ci >> 1] |= hb << (16 * (ci & 1));
