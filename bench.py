@@ -10,9 +10,11 @@ owns 256 clips of its own (weak scaling, clips are independent, no data-path col
 step time is the max over ranks.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line (tier contract):
-  roofline      dominant kernel (the 7x7 circular pitch convolutions, 65 % of the MACs):
-                algorithmic FLOPs of its launches / their hipEvent-measured duration, vs the
-                157.3 TFLOP/s fp32 peak of MI355X.
+  roofline      dominant kernel (conv_p2p_bf16_kernel: the 7x7 circular pitch convolutions, 65 % of
+                the MACs): algorithmic FLOPs (2 x MACs) of its launches / their hipEvent-measured
+                duration, vs the 2.5 PFLOP/s dense bf16 MFMA peak of MI355X; the kernel multiplies
+                split-bf16 operands (3 MFMA products per MAC), so `frac_of_split_ceiling` = 3 x frac
+                is the fraction of what this formulation can reach.
   roofline_cqt  the CQT stage against the 8 TB/s HBM peak (1 410 552 algorithmic bytes per clip).
   cpu_baseline  the CPU oracle (direct-form CQT as BLAS matmuls + the float64 network, the
                 reference's dtype) timed on this box's host cores on a bounded sample.
@@ -41,8 +43,6 @@ P = 36 * OCTAVES
 # SURVEY.md section 8d / DESIGN.md "Measurement"
 CQT_BYTES_PER_CLIP = N_SAMPLES * 4 + P * T_FRAMES * 4                  # 1 410 552
 P2P_MACS_PER_CLIP = (5 * 8 + 8 * 8 + 8 * 8) * 49 * P * T_FRAMES        # 180 166 656 (three 7x7 convs: 5->8, 8->8, 8->8)
-P2P0_MACS_PER_CLIP = 5 * 8 * 49 * P * T_FRAMES                        # 42 896 832: first conv of the stack (f32 MFMA kernel)
-P2PBF_MACS_PER_CLIP = 8 * 8 * 49 * P * T_FRAMES                       # 68 634 931: each 8->8 conv (bf16x3 MFMA kernel)
 PEAK_BF16_TFLOPS = 2500.0
 NET_MACS_PER_CLIP = 277_395_712
 PEAK_FP32_TFLOPS = 157.3
@@ -196,9 +196,9 @@ def main():
     for _ in range(max(args.warmup, 1)):
         out = est(audio)
     torch.cuda.synchronize()
-    # timed region: hipEvents (on the launch stream) bracket only the dominant kernel -- 12 launches per step
+    # timed region: hipEvents (on the launch stream) bracket only the dominant kernel -- 3 launches per step
     ake_amd._lib.lib().ake_prof_reset()
-    ake_amd._lib.prof_enable("conv_mfma_kernel/p2p", True)
+    ake_amd._lib.prof_enable("conv_p2p_bf16_kernel", True)
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -225,48 +225,41 @@ def main():
 
     clips = B * world * args.steps
     value = clips / dt
-    p2p_ms, p2p_n = prof.get("conv_mfma_kernel/p2p", (0.0, 0))
+    # dominant kernel: the three 7x7 pitch convolutions (65 % of the network's MACs), conv_p2p_bf16_kernel
+    p2p_ms, p2p_n = prof.get("conv_p2p_bf16_kernel", (0.0, 0))
     launches_per_step = p2p_n / args.steps if args.steps else 0
-    p2p_flops = 2.0 * P2P0_MACS_PER_CLIP * B * args.steps             # the f32-MFMA launches of the pitch stack (first conv)
+    p2p_flops = 2.0 * P2P_MACS_PER_CLIP * B * args.steps              # algorithmic: (5*8 + 8*8 + 8*8) * 49 MACs per position
     achieved = p2p_flops / (p2p_ms * 1e-3) / 1e12 if p2p_ms > 0 else None
-    bf_ms, bf_n = prof_all.get("conv_p2p_bf16_kernel", (0.0, 0))
-    bf_tflops = 2.0 * P2PBF_MACS_PER_CLIP * B * bf_n / (bf_ms * 1e-3) / 1e12 if bf_ms > 0 else None
     cqt_ms = sum(prof_all.get(k, (0.0, 0))[0] for k in prof_all if k.startswith("cqt_"))
     cqt_gbs = CQT_BYTES_PER_CLIP * B * args.steps / (cqt_ms * 1e-3) / 1e9 if cqt_ms > 0 else None
     kernel_ms = {k: round(v[0] / args.steps, 4) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}
     traffic_src, traffic = pmc_traffic()
-    p2p_traffic = cqt_traffic = bf_traffic = None
+    p2p_traffic = cqt_traffic = None
     if B == 256 and traffic:
-        p2p_rows = [v for k, v in traffic.items() if k.startswith("conv_mfma_kernel<8, 1, 3") and v["hbm_bytes"] > 2e8]
-        p2p_traffic = p2p_rows[0]["hbm_bytes"] if p2p_rows else None
         bf_rows = [v for k, v in traffic.items() if k.startswith("conv_p2p_bf16_kernel")]
-        bf_traffic = round(sum(v["hbm_bytes"] * v["dispatches"] for v in bf_rows) / max(1, sum(v["dispatches"] for v in bf_rows))) if bf_rows else None
+        p2p_traffic = round(sum(v["hbm_bytes"] * v["dispatches"] for v in bf_rows) / max(1, sum(v["dispatches"] for v in bf_rows))) if bf_rows else None
         cqt_traffic = sum(v["hbm_bytes"] for k, v in traffic.items() if k.startswith("cqt_")) or None
     line = {
         "metric": "clips/s (15 s @ 22.05 kHz), HIP CQT + PitchClassNet forward",
         "value": round(value, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (8->8 pitch convs and the CQT bank as 3-term split-bf16 MFMA with f32 accumulation, ~1e-5 rel.)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 storage and accumulation; the pitch / pitch-class convolutions and the CQT filter bank multiply as 3-term split-bf16 on MFMA (hi*hi + lo*hi + hi*lo, ~1e-5 relative to f32)", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: batch={B} synthetic 15 s sine-mix clips per GPU, HIP CQT (288 bins, hop 4410) "
                                f"+ default PitchClassNet inference (genre head on), audio resident in HBM",
                    "clips_per_gpu": B, "n_samples": N_SAMPLES, "frames": T_FRAMES, "weights": "tests/golden/pcnet_default.npz (seeded)",
                    "parallelism": f"clip-sharded x{world}, no data-path collective"},
-        "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel<8,1,3> on the first pitch conv (7x7 circular, 5 -> 8 channels, f32-MFMA implicit GEMM): "
-                               "the largest single launch of the step",
-                     "achieved": round(achieved, 3) if achieved else None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_FP32_TFLOPS, 4) if achieved else None, "traffic": p2p_traffic,
-                     "traffic_source": f"profiles/{traffic_src}: HBM bytes of that launch, rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE" if p2p_traffic else None,
-                     "algorithmic_bytes_per_launch": B * (1 + 8) * P * T_FRAMES * 4,
+        "roofline": {"bound": "mfma",
+                     "kernel": "conv_p2p_bf16_kernel (7x7 circular pitch convolution, 8 channels, split-bf16 operands on v_mfma_f32_16x16x32_bf16 "
+                               "with f32 accumulation: 3 MFMA products per algorithmic MAC), 3 launches per step",
+                     "achieved": round(achieved, 2) if achieved else None, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4) if achieved else None,
+                     "mfma_products_per_mac": 3,
+                     "frac_of_split_ceiling": round(3 * achieved / PEAK_BF16_TFLOPS, 4) if achieved else None,
+                     "traffic": p2p_traffic,
+                     "traffic_source": f"profiles/{traffic_src}: mean HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE" if p2p_traffic else None,
+                     "algorithmic_bytes_per_launch": B * (8 + 8) * P * T_FRAMES * 4,
                      "avg_launch_ms": round(p2p_ms / p2p_n, 4) if p2p_n else None, "launches_per_step": launches_per_step,
-                     "algorithmic_flops_per_clip": 2 * P2P0_MACS_PER_CLIP},
-        "roofline_p2p_bf16": {"bound": "mfma", "kernel": "conv_p2p_bf16_kernel (7x7 circular, 8 -> 8 channels, split-bf16 operands: 3 bf16 MFMA products per "
-                                                        "algorithmic MAC, f32 accumulate), 2 launches per step",
-                              "achieved": round(bf_tflops, 2) if bf_tflops else None, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(3 * bf_tflops / PEAK_BF16_TFLOPS, 4) if bf_tflops else None,
-                              "frac_note": "3 x achieved / peak: every algorithmic MAC costs three bf16 MFMA MACs",
-                              "traffic": bf_traffic, "algorithmic_bytes_per_launch": B * (8 + 8) * P * T_FRAMES * 4,
-                              "avg_launch_ms": round(bf_ms / bf_n, 4) if bf_n else None,
-                              "algorithmic_flops_per_clip_per_launch": 2 * P2PBF_MACS_PER_CLIP},
+                     "algorithmic_flops_per_clip": 2 * P2P_MACS_PER_CLIP},
         "roofline_cqt": {"bound": "hbm", "kernels": " + ".join(sorted(k for k in prof_all if k.startswith("cqt_"))), "achieved": round(cqt_gbs, 1) if cqt_gbs else None,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(cqt_gbs / PEAK_HBM_GBS, 4) if cqt_gbs else None,
                          "traffic": cqt_traffic, "algorithmic_bytes_per_step": CQT_BYTES_PER_CLIP * B, "algorithmic_bytes_per_clip": CQT_BYTES_PER_CLIP,
