@@ -442,7 +442,8 @@ int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
     a.Tp = a.T_out + 8;
     a.cout = pc.cout; a.lrelu = lrelu ? 1 : 0;
     a.dst = dst_nchw; a.dst_clip_stride = static_cast<long long>(pc.cout) * 12 * a.T_out;
-    if (planes_out) { a.oh = planes_out; a.ol = planes_out + static_cast<long long>(batch) * 12 * a.T_out * 16; }
+    a.cl_stride = pc.cout;
+    if (planes_out) { a.oh = planes_out; a.ol = planes_out + static_cast<long long>(batch) * 12 * a.T_out * pc.cout; }
     const size_t lds = static_cast<size_t>(2) * 12 * a.Tp * 2 * sizeof(uint4);
     AKE_REQUIRE(lds <= 150 * 1024, AKE_ERR_UNSUPPORTED, "conv %s: %d frames do not fit the bf16 kernel's LDS patch", name, T_in);
     static bool attr_set = false;
@@ -450,6 +451,7 @@ int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
         AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
     const int tiles = (12 * a.T_out + 15) / 16;
@@ -458,6 +460,7 @@ int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
     ake::ProfScope ps(name, s);
     if (pc.cout == 16 && planes_out) hipLaunchKernelGGL((conv_pc_bf16_kernel<1, true>), grid, block, lds, s, a);
     else if (pc.cout == 16) hipLaunchKernelGGL((conv_pc_bf16_kernel<1, false>), grid, block, lds, s, a);
+    else if (planes_out) hipLaunchKernelGGL((conv_pc_bf16_kernel<2, true>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((conv_pc_bf16_kernel<2, false>), grid, block, lds, s, a);
     return AKE_OK;
 }
@@ -970,6 +973,13 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
         pc->bf_off = -1;
         if (pc_bf16_eligible(*pc)) { pc->bf_off = static_cast<long long>(count); count += static_cast<size_t>(48) * (pc->cout / 16) * 2 * 64; }
     }
+    std::vector<PackedConv*> h1;                              // 32 -> 1 last convolutions of the key / tonic heads (2-conv heads only)
+    if (n->head_key.size() == 2) h1.push_back(&n->head_key[1]);
+    if (n->head_tonic.size() == 2) h1.push_back(&n->head_tonic[1]);
+    for (PackedConv* pc : h1) {
+        pc->bf_off = -1;
+        if (pc->kh == 12 && pc->kw == 7 && pc->cout == 1 && pc->co == 1 && pc->cin == 32) { pc->bf_off = static_cast<long long>(count); count += static_cast<size_t>(264) * 2 * 64; }
+    }
     if (count == 0) return AKE_OK;
     if (n->bf_frags_count != count) {
         if (n->bf_frags_dev) { (void)hipFree(n->bf_frags_dev); n->bf_frags_dev = nullptr; }
@@ -987,6 +997,9 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
             hipLaunchKernelGGL(pack_pc_bf16_kernel, dim3((48 * NT * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off, n->bf_frags_dev + pc->bf_off,
                                pc->cin, pc->cout, pc->co, NT);
         }
+    for (const PackedConv* pc : h1)
+        if (pc->bf_off >= 0)
+            hipLaunchKernelGGL(pack_head1_bf16_kernel, dim3((264 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off, n->bf_frags_dev + pc->bf_off, pc->cin);
     AKE_HIP_CHECK(hipGetLastError());
     return AKE_OK;
 }
@@ -1374,7 +1387,37 @@ struct Fwd {
                              n->head_tonic[0].bf_off >= 0 && Tf <= kPcBf16MaxFrames;
         unsigned short* feat_cl = b.feat_cl;
         if (head_bf) run_nchw_to_cl16(feat, n->final_ch, B, Tf, feat_cl, s);
-        for (int h = 0; h < (c.genre ? 3 : 2); ++h) {
+        // two-conv heads: conv0 leaves its 32 channels as channels-last planes and ONE launch of conv_head1_bf16_kernel finishes
+        // both the key and the tonic map
+        const int T1 = Tf - (c.kernel_size - 1), T2 = T1 - (c.kernel_size - 1);
+        const bool head1_bf = head_bf && c.head_layers == 2 && n->head_key[1].bf_off >= 0 && n->head_tonic[1].bf_off >= 0 && T2 > 0 &&
+                              (12 * ((T2 + 15) / 16) + 15) / 16 <= kHead1MT;
+        if (head1_bf) {
+            Head1BfArgs ha;
+            std::memset(&ha, 0, sizeof(ha));
+            float* maps[2] = {b.map_k, b.map_t};
+            float* hids[2] = {b.hid_k, b.hid_t};
+            const PackedConv* c0[2] = {&n->head_key[0], &n->head_tonic[0]};
+            const PackedConv* c1[2] = {&n->head_key[1], &n->head_tonic[1]};
+            for (int h = 0; h < 2; ++h) {
+                unsigned short* planes = reinterpret_cast<unsigned short*>(hids[h]);
+                if ((rc = run_pc_bf16(n, *c0[h], feat_cl, B, Tf, false, true, nullptr, planes, s, "conv_pc_bf16_kernel/head"))) return rc;
+                ha.xh[h] = planes; ha.xl[h] = planes + static_cast<long long>(B) * 12 * T1 * 32;
+                ha.bfrag[h] = n->bf_frags_dev + c1[h]->bf_off; ha.bias[h] = n->blob_dev + c1[h]->b_off; ha.dst[h] = maps[h];
+            }
+            ha.T_in = T1; ha.T_out = T2; ha.JB = (T2 + 15) / 16; ha.Tp = 16 * (ha.JB - 1) + 22;
+            const size_t lds = static_cast<size_t>(2) * 12 * ha.Tp * 4 * sizeof(uint4) + static_cast<size_t>(8) * kHead1MT * 4 * 64 * sizeof(float);
+            static bool h1_attr = false;
+            if (!h1_attr) {
+                AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head1_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                h1_attr = true;
+            }
+            AKE_REQUIRE(lds <= 150 * 1024, AKE_ERR_UNSUPPORTED, "heads: %d frames do not fit conv_head1_bf16_kernel", T1);
+            ake::ProfScope ps("conv_head1_bf16_kernel", s);
+            hipLaunchKernelGGL(conv_head1_bf16_kernel, dim3(B, 2), dim3(512), lds, s, ha);
+            Tm = T2;
+        }
+        for (int h = head1_bf ? 2 : 0; h < (c.genre ? 3 : 2); ++h) {
             const float* src = feat;
             const float* src_aff = feat_aff;
             int hc = n->final_ch, Tcur = Tf;

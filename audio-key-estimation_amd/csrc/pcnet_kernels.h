@@ -686,9 +686,9 @@ struct PcBfArgs {
     const float* bias;            // [cout]
     float* dst;                   // NCHW f32 [clip][dst_ctot][12][T_out] (OUT_CL == false)
     long long dst_clip_stride;
-    unsigned short* oh;           // channels-last planes [clip][12][T_out][16] (OUT_CL == true, cout == 16)
+    unsigned short* oh;           // channels-last planes [clip][12][T_out][cl_stride] (OUT_CL == true; cl_stride = cout = 16 or 32)
     unsigned short* ol;
-    int T_in, T_out, pad_l, Tp, cout, lrelu;
+    int T_in, T_out, pad_l, Tp, cout, lrelu, cl_stride;
 };
 
 template <int NT, bool OUT_CL>
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
                     float v = acc[mt][nt][i] + bias;
                     if (a.lrelu) v = v > 0.f ? v : v * kSlope;
                     if (OUT_CL) {
-                        const long long idx = ((static_cast<long long>(clip) * 12 + y) * a.T_out + t) * 16 + co;
+                        const long long idx = ((static_cast<long long>(clip) * 12 + y) * a.T_out + t) * a.cl_stride + co;
                         const unsigned int hb = bf16_bits(v);
                         a.oh[idx] = static_cast<unsigned short>(hb);
                         a.ol[idx] = static_cast<unsigned short>(bf16_bits(v - __uint_as_float(hb << 16)));
@@ -804,6 +804,129 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
             }
         }
     }
+}
+
+// ==========================================================================================
+// Last convolution of the key / tonic heads: 32 channels -> ONE map, 12 x 7 over circular pitch classes, valid in time
+// (models.py:730-731).  With a single output channel the N dimension of the MFMA is filled with 16 output FRAMES (Toeplitz in
+// time), the K dimension with the 32 input channels of one tap -- channels-last split planes [clip][12][T_in][32] again:
+//   m = (frame block jb, pitch class y)     A[m][k = ci] = X[(y + dy) mod 12][16 jb + dxe][ci]
+//   n = tau (frame within the block)        B[k][n] = w[ci][dy][dxe - tau]   (zero outside the 7 taps)
+//   k-step = (dy, dxe): 12 x 22 = 264, split over the 8 waves of the workgroup (one workgroup per clip and head); the partial
+//   tiles are reduced through LDS.  The implicit-GEMM f32 kernel needed 100 us per launch for these 0.8 M MACs per clip.
+// ==========================================================================================
+struct Head1BfArgs {
+    const unsigned short* xh[2];  // per head: [clip][12][T_in][32]
+    const unsigned short* xl[2];
+    const uint4* bfrag[2];        // per head: [264 k-steps][hi|lo][64 lanes]
+    const float* bias[2];
+    float* dst[2];                // per head: [clip][12][T_out]
+    int T_in, T_out, Tp, JB;
+};
+
+constexpr int kHead1MT = 4;       // M-tiles (12 * JB positions / 16): T_out <= 80
+
+__global__ __launch_bounds__(512) void conv_head1_bf16_kernel(Head1BfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+    const int clip = blockIdx.x, head = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int Tp = a.Tp;
+    uint4* const pH = lds4;                                  // [12][Tp][4 groups of 8 channels]
+    uint4* const pL = lds4 + 12 * Tp * 4;
+    float* const red = reinterpret_cast<float*>(lds4 + 2 * 12 * Tp * 4);      // [8 waves][kHead1MT][4][64]
+    {
+        const long long cbase = static_cast<long long>(clip) * 12 * a.T_in * 4;
+        const uint4* gh = reinterpret_cast<const uint4*>(a.xh[head]) + cbase;
+        const uint4* gl = reinterpret_cast<const uint4*>(a.xl[head]) + cbase;
+        const int n16 = 12 * Tp * 4;
+        for (int i = threadIdx.x; i < n16; i += blockDim.x) {
+            const int grp = i & 3, pos = i >> 2;
+            const int row = pos / Tp, f = pos - row * Tp;
+            uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+            if (f < a.T_in) {
+                const long long g = (static_cast<long long>(row) * a.T_in + f) * 4 + grp;
+                vh = gh[g]; vl = gl[g];
+            }
+            pH[i] = vh; pL[i] = vl;
+        }
+    }
+    __syncthreads();
+    const int Mtot = 12 * a.JB;
+    const int mtiles = (Mtot + 15) / 16;
+    int ay[kHead1MT], af[kHead1MT];
+#pragma unroll
+    for (int mt = 0; mt < kHead1MT; ++mt) {
+        int m = mt * 16 + r16;
+        if (m >= Mtot) m = Mtot - 1;
+        const int jb = m / 12;
+        ay[mt] = m - jb * 12;
+        af[mt] = 16 * jb;
+    }
+    typedef float f32x4c __attribute__((ext_vector_type(4)));
+    f32x4c acc[kHead1MT];
+#pragma unroll
+    for (int mt = 0; mt < kHead1MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
+    const uint4* __restrict__ bg = a.bfrag[head] + lane;
+    for (int ks = wave; ks < 264; ks += 8) {
+        const int dy = ks / 22, dxe = ks - dy * 22;
+        const bf16x8c bh = __builtin_bit_cast(bf16x8c, bg[(2 * ks + 0) * 64]);
+        const bf16x8c bl = __builtin_bit_cast(bf16x8c, bg[(2 * ks + 1) * 64]);
+#pragma unroll
+        for (int mt = 0; mt < kHead1MT; ++mt) {
+            if (mt < mtiles) {
+                int row = ay[mt] + dy;
+                row -= row >= 12 ? 12 : 0;
+                const int ad = ((row * Tp + af[mt] + dxe) << 2) + q;
+                const bf16x8c ah = __builtin_bit_cast(bf16x8c, pH[ad]);
+                const bf16x8c al = __builtin_bit_cast(bf16x8c, pL[ad]);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[mt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < kHead1MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[((wave * kHead1MT + mt) * 4 + i) * 64 + lane] = acc[mt][i];
+    __syncthreads();
+    // wave w finishes M-tile w: D[row m = 4q + i][col tau]
+    if (wave < mtiles) {
+        const float bias = a.bias[head][0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = bias;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[((w * kHead1MT + wave) * 4 + i) * 64 + lane];
+            const int m = wave * 16 + 4 * q + i;
+            const int jb = m / 12, y = m - jb * 12;
+            const int t = 16 * jb + r16;
+            if (m < Mtot && t < a.T_out) a.dst[head][(static_cast<long long>(clip) * 12 + y) * a.T_out + t] = v;
+        }
+    }
+}
+
+// weight fragments of conv_head1_bf16_kernel from the VALU-layout eval pack [ci][12][7] (cout == 1): one thread per (k-step, lane)
+__global__ void pack_head1_bf16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 264 * 64) return;
+    const int lane = i & 63, ks = i >> 6;
+    const int dy = ks / 22, dxe = ks - dy * 22;
+    const int tau = lane & 15, qq = lane >> 4;
+    const int dx = dxe - tau;
+    unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+    for (int e = 0; e < 8; ++e) {
+        const int ci = 8 * qq + e;
+        float v = 0.f;
+        if (dx >= 0 && dx < 7 && ci < cin) v = w[(ci * 12 + dy) * 7 + dx];
+        const unsigned int hb = bf16_bits(v);
+        hi[e >> 1] |= hb << (16 * (e & 1));
+        lo[e >> 1] |= bf16_bits(v - __uint_as_float(hb << 16)) << (16 * (e & 1));
+    }
+    out[(2 * ks + 0) * 64 + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    out[(2 * ks + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
 // weight fragments of conv_pc_bf16_kernel from the VALU-layout eval pack [co group of CO][ci][12][7][CO]: one thread per (k-step, N-tile, lane)
