@@ -390,11 +390,12 @@ bool pc2pc_uses_bf16(const ake_pcnet* n, int i, int T) {
 }
 
 // 8 -> 8 channel 7x7 pitch convolution on bf16 MFMA (conv_p2p_bf16_kernel): channels-last split planes in, planes or NCHW f32 out
-int run_p2p_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const unsigned short* xl, int batch, int H, int T,
+int run_p2p_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const unsigned short* xl, const Src* nchw, int batch, int H, int T,
                  float* dst_nchw, int dst_ctot, unsigned short* oh, unsigned short* ol, hipStream_t s, const char* name) {
     P2pBfArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.xh = xh; a.xl = xl; a.bfrag = n->bf_frags_dev + pc.bf_off; a.bias = n->blob_dev + pc.b_off;
+    a.xh = xh; a.xl = xl;
+    if (nchw) { a.p = nchw->p0; a.c0 = nchw->c0; a.u = nchw->p1; a.c1 = nchw->c1; a.h1 = nchw->h1 > 0 ? nchw->h1 : 1; } a.bfrag = n->bf_frags_dev + pc.bf_off; a.bias = n->blob_dev + pc.b_off;
     a.dst = dst_nchw; a.dst_clip_stride = static_cast<long long>(dst_ctot) * H * T; a.dst_coff = 0;
     a.oh = oh; a.ol = ol;
     a.H = H; a.T = T;
@@ -407,14 +408,17 @@ int run_p2p_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short*
     a.n_row_tiles = (H + a.R - 1) / a.R;
     static bool attr_set = false;
     if (!attr_set) {
-        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
     dim3 grid(a.n_row_tiles, 1, batch), block(512);
     ake::ProfScope ps(name, s);
-    if (oh) hipLaunchKernelGGL(conv_p2p_bf16_kernel<true>, grid, block, lds_of(a.R), s, a);
-    else hipLaunchKernelGGL(conv_p2p_bf16_kernel<false>, grid, block, lds_of(a.R), s, a);
+    AKE_REQUIRE(!nchw || oh, AKE_ERR_STATE, "conv %s: the assembling variant writes channels-last planes", name);
+    if (nchw) hipLaunchKernelGGL((conv_p2p_bf16_kernel<true, true>), grid, block, lds_of(a.R), s, a);
+    else if (oh) hipLaunchKernelGGL((conv_p2p_bf16_kernel<true, false>), grid, block, lds_of(a.R), s, a);
+    else hipLaunchKernelGGL((conv_p2p_bf16_kernel<false, false>), grid, block, lds_of(a.R), s, a);
     return AKE_OK;
 }
 
@@ -1278,19 +1282,12 @@ struct Fwd {
                 if (bf) {
                     unsigned short* oh = reinterpret_cast<unsigned short*>(out);
                     const bool last_conv = j == c.conv_layers - 1;
-                    if (j == 0) {   // the stack's input (pitch stream | repeated up_sixth output) as channels-last planes, parked in the OTHER buffer
-                        unsigned short* ih = reinterpret_cast<unsigned short*>(b.pb[i]);
-                        const long long npos = static_cast<long long>(B) * P * Ti;
-                        {
-                            ake::ProfScope ps("p2p_input_cl8_kernel", s);
-                            hipLaunchKernelGGL(p2p_input_cl8_kernel, dim3(static_cast<unsigned>((npos + 255) / 256)), dim3(256), 0, s, sdesc.p0, sdesc.c0,
-                                               sdesc.p1, sdesc.c1, sdesc.h1 > 0 ? sdesc.h1 : 1, P, Ti, ih, ih + plane, npos);
-                        }
-                        if ((rc = run_p2p_bf16(n, n->p2p[i][0], ih, ih + plane, B, P, Ti, nullptr, d.out_p, oh, oh + plane, s, "conv_p2p_bf16_kernel")))
+                    if (j == 0) {   // the stack's input (pitch stream | repeated up_sixth output) is assembled by the kernel's own loader
+                        if ((rc = run_p2p_bf16(n, n->p2p[i][0], nullptr, nullptr, &sdesc, B, P, Ti, nullptr, d.out_p, oh, oh + plane, s, "conv_p2p_bf16_kernel")))
                             return rc;
                     } else {
                         const unsigned short* xh = reinterpret_cast<const unsigned short*>(((j - 1) & 1) ? b.pb[i] : b.pa[i]);
-                        if ((rc = run_p2p_bf16(n, n->p2p[i][j], xh, xh + plane, B, P, Ti, last_conv ? out : nullptr, d.out_p, last_conv ? nullptr : oh,
+                        if ((rc = run_p2p_bf16(n, n->p2p[i][j], xh, xh + plane, nullptr, B, P, Ti, last_conv ? out : nullptr, d.out_p, last_conv ? nullptr : oh,
                                                last_conv ? nullptr : oh + plane, s, "conv_p2p_bf16_kernel")))
                             return rc;
                     }

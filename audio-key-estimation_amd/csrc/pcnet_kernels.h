@@ -562,8 +562,14 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
 // Output: NCHW f32 (for the semitone pooling that follows the stack) or channels-last split planes (next conv).
 // ==========================================================================================
 struct P2pBfArgs {
-    const unsigned short* xh;     // [clip][H][T][8]
+    const unsigned short* xh;     // [clip][H][T][8]   (IN_NCHW == false)
     const unsigned short* xl;
+    // IN_NCHW == true (first convolution of a stack): the input is assembled while staging, channels [0, c0) from the pitch stream
+    // p [clip][c0][H][T], channels [c0, c0 + c1) from the up_sixth output u [clip][c1][h1][T] repeated over the octaves (row % h1;
+    // models.py:140-143, 378-383), the rest zero -- the concatenated tensor never exists in memory
+    const float* p;
+    const float* u;
+    int c0, c1, h1;
     const uint4* bfrag;           // [14 k-steps][hi|lo][64 lanes] x 8 bf16
     const float* bias;            // [8] (BatchNorm folded)
     float* dst;                   // NCHW f32 [clip][dst_ctot][H][T] (OUT_CL == false)
@@ -576,7 +582,7 @@ struct P2pBfArgs {
 
 typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
 
-template <bool OUT_CL>
+template <bool OUT_CL, bool IN_NCHW>
 __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
     const int clip = blockIdx.z;
@@ -602,9 +608,26 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
             row += row < 0 ? a.H : 0;
             row -= row >= a.H ? a.H : 0;
             const int t = wrap(f - 3, a.T);
-            const long long g = static_cast<long long>(row) * a.T + t;
-            pH[i] = gh[g];
-            pL[i] = gl[g];
+            if (IN_NCHW) {
+                unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+                const int ru = row % a.h1;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (c < a.c0 + a.c1) {
+                        const float v = c < a.c0 ? a.p[((static_cast<long long>(clip) * a.c0 + c) * a.H + row) * a.T + t]
+                                                 : a.u[((static_cast<long long>(clip) * a.c1 + (c - a.c0)) * a.h1 + ru) * a.T + t];
+                        const unsigned int hb = bf16_bits(v);
+                        hi[c >> 1] |= hb << (16 * (c & 1));
+                        lo[c >> 1] |= bf16_bits(v - __uint_as_float(hb << 16)) << (16 * (c & 1));
+                    }
+                }
+                pH[i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                pL[i] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            } else {
+                const long long g = static_cast<long long>(row) * a.T + t;
+                pH[i] = gh[g];
+                pL[i] = gl[g];
+            }
         }
         for (int i = threadIdx.x; i < 14 * 2 * 64; i += blockDim.x) pB[i] = a.bfrag[i];
     }
@@ -975,28 +998,6 @@ __global__ void nchw_to_cl16_kernel(const float* __restrict__ src, long long src
     uint4* ol = reinterpret_cast<uint4*>(xl) + i * 2;
     oh[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); oh[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
     ol[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]); ol[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
-}
-
-// Input of a Pitch2Pitch stack as channels-last split planes [clip][H][T][8]: channels [0, c0) = the pitch stream p [clip][c0][H][T],
-// channels [c0, c0 + c1) = the up_sixth output [clip][c1][h1][T] repeated over the octaves (row % h1: PitchClass2Pitch, models.py:140-143),
-// the rest zero -- what torch.cat((p, pc2p(up_sixth(pc))), 1) materialises in the reference (models.py:378-383).
-__global__ void p2p_input_cl8_kernel(const float* __restrict__ p, int c0, const float* __restrict__ u, int c1, int h1, int H, int T,
-                                     unsigned short* __restrict__ xh, unsigned short* __restrict__ xl, long long npos) {
-    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;      // (clip, row, t)
-    if (i >= npos) return;
-    const int t = static_cast<int>(i % T);
-    const long long r = i / T;
-    const int y = static_cast<int>(r % H);
-    const long long clip = r / H;
-    unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
-    for (int c = 0; c < c0 + c1 && c < 8; ++c) {
-        const float v = c < c0 ? p[((clip * c0 + c) * H + y) * T + t] : u[((clip * c1 + (c - c0)) * h1 + (y % h1)) * T + t];
-        const unsigned int hb = bf16_bits(v);
-        hi[c >> 1] |= hb << (16 * (c & 1));
-        lo[c >> 1] |= bf16_bits(v - __uint_as_float(hb << 16)) << (16 * (c & 1));
-    }
-    reinterpret_cast<uint4*>(xh)[i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    reinterpret_cast<uint4*>(xl)[i] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
 // debug taps: channels-last split planes [clip][H][T][C] -> NCHW f32 [clip][C][H][T]

@@ -88,7 +88,7 @@ def test_kernel_timer_reports_the_launched_kernels(net):
     est(audio)
     res = ake_amd._lib.prof_results()
     ake_amd._lib.prof_enable("", False)
-    assert {"cqt_bank_bf16_kernel", "cqt_cascade_kernel", "cqt_transpose_kernel", "p2p_input_cl8_kernel", "conv_p2p_bf16_kernel",
+    assert {"cqt_bank_bf16_kernel", "cqt_cascade_kernel", "cqt_transpose_kernel", "conv_p2p_bf16_kernel",
             "conv_pc_bf16_kernel/pc2pc", "conv_pc_bf16_kernel/head", "conv_head1_bf16_kernel", "head_pool_kernel"} <= set(res)
     # Pitch2Pitch stack: all three convs on the bf16x3 kernel (the 5-channel input is assembled channels-last, padded to 8)
     assert "conv_mfma_kernel/p2p" not in res and res["conv_p2p_bf16_kernel"][1] == 3
