@@ -665,29 +665,42 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt], 0, 0, 0);
     }
-    // ---- epilogue: D[row m = 4q + i][col n = 8*tau + co] ----
+    // ---- epilogue: D[row m = 4q + i][col n = 8*tau + co]; 32-bit offsets inside the clip, hardware bf16 conversion (v_cvt_pk_bf16_f32) ----
     const int tau = r16 >> 3, co = r16 & 7;
     const float bias = a.bias[co];
+    typedef float f32x2e __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2e __attribute__((ext_vector_type(2)));
+    unsigned short* const oh = OUT_CL ? a.oh + static_cast<long long>(clip) * a.H * a.T * 8 + co : nullptr;
+    unsigned short* const ol = OUT_CL ? a.ol + static_cast<long long>(clip) * a.H * a.T * 8 + co : nullptr;
+    float* const od = OUT_CL ? nullptr : a.dst + clip * a.dst_clip_stride + static_cast<long long>(a.dst_coff + co) * a.H * a.T;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m0 = (wave * MT + mt) * 16 + 4 * q;
         int r = m0 / J, j = m0 - r * J;
+        float v[4];
+        int pos[4];                                              // position (row * T + frame) inside the clip, or -1
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int t = 2 * j + tau;
-            if (m0 + i < Mblk && t < a.T) {
-                float v = acc[mt][i] + bias;
-                v = v > 0.f ? v : v * kSlope;
-                if (OUT_CL) {
-                    const long long idx = ((static_cast<long long>(clip) * a.H + (y0 + r)) * a.T + t) * 8 + co;
-                    const unsigned int hb = bf16_bits(v);
-                    a.oh[idx] = static_cast<unsigned short>(hb);
-                    a.ol[idx] = static_cast<unsigned short>(bf16_bits(v - __uint_as_float(hb << 16)));
-                } else {
-                    a.dst[clip * a.dst_clip_stride + (static_cast<long long>(a.dst_coff + co) * a.H + (y0 + r)) * a.T + t] = v;
-                }
-            }
+            const float x = acc[mt][i] + bias;
+            v[i] = x > 0.f ? x : x * kSlope;
+            pos[i] = (m0 + i < Mblk && t < a.T) ? (y0 + r) * a.T + t : -1;
             if (++j == J) { j = 0; ++r; }
+        }
+        if (OUT_CL) {
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                const f32x2e x = {v[i], v[i + 1]};
+                const bf16x2e h = __builtin_convertvector(x, bf16x2e);
+                const bf16x2e l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2e), bf16x2e);
+                const unsigned int hp = __builtin_bit_cast(unsigned int, h), lp = __builtin_bit_cast(unsigned int, l);
+                if (pos[i] >= 0) { oh[pos[i] * 8] = static_cast<unsigned short>(hp); ol[pos[i] * 8] = static_cast<unsigned short>(lp); }
+                if (pos[i + 1] >= 0) { oh[pos[i + 1] * 8] = static_cast<unsigned short>(hp >> 16); ol[pos[i + 1] * 8] = static_cast<unsigned short>(lp >> 16); }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (pos[i] >= 0) od[pos[i]] = v[i];
         }
     }
 }
