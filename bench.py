@@ -265,7 +265,7 @@ def main():
                          "traffic": cqt_traffic, "algorithmic_bytes_per_step": CQT_BYTES_PER_CLIP * B, "algorithmic_bytes_per_clip": CQT_BYTES_PER_CLIP,
                          "stage_ms_per_step": round(cqt_ms / args.steps, 4)},
         "kernel_ms_per_step": kernel_ms,
-        "net_fp32_frac_of_peak": round(2.0 * NET_MACS_PER_CLIP * value / world / (PEAK_FP32_TFLOPS * 1e12), 4),
+        "net_algorithmic_tflops": round(2.0 * NET_MACS_PER_CLIP * value / world / 1e12, 2),
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(sd)
