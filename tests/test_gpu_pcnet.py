@@ -171,6 +171,19 @@ def test_full_size_batch_properties(gold_default):
         assert rel_err(a.cpu(), b) < TOL
 
 
+def test_batch_larger_than_the_pitch_stream_chunk(gold_default):
+    """B = 300 > the 256-clip chunk of the pitch stream: the second chunk (44 clips) reuses the ping-pong buffers of the first;
+    the pitch-class stack and the heads run batch-wide.  Every clip must equal its result in a batch of its own."""
+    net, _ = make_net(gold_default)
+    g = torch.Generator().manual_seed(21)
+    x = (torch.rand((300, 1, 288, 40), generator=g) * 2.5).to(DEV)
+    seq = torch.randint(30, 41, (300,), generator=g).to(DEV)
+    key, tonic, genre = net(x, seq)
+    idx = [0, 255, 256, 257, 299]
+    ks, ts, gs = net(x[idx], seq[idx])
+    assert torch.equal(ks, key[idx]) and torch.equal(ts, tonic[idx]) and torch.equal(gs, genre[idx])
+
+
 def test_edge_shapes(gold_default):
     net, _ = make_net(gold_default)
     sd = golden_state_dict(gold_default, torch.float64)
