@@ -81,7 +81,9 @@ struct Bwd {
         a.n_row_tiles = (a.H_out + R - 1) / R;
         a.n_time_tiles = (a.T_out + TT - 1) / TT;
         const int tiles = a.n_row_tiles * a.n_time_tiles;
-        wa.rt_per_block = std::max(1, (tiles + 3) / 4);          // up to 4 workgroups per clip
+        // workgroups per clip: 4 at training batch sizes (fewer atomics), more for small batches so that the chip still fills
+        const int wgs_per_clip = std::min(tiles, std::max(4, (512 + B - 1) / B));
+        wa.rt_per_block = std::max(1, (tiles + wgs_per_clip - 1) / wgs_per_clip);
         dim3 grid((tiles + wa.rt_per_block - 1) / wa.rt_per_block, 1, B), block(512);
         const size_t lds = lds_of(R, TT);
         ake::ProfScope ps(name, s);
