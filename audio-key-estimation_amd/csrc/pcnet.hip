@@ -1160,7 +1160,7 @@ struct Fwd {
         a.w = n->blob_dev + pc.w_off; a.bias = n->blob_dev + pc.b_off;
         a.dst = b.semi_raw[layer]; a.dst_coff = 0; a.dst_clip_stride = 0;
         a.n_strips = (Tn + TW - 1) / TW;
-        ta.in_affine = in_aff; ta.stats = b.stats + 2 * n->bns[bn].ch_off;
+        ta.in_affine = in_aff; ta.stats = b.stats + 2 * n->bns[bn].ch_off; ta.stats_stride = 2 * n->bn_channels;
         const int per_clip = 12 * a.n_strips;
         const int threads = per_clip >= 256 ? 256 : (per_clip + 63) / 64 * 64;
         dim3 grid((per_clip + threads - 1) / threads, pc.groups, B), block(threads);
@@ -1197,7 +1197,7 @@ struct Fwd {
             ake::ProfScope ps("up_sixth_train_kernel", s);
             hipLaunchKernelGGL(up_sixth_train_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, src, src_clip_stride,
                                in_aff, n->blob_dev + n->up_t[layer].w_off, n->blob_dev + n->up_t[layer].b_off, dst,
-                               b.stats + 2 * n->bns[bn].ch_off, C, Tn, total);
+                               b.stats + 2 * n->bns[bn].ch_off, 2 * n->bn_channels, C, Tn, total);
         }
         finalize_bn(bn, static_cast<double>(B) * 36 * Tn, aff_dst);
     }

@@ -1063,12 +1063,13 @@ __device__ __forceinline__ float affine_act(float x, const float* aff, int c) {
 }
 
 // wave-level (sum, sumsq) -> one double atomic pair per wave
-__device__ __forceinline__ void stats_commit(double* stats, int c, float s1, float s2) {
+__device__ __forceinline__ void stats_commit(double* stats, int stats_stride, int c, float s1, float s2) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(stats + 2 * c, static_cast<double>(s1));
-        atomicAdd(stats + 2 * c + 1, static_cast<double>(s2));
+        double* st = stats + static_cast<size_t>((blockIdx.x + 7 * blockIdx.z + (threadIdx.x >> 6)) & (kStatSlots - 1)) * stats_stride;
+        atomicAdd(st + 2 * c, static_cast<double>(s1));
+        atomicAdd(st + 2 * c + 1, static_cast<double>(s2));
     }
 }
 
@@ -1077,7 +1078,8 @@ __device__ __forceinline__ void stats_commit(double* stats, int c, float s1, flo
 struct SemiTrainArgs {
     SemiArgs s;               // dst = raw [B][C][H/3][T] (dst_coff / dst_clip_stride unused: dense)
     const float* in_affine;   // [C][3] or null
-    double* stats;            // [C][2]
+    double* stats;            // [kStatSlots][..][2]
+    int stats_stride;
 };
 
 template <int CO>
@@ -1144,7 +1146,7 @@ __global__ void semi_conv_stats_kernel(SemiTrainArgs ta) {
 #pragma unroll
     for (int co = 0; co < CO; ++co) {
         const int c = grp * CO + co;
-        if (c < a.C) stats_commit(ta.stats, c, s1[co], s2[co]);
+        if (c < a.C) stats_commit(ta.stats, ta.stats_stride, c, s1[co], s2[co]);
     }
 }
 
@@ -1168,7 +1170,7 @@ __global__ void fold_affine_kernel(const float* __restrict__ src, const float* _
 // up_sixth in training mode: raw ConvTranspose2d output + statistics; input carries a pending affine.
 __global__ void up_sixth_train_kernel(const float* __restrict__ src, long long src_clip_stride, const float* __restrict__ in_aff,
                                       const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ dst,
-                                      double* __restrict__ stats, int C, int T, long long total) {
+                                      double* __restrict__ stats, int stats_stride, int C, int T, long long total) {
     __shared__ double sh[2 * 128];
     for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) sh[k] = 0.0;
     __syncthreads();
@@ -1190,7 +1192,7 @@ __global__ void up_sixth_train_kernel(const float* __restrict__ src, long long s
     }
     __syncthreads();
     for (int k = threadIdx.x; k < 2 * C; k += blockDim.x)
-        if (sh[k] != 0.0) atomicAdd(stats + k, sh[k]);
+        if (sh[k] != 0.0) atomicAdd(stats + static_cast<size_t>(blockIdx.x & (kStatSlots - 1)) * stats_stride + k, sh[k]);
 }
 
 // time pooling with a pending affine on the input
