@@ -581,6 +581,7 @@ struct P2pBfArgs {
 };
 
 typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
+constexpr bool kP2pStreamB = true;
 
 template <bool OUT_CL, bool IN_NCHW>
 __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
@@ -629,7 +630,8 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
                 pL[i] = gl[g];
             }
         }
-        for (int i = threadIdx.x; i < 14 * 2 * 64; i += blockDim.x) pB[i] = a.bfrag[i];
+        if (!kP2pStreamB)
+            for (int i = threadIdx.x; i < 14 * 2 * 64; i += blockDim.x) pB[i] = a.bfrag[i];
     }
     __syncthreads();
     constexpr int MT = 3;
@@ -646,11 +648,20 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
     f32x4c acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
+    const uint4* __restrict__ bg = a.bfrag + lane;
+    uint4 nbh = bg[0], nbl = bg[64];
 #pragma unroll 2
     for (int ks = 0; ks < 14; ++ks) {
         const int dy = ks >> 1, h = ks & 1;
-        const bf16x8c bh = __builtin_bit_cast(bf16x8c, pB[(2 * ks + 0) * 64 + lane]);
-        const bf16x8c bl = __builtin_bit_cast(bf16x8c, pB[(2 * ks + 1) * 64 + lane]);
+        bf16x8c bh, bl;
+        if (kP2pStreamB) {   // weight fragments straight from L2, one k-step ahead: 28 KB less LDS per workgroup -> 3 workgroups per CU
+            bh = __builtin_bit_cast(bf16x8c, nbh); bl = __builtin_bit_cast(bf16x8c, nbl);
+            const int kn = ks + 1 < 14 ? ks + 1 : ks;
+            nbh = bg[(2 * kn + 0) * 64]; nbl = bg[(2 * kn + 1) * 64];
+        } else {
+            bh = __builtin_bit_cast(bf16x8c, pB[(2 * ks + 0) * 64 + lane]);
+            bl = __builtin_bit_cast(bf16x8c, pB[(2 * ks + 1) * 64 + lane]);
+        }
         bf16x8c ah[MT], al[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
