@@ -401,7 +401,7 @@ int run_p2p_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short*
     a.H = H; a.T = T;
     a.J = (T + 1) / 2;
     a.Tp = 2 * a.J + 6;
-    a.R = std::max(1, std::min(H, 8 * 3 * 16 / a.J));
+    a.R = std::max(1, std::min(H, 8 * kP2pMT * 16 / a.J));
     auto lds_of = [&](int R) { return (static_cast<size_t>(2) * (R + 6) * a.Tp + (kP2pStreamB ? 0 : kBfFragsPerConv)) * sizeof(uint4); };
     while (a.R > 1 && lds_of(a.R) > 76 * 1024) --a.R;
     AKE_REQUIRE(lds_of(a.R) <= 150 * 1024, AKE_ERR_UNSUPPORTED, "conv %s: %d frames do not fit the bf16 kernel's LDS patch", name, T);

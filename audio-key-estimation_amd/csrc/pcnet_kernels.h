@@ -582,6 +582,7 @@ struct P2pBfArgs {
 
 typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
 constexpr bool kP2pStreamB = true;
+constexpr int kP2pMT = 3;            // M-tiles (16 positions) per wave
 
 template <bool OUT_CL, bool IN_NCHW>
 __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
@@ -634,7 +635,7 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
             for (int i = threadIdx.x; i < 14 * 2 * 64; i += blockDim.x) pB[i] = a.bfrag[i];
     }
     __syncthreads();
-    constexpr int MT = 3;
+    constexpr int MT = kP2pMT;
     if (wave * MT * 16 >= Mblk) return;
     int abase[MT];
 #pragma unroll
