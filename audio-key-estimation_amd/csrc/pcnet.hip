@@ -445,9 +445,11 @@ int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
     AKE_REQUIRE(a.T_out > 0, AKE_ERR_INVALID, "conv %s: %d frames is too short for the valid head convolutions", name, T_in);
     a.Tp = a.T_out + 8;
     a.cout = pc.cout; a.lrelu = lrelu ? 1 : 0;
-    a.dst = dst_nchw; a.dst_clip_stride = static_cast<long long>(pc.cout) * 12 * a.T_out;
+    a.KH = pc.kh; a.circular = pc.kh == 12 ? 1 : 0;
+    const int H_out = a.circular ? 12 : 12 - pc.kh + 1;
+    a.dst = dst_nchw; a.dst_clip_stride = static_cast<long long>(pc.cout) * H_out * a.T_out;
     a.cl_stride = pc.cout;
-    if (planes_out) { a.oh = planes_out; a.ol = planes_out + static_cast<long long>(batch) * 12 * a.T_out * pc.cout; }
+    if (planes_out) { a.oh = planes_out; a.ol = planes_out + static_cast<long long>(batch) * H_out * a.T_out * pc.cout; }
     const size_t lds = static_cast<size_t>(2) * 12 * a.Tp * 2 * sizeof(uint4);
     AKE_REQUIRE(lds <= 150 * 1024, AKE_ERR_UNSUPPORTED, "conv %s: %d frames do not fit the bf16 kernel's LDS patch", name, T_in);
     static bool attr_set = false;
@@ -458,7 +460,7 @@ int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
         AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
-    const int tiles = (12 * a.T_out + 15) / 16;
+    const int tiles = (H_out * a.T_out + 15) / 16;
     const int waves = std::min(8, (tiles + 3) / 4);
     dim3 grid((tiles + waves * 4 - 1) / (waves * 4), 1, batch), block(waves * 64);
     ake::ProfScope ps(name, s);
@@ -958,7 +960,7 @@ int build_fold_tables(ake_pcnet* n) {
 
 // Inference runs the 8 -> 8 channel 7x7 pitch convolutions (every conv of a Pitch2Pitch stack but the first) on bf16 MFMA
 // with split operands; their weight fragments are derived on the device from the eval packs, after every (re)pack.
-bool pc_bf16_eligible(const PackedConv& pc) { return pc.kh == 12 && pc.kw == 7 && pc.cin <= 16 && (pc.cout == 16 || pc.cout == 32); }
+bool pc_bf16_eligible(const PackedConv& pc) { return (pc.kh == 12 || pc.kh == 1) && pc.kw == 7 && pc.cin <= 16 && (pc.cout == 16 || pc.cout == 32); }
 
 int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
     size_t count = 0;
@@ -973,16 +975,18 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
         for (PackedConv& pc : layer) pcs.push_back(&pc);
     if (!n->head_key.empty()) pcs.push_back(&n->head_key[0]);
     if (!n->head_tonic.empty()) pcs.push_back(&n->head_tonic[0]);
+    if (n->head_genre.size() == 2) pcs.push_back(&n->head_genre[0]);            // 1 x 7: rows independent
     for (PackedConv* pc : pcs) {
         pc->bf_off = -1;
-        if (pc_bf16_eligible(*pc)) { pc->bf_off = static_cast<long long>(count); count += static_cast<size_t>(48) * (pc->cout / 16) * 2 * 64; }
+        if (pc_bf16_eligible(*pc)) { pc->bf_off = static_cast<long long>(count); count += static_cast<size_t>(pc->kh) * 4 * (pc->cout / 16) * 2 * 64; }
     }
     std::vector<PackedConv*> h1;                              // 32 -> 1 last convolutions of the key / tonic heads (2-conv heads only)
     if (n->head_key.size() == 2) h1.push_back(&n->head_key[1]);
     if (n->head_tonic.size() == 2) h1.push_back(&n->head_tonic[1]);
+    if (n->head_genre.size() == 2) h1.push_back(&n->head_genre[1]);              // 2 x 7 over valid rows
     for (PackedConv* pc : h1) {
         pc->bf_off = -1;
-        if (pc->kh == 12 && pc->kw == 7 && pc->cout == 1 && pc->co == 1 && pc->cin == 32) { pc->bf_off = static_cast<long long>(count); count += static_cast<size_t>(264) * 2 * 64; }
+        if ((pc->kh == 12 || pc->kh == 2) && pc->kw == 7 && pc->cout == 1 && pc->co == 1 && pc->cin == 32) { pc->bf_off = static_cast<long long>(count); count += static_cast<size_t>(pc->kh) * 22 * 2 * 64; }
     }
     if (count == 0) return AKE_OK;
     if (n->bf_frags_count != count) {
@@ -998,12 +1002,13 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
     for (const PackedConv* pc : pcs)
         if (pc->bf_off >= 0) {
             const int NT = pc->cout / 16;
-            hipLaunchKernelGGL(pack_pc_bf16_kernel, dim3((48 * NT * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off, n->bf_frags_dev + pc->bf_off,
-                               pc->cin, pc->cout, pc->co, NT);
+            hipLaunchKernelGGL(pack_pc_bf16_kernel, dim3((pc->kh * 4 * NT * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
+                               n->bf_frags_dev + pc->bf_off, pc->cin, pc->cout, pc->co, NT, pc->kh);
         }
     for (const PackedConv* pc : h1)
         if (pc->bf_off >= 0)
-            hipLaunchKernelGGL(pack_head1_bf16_kernel, dim3((264 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off, n->bf_frags_dev + pc->bf_off, pc->cin);
+            hipLaunchKernelGGL(pack_head1_bf16_kernel, dim3((pc->kh * 22 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
+                               n->bf_frags_dev + pc->bf_off, pc->cin, pc->kh);
     AKE_HIP_CHECK(hipGetLastError());
     return AKE_OK;
 }
@@ -1389,18 +1394,23 @@ struct Fwd {
         const int T1 = Tf - (c.kernel_size - 1), T2 = T1 - (c.kernel_size - 1);
         const bool head1_bf = head_bf && c.head_layers == 2 && n->head_key[1].bf_off >= 0 && n->head_tonic[1].bf_off >= 0 && T2 > 0 &&
                               (12 * ((T2 + 15) / 16) + 15) / 16 <= kHead1MT;
+        const bool genre_bf = head1_bf && c.genre && n->head_genre.size() == 2 && n->head_genre[0].bf_off >= 0 && n->head_genre[1].bf_off >= 0 &&
+                              n->head_genre[0].kh == 1 && n->head_genre[1].kh == 2;
         if (head1_bf) {
             Head1BfArgs ha;
             std::memset(&ha, 0, sizeof(ha));
-            float* maps[2] = {b.map_k, b.map_t};
-            float* hids[2] = {b.hid_k, b.hid_t};
-            const PackedConv* c0[2] = {&n->head_key[0], &n->head_tonic[0]};
-            const PackedConv* c1[2] = {&n->head_key[1], &n->head_tonic[1]};
-            for (int h = 0; h < 2; ++h) {
+            float* maps[3] = {b.map_k, b.map_t, b.map_g};
+            float* hids[3] = {b.hid_k, b.hid_t, b.hid_g};
+            const PackedConv* c0[3] = {&n->head_key[0], &n->head_tonic[0], genre_bf ? &n->head_genre[0] : nullptr};
+            const PackedConv* c1[3] = {&n->head_key[1], &n->head_tonic[1], genre_bf ? &n->head_genre[1] : nullptr};
+            const int nh = genre_bf ? 3 : 2;
+            for (int h = 0; h < nh; ++h) {
                 unsigned short* planes = reinterpret_cast<unsigned short*>(hids[h]);
-                if ((rc = run_pc_bf16(n, *c0[h], feat_cl, B, Tf, false, true, nullptr, planes, s, "conv_pc_bf16_kernel/head"))) return rc;
+                if ((rc = run_pc_bf16(n, *c0[h], feat_cl, B, Tf, false, true, nullptr, planes, s, h == 2 ? "conv_pc_bf16_kernel/genre_head" : "conv_pc_bf16_kernel/head")))
+                    return rc;
                 ha.xh[h] = planes; ha.xl[h] = planes + static_cast<long long>(B) * 12 * T1 * 32;
                 ha.bfrag[h] = n->bf_frags_dev + c1[h]->bf_off; ha.bias[h] = n->blob_dev + c1[h]->b_off; ha.dst[h] = maps[h];
+                ha.KH[h] = c1[h]->kh; ha.circular[h] = c1[h]->kh == 12 ? 1 : 0; ha.H_out[h] = ha.circular[h] ? 12 : 12 - c1[h]->kh + 1;
             }
             ha.T_in = T1; ha.T_out = T2; ha.JB = (T2 + 15) / 16; ha.Tp = 16 * (ha.JB - 1) + 22;
             const size_t lds = static_cast<size_t>(2) * 12 * ha.Tp * 4 * sizeof(uint4) + static_cast<size_t>(8) * kHead1MT * 4 * 64 * sizeof(float);
@@ -1411,10 +1421,10 @@ struct Fwd {
             }
             AKE_REQUIRE(lds <= 150 * 1024, AKE_ERR_UNSUPPORTED, "heads: %d frames do not fit conv_head1_bf16_kernel", T1);
             ake::ProfScope ps("conv_head1_bf16_kernel", s);
-            hipLaunchKernelGGL(conv_head1_bf16_kernel, dim3(B, 2), dim3(512), lds, s, ha);
+            hipLaunchKernelGGL(conv_head1_bf16_kernel, dim3(B, nh), dim3(512), lds, s, ha);
             Tm = T2;
         }
-        for (int h = head1_bf ? 2 : 0; h < (c.genre ? 3 : 2); ++h) {
+        for (int h = head1_bf ? (genre_bf ? 3 : 2) : 0; h < (c.genre ? 3 : 2); ++h) {
             const float* src = feat;
             const float* src_aff = feat_aff;
             int hc = n->final_ch, Tcur = Tf;

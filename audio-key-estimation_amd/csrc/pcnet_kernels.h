@@ -730,13 +730,14 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
 struct PcBfArgs {
     const unsigned short* xh;     // [clip][12][T_in][16]
     const unsigned short* xl;
-    const uint4* bfrag;           // [48 k-steps][NT][hi|lo][64 lanes] x 8 bf16
+    const uint4* bfrag;           // [KH * 4 k-steps][NT][hi|lo][64 lanes] x 8 bf16
     const float* bias;            // [cout]
     float* dst;                   // NCHW f32 [clip][dst_ctot][12][T_out] (OUT_CL == false)
     long long dst_clip_stride;
     unsigned short* oh;           // channels-last planes [clip][12][T_out][cl_stride] (OUT_CL == true; cl_stride = cout = 16 or 32)
     unsigned short* ol;
     int T_in, T_out, pad_l, Tp, cout, lrelu, cl_stride;
+    int KH, circular;             // kernel rows (12 circular for the pitch-class convs; 1, rows independent, for the genre head's first conv)
 };
 
 template <int NT, bool OUT_CL>
@@ -749,7 +750,9 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
     const int r16 = lane & 15, q = lane >> 4;
     const int Tp = a.Tp;
     constexpr int MT = 4;
-    const int Mtot = 12 * a.T_out;
+    const int H_out = a.circular ? 12 : 12 - a.KH + 1;
+    const int Mtot = H_out * a.T_out;
+    const int nks = a.KH * 4;
     uint4* const pH = lds4;                                  // [12][Tp][2 halves of 8 channels]
     uint4* const pL = lds4 + 12 * Tp * 2;
     {   // patch frame f <-> input frame f - pad_l, zeros outside [0, T_in)
@@ -791,7 +794,7 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { nbh[nt] = bg[(nt * 2 + 0) * 64]; nbl[nt] = bg[(nt * 2 + 1) * 64]; }
     const int dxq = q >> 1, half = q & 1;
-    for (int dy = 0; dy < 12; ++dy) {
+    for (int dy = 0; dy < a.KH; ++dy) {
         int rowoff[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -805,7 +808,7 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
             bf16x8c bh[NT], bl[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { bh[nt] = __builtin_bit_cast(bf16x8c, nbh[nt]); bl[nt] = __builtin_bit_cast(bf16x8c, nbl[nt]); }
-            const int kn = ks + 1 < 48 ? ks + 1 : ks;                 // next k-step's weights, in flight during this one's MFMAs
+            const int kn = ks + 1 < nks ? ks + 1 : ks;                // next k-step's weights, in flight during this one's MFMAs
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { nbh[nt] = bg[((kn * NT + nt) * 2 + 0) * 64]; nbl[nt] = bg[((kn * NT + nt) * 2 + 1) * 64]; }
             bf16x8c ah[MT], al[MT];
@@ -840,12 +843,12 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
                     float v = acc[mt][nt][i] + bias;
                     if (a.lrelu) v = v > 0.f ? v : v * kSlope;
                     if (OUT_CL) {
-                        const long long idx = ((static_cast<long long>(clip) * 12 + y) * a.T_out + t) * a.cl_stride + co;
+                        const long long idx = ((static_cast<long long>(clip) * H_out + y) * a.T_out + t) * a.cl_stride + co;
                         const unsigned int hb = bf16_bits(v);
                         a.oh[idx] = static_cast<unsigned short>(hb);
                         a.ol[idx] = static_cast<unsigned short>(bf16_bits(v - __uint_as_float(hb << 16)));
                     } else {
-                        a.dst[clip * a.dst_clip_stride + (static_cast<long long>(co) * 12 + y) * a.T_out + t] = v;
+                        a.dst[clip * a.dst_clip_stride + (static_cast<long long>(co) * H_out + y) * a.T_out + t] = v;
                     }
                 }
                 if (++t == a.T_out) { t = 0; ++y; }
@@ -864,11 +867,12 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
 //   tiles are reduced through LDS.  The implicit-GEMM f32 kernel needed 100 us per launch for these 0.8 M MACs per clip.
 // ==========================================================================================
 struct Head1BfArgs {
-    const unsigned short* xh[2];  // per head: [clip][12][T_in][32]
-    const unsigned short* xl[2];
-    const uint4* bfrag[2];        // per head: [264 k-steps][hi|lo][64 lanes]
-    const float* bias[2];
-    float* dst[2];                // per head: [clip][12][T_out]
+    const unsigned short* xh[3];  // per head (key, tonic, genre): [clip][12][T_in][32]
+    const unsigned short* xl[3];
+    const uint4* bfrag[3];        // per head: [KH * 22 k-steps][hi|lo][64 lanes]
+    const float* bias[3];
+    float* dst[3];                // per head: [clip][H_out][T_out]
+    int KH[3], H_out[3], circular[3];   // key / tonic: 12 rows over circular pitch classes; genre: 2 rows, valid (11 output rows)
     int T_in, T_out, Tp, JB;
 };
 
@@ -901,15 +905,16 @@ __global__ __launch_bounds__(512) void conv_head1_bf16_kernel(Head1BfArgs a) {
         }
     }
     __syncthreads();
-    const int Mtot = 12 * a.JB;
+    const int HO = a.H_out[head], circ = a.circular[head], nks = a.KH[head] * 22;
+    const int Mtot = HO * a.JB;
     const int mtiles = (Mtot + 15) / 16;
     int ay[kHead1MT], af[kHead1MT];
 #pragma unroll
     for (int mt = 0; mt < kHead1MT; ++mt) {
         int m = mt * 16 + r16;
         if (m >= Mtot) m = Mtot - 1;
-        const int jb = m / 12;
-        ay[mt] = m - jb * 12;
+        const int jb = m / HO;
+        ay[mt] = m - jb * HO;
         af[mt] = 16 * jb;
     }
     typedef float f32x4c __attribute__((ext_vector_type(4)));
@@ -917,7 +922,7 @@ __global__ __launch_bounds__(512) void conv_head1_bf16_kernel(Head1BfArgs a) {
 #pragma unroll
     for (int mt = 0; mt < kHead1MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
     const uint4* __restrict__ bg = a.bfrag[head] + lane;
-    for (int ks = wave; ks < 264; ks += 8) {
+    for (int ks = wave; ks < nks; ks += 8) {
         const int dy = ks / 22, dxe = ks - dy * 22;
         const bf16x8c bh = __builtin_bit_cast(bf16x8c, bg[(2 * ks + 0) * 64]);
         const bf16x8c bl = __builtin_bit_cast(bf16x8c, bg[(2 * ks + 1) * 64]);
@@ -925,7 +930,7 @@ __global__ __launch_bounds__(512) void conv_head1_bf16_kernel(Head1BfArgs a) {
         for (int mt = 0; mt < kHead1MT; ++mt) {
             if (mt < mtiles) {
                 int row = ay[mt] + dy;
-                row -= row >= 12 ? 12 : 0;
+                row -= (circ && row >= 12) ? 12 : 0;
                 const int ad = ((row * Tp + af[mt] + dxe) << 2) + q;
                 const bf16x8c ah = __builtin_bit_cast(bf16x8c, pH[ad]);
                 const bf16x8c al = __builtin_bit_cast(bf16x8c, pL[ad]);
@@ -949,17 +954,17 @@ __global__ __launch_bounds__(512) void conv_head1_bf16_kernel(Head1BfArgs a) {
 #pragma unroll
             for (int w = 0; w < 8; ++w) v += red[((w * kHead1MT + wave) * 4 + i) * 64 + lane];
             const int m = wave * 16 + 4 * q + i;
-            const int jb = m / 12, y = m - jb * 12;
+            const int jb = m / HO, y = m - jb * HO;
             const int t = 16 * jb + r16;
-            if (m < Mtot && t < a.T_out) a.dst[head][(static_cast<long long>(clip) * 12 + y) * a.T_out + t] = v;
+            if (m < Mtot && t < a.T_out) a.dst[head][(static_cast<long long>(clip) * HO + y) * a.T_out + t] = v;
         }
     }
 }
 
 // weight fragments of conv_head1_bf16_kernel from the VALU-layout eval pack [ci][12][7] (cout == 1): one thread per (k-step, lane)
-__global__ void pack_head1_bf16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin) {
+__global__ void pack_head1_bf16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin, int KH) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 264 * 64) return;
+    if (i >= KH * 22 * 64) return;
     const int lane = i & 63, ks = i >> 6;
     const int dy = ks / 22, dxe = ks - dy * 22;
     const int tau = lane & 15, qq = lane >> 4;
@@ -968,7 +973,7 @@ __global__ void pack_head1_bf16_kernel(const float* __restrict__ w, uint4* __res
     for (int e = 0; e < 8; ++e) {
         const int ci = 8 * qq + e;
         float v = 0.f;
-        if (dx >= 0 && dx < 7 && ci < cin) v = w[(ci * 12 + dy) * 7 + dx];
+        if (dx >= 0 && dx < 7 && ci < cin) v = w[(ci * KH + dy) * 7 + dx];
         const unsigned int hb = bf16_bits(v);
         hi[e >> 1] |= hb << (16 * (e & 1));
         lo[e >> 1] |= bf16_bits(v - __uint_as_float(hb << 16)) << (16 * (e & 1));
@@ -978,9 +983,9 @@ __global__ void pack_head1_bf16_kernel(const float* __restrict__ w, uint4* __res
 }
 
 // weight fragments of conv_pc_bf16_kernel from the VALU-layout eval pack [co group of CO][ci][12][7][CO]: one thread per (k-step, N-tile, lane)
-__global__ void pack_pc_bf16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin, int cout, int CO, int NT) {
+__global__ void pack_pc_bf16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin, int cout, int CO, int NT, int KH) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 48 * NT * 64) return;
+    if (i >= KH * 4 * NT * 64) return;
     const int lane = i & 63, nt = (i >> 6) % NT, ks = i / (64 * NT);
     const int dy = ks >> 2, p = ks & 3;
     const int co = nt * 16 + (lane & 15), qq = lane >> 4;
@@ -989,7 +994,7 @@ __global__ void pack_pc_bf16_kernel(const float* __restrict__ w, uint4* __restri
     for (int e = 0; e < 8; ++e) {
         const int ci = c8 + e;
         float v = 0.f;
-        if (dx < 7 && ci < cin && co < cout) v = w[((((co / CO) * cin + ci) * 12 + dy) * 7 + dx) * CO + (co % CO)];
+        if (dx < 7 && ci < cin && co < cout) v = w[((((co / CO) * cin + ci) * KH + dy) * 7 + dx) * CO + (co % CO)];
         const unsigned int hb = bf16_bits(v);
         const unsigned int lb = bf16_bits(v - __uint_as_float(hb << 16));
         hi[e >> 1] |= hb << (16 * (e & 1));
