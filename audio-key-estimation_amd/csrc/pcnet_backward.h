@@ -46,6 +46,28 @@ struct Bwd {
     // weight gradient of one convolution: dW += corr(act(input), dz)
     int wgrad(const PackedConv& pc, int kind, Src src, const float* in_aff, int H, int T_in, bool same_time, const float* dz, int dz_ctot,
               int dz_coff, float* dW, const char* name) {
+        static const bool wg_f32 = std::getenv("AKE_WGRAD_F32") != nullptr;
+        if (!wg_f32 && kind == 0 && pc.kh == 7 && pc.kw == 7 && pc.cout == 8 && pc.cin <= 8 && T_in <= kWgMaxT && dz_ctot == 8 && dz_coff == 0) {
+            WgradBfArgs w;
+            std::memset(&w, 0, sizeof(w));
+            w.src0 = src.p0; w.c0 = src.c0; w.src1 = src.p1; w.c1 = src.c1; w.h1 = src.h1 > 0 ? src.h1 : 1;
+            w.src0_clip_stride = static_cast<long long>(src.c0) * H * T_in;
+            w.src1_clip_stride = static_cast<long long>(src.c1) * w.h1 * T_in;
+            w.in_affine = in_aff; w.dz = dz; w.dW = dW; w.slot_stride = static_cast<long long>(n->grad_floats);
+            w.cin = pc.cin; w.H = H; w.T = T_in;
+            const int wgs_per_clip = std::max(4, std::min(H, (512 + B - 1) / B));
+            w.rows_per_wg = (H + wgs_per_clip - 1) / wgs_per_clip;
+            dim3 grid((H + w.rows_per_wg - 1) / w.rows_per_wg, 1, B);
+            const size_t lds = (static_cast<size_t>(6) * 64 * kWgKP + kWgKP) * sizeof(unsigned short);
+            static bool attr_set = false;
+            if (!attr_set) {
+                AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_p2p_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                attr_set = true;
+            }
+            ake::ProfScope ps("conv_wgrad_p2p_bf16_kernel", s);
+            hipLaunchKernelGGL(conv_wgrad_p2p_bf16_kernel, grid, dim3(256), lds, s, w);
+            return AKE_OK;
+        }
         WgradArgs wa;
         std::memset(&wa, 0, sizeof(wa));
         ConvArgs& a = wa.c;

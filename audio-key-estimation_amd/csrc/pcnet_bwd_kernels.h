@@ -482,4 +482,165 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs wa) {
     }
 }
 
+// ---- weight gradient of the 7x7 circular pitch convolution on bf16 MFMA with split operands ---------------------------------
+// The f32 kernel above keeps one input channel per wave and gets 38 % useful MFMA work (8 of 16 rows, 49 of 64 columns) at the
+// vector rate: 1.2 ms per convolution and 256 clips, the largest kernel of a training step.  Here ONE row of the activated input
+// ("a-row" ya) and the 7 dz rows it meets are a complete 56 x 56 GEMM per row:
+//   D[m = (dy, co)][n = (dx, ci)] += sum_t  dz[co][ya - dy + 3][t]  *  a[ci][ya][t + dx - 3]         (rows / frames circular)
+// i.e. the whole dW (8 x 8 x 7 x 7) as 4 x 4 tiles of 16 x 16, K = the frames of the row (3 k-steps of 32), three MFMAs per
+// tile and k-step.  The time shift dx is resolved when the a-row is staged: it is written to LDS seven times, rotated, so every
+// B fragment is an aligned 16-byte read; dz rows sit in a ring of 8.  Both operands are read as raw f32 (the pending
+// BatchNorm + LeakyReLU of the input applied on the fly) and split into bf16 hi / lo while staging.
+// Workgroup = (clip, block of a-rows), 4 waves = the 4 M-tiles; partial sums go to the gradient slots with one atomic per weight.
+constexpr int kWgKP = 104;                  // LDS row pitch in bf16 (>= 96 frames; 52 dwords: conflict-free 16-byte reads)
+constexpr int kWgMaxT = 96;
+
+struct WgradBfArgs {
+    const float* src0;        // [clip][c0][H][T] raw
+    const float* src1;        // [clip][c1][h1][T] raw (rows repeat: row % h1), or null
+    long long src0_clip_stride, src1_clip_stride;
+    const float* in_affine;   // [cin][3] or null
+    const float* dz;          // [clip][8][H][T]
+    float* dW;                // [8][cin][7][7], slot 0
+    long long slot_stride;
+    int c0, c1, h1, cin, H, T, rows_per_wg;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_p2p_bf16_kernel(WgradBfArgs a) {
+    // two copies of the rotated a-row [8 dx][8 ci][kWgKP] (hi, lo) -- the next row is written while this one is multiplied --,
+    // the dz ring [8 slots][8 co][kWgKP] (hi, lo; 7 slots live, the 8th receives the next row), one zero row
+    extern __shared__ __attribute__((aligned(16))) unsigned short wg_lds[];
+    constexpr int kA = 64 * kWgKP;                                 // one plane of one a-row copy
+    unsigned short* const aBase = wg_lds;                          // [buf 2][hi|lo][64 rows][kWgKP]
+    unsigned short* const zH = wg_lds + 4 * kA;
+    unsigned short* const zL = zH + kA;
+    const unsigned short* const zero = zL + kA;
+    const int clip = blockIdx.z;
+    const int y0 = blockIdx.x * a.rows_per_wg;
+    const int rows = a.H - y0 < a.rows_per_wg ? a.H - y0 : a.rows_per_wg;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    for (int i = tid; i < (6 * kA + kWgKP) / 2; i += 256) reinterpret_cast<unsigned int*>(wg_lds)[i] = 0u;
+    __syncthreads();
+    const float* s0 = a.src0 + clip * a.src0_clip_stride;
+    const float* s1 = a.src1 ? a.src1 + clip * a.src1_clip_stride : nullptr;
+    const float* dzc = a.dz + static_cast<long long>(clip) * 8 * a.H * a.T;
+    // staging map: thread -> (channel tid >> 5, frames tl, tl + 32, tl + 64): no divisions, 3 values per operand and row in registers
+    const int ch = tid >> 5, tl = tid & 31;
+    float av[3], zv[3];
+    auto fetch = [&](int yl) {                                     // raw values of a-row y0 + yl and dz row l = yl + 3
+        int zr = (y0 + yl + 3) % a.H;
+        const int ya = y0 + yl;
+        const bool a_ok = ch < a.cin && yl < rows;
+        const float* ap = nullptr;
+        if (a_ok) ap = ch < a.c0 ? s0 + (static_cast<long long>(ch) * a.H + ya) * a.T : s1 + (static_cast<long long>(ch - a.c0) * a.h1 + (ya % a.h1)) * a.T;
+        const float* zp = dzc + (static_cast<long long>(ch) * a.H + zr) * a.T;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int t = tl + 32 * i;
+            av[i] = (a_ok && t < a.T) ? ap[t] : 0.f;
+            zv[i] = t < a.T ? zp[t] : 0.f;
+        }
+    };
+    auto commit = [&](int yl) {                                    // registers -> LDS: a-row copy (yl & 1), dz slot (yl + 3) & 7
+        unsigned short* aH = aBase + (yl & 1) * 2 * kA;
+        unsigned short* aL = aH + kA;
+        const int slot = (yl + 3 + 8) & 7;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int t = tl + 32 * i;
+            if (t < a.T) {
+                const unsigned int zb = bf16_bits(zv[i]);
+                zH[(slot * 8 + ch) * kWgKP + t] = static_cast<unsigned short>(zb);
+                zL[(slot * 8 + ch) * kWgKP + t] = static_cast<unsigned short>(bf16_bits(zv[i] - __uint_as_float(zb << 16)));
+                if (ch < a.cin) {
+                    const float v = affine_act(av[i], a.in_affine, ch);
+                    const unsigned int hb = bf16_bits(v);
+                    const unsigned short h = static_cast<unsigned short>(hb), l = static_cast<unsigned short>(bf16_bits(v - __uint_as_float(hb << 16)));
+#pragma unroll
+                    for (int dx = 0; dx < 7; ++dx) {
+                        int k = t - dx + 3;                        // aS[dx][ci][k] = a[ci][ya][(k + dx - 3) mod T]
+                        k += k < 0 ? a.T : 0;
+                        k -= k >= a.T ? a.T : 0;
+                        aH[(dx * 8 + ch) * kWgKP + k] = h;
+                        aL[(dx * 8 + ch) * kWgKP + k] = l;
+                    }
+                }
+            }
+        }
+    };
+    typedef float f32x4w __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+    f32x4w acc[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[ni] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    const int m = 16 * wave + r16;                                 // A row -> (dy = m >> 3, co = m & 7)
+    const int dy = m >> 3, co = m & 7;
+    const int ksteps = (a.T + 31) / 32;
+    // prologue: dz rows l = -3 .. 2 (fetch(yl) brings row l = yl + 3), then row 0 of both operands; row 1 stays in registers
+    for (int yl = -6; yl < 0; ++yl) {
+        int zr = (y0 + yl + 3) % a.H;
+        zr += zr < 0 ? a.H : 0;
+        const float* zp = dzc + (static_cast<long long>(ch) * a.H + zr) * a.T;
+        const int slot = (yl + 3 + 8) & 7;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int t = tl + 32 * i;
+            if (t < a.T) {
+                const float v = zp[t];
+                const unsigned int zb = bf16_bits(v);
+                zH[(slot * 8 + ch) * kWgKP + t] = static_cast<unsigned short>(zb);
+                zL[(slot * 8 + ch) * kWgKP + t] = static_cast<unsigned short>(bf16_bits(v - __uint_as_float(zb << 16)));
+            }
+        }
+    }
+    fetch(0);
+    commit(0);
+    fetch(1);
+    __syncthreads();
+    for (int yl = 0; yl < rows; ++yl) {
+        const unsigned short* aH = aBase + (yl & 1) * 2 * kA;
+        const unsigned short* aL = aH + kA;
+        const int slot = (yl - dy + 3 + 8) & 7;
+        const unsigned short* zh = dy < 7 ? zH + (slot * 8 + co) * kWgKP : zero;
+        const unsigned short* zl = dy < 7 ? zL + (slot * 8 + co) * kWgKP : zero;
+        for (int s = 0; s < ksteps; ++s) {
+            const int ko = 32 * s + 8 * q;
+            const bf16x8w ah = __builtin_bit_cast(bf16x8w, *reinterpret_cast<const uint4*>(zh + ko));
+            const bf16x8w al = __builtin_bit_cast(bf16x8w, *reinterpret_cast<const uint4*>(zl + ko));
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = 16 * ni + r16;
+                const bool ok = n < 56;                            // dx = n >> 3 < 7
+                const bf16x8w bh = __builtin_bit_cast(bf16x8w, *reinterpret_cast<const uint4*>(ok ? aH + n * kWgKP + ko : zero));
+                const bf16x8w bl = __builtin_bit_cast(bf16x8w, *reinterpret_cast<const uint4*>(ok ? aL + n * kWgKP + ko : zero));
+                acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[ni], 0, 0, 0);
+                acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[ni], 0, 0, 0);
+                acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[ni], 0, 0, 0);
+            }
+        }
+        // the next row (already in registers) goes to the other a-row copy and to the free ring slot while other waves may still
+        // multiply this one; then the row after that is requested
+        if (yl + 1 < rows) {
+            commit(yl + 1);
+            fetch(yl + 2);
+        }
+        __syncthreads();
+    }
+    // flush: D[row mm = 16 * wave + 4q + i][col n = 16 * ni + r16]
+    float* const dWs = grad_slot(a.dW, a.slot_stride);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = 16 * ni + r16;
+        const int dx = n >> 3, ci = n & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mm = 16 * wave + 4 * q + i;
+            const int dyy = mm >> 3, coo = mm & 7;
+            if (dyy < 7 && dx < 7 && ci < a.cin) atomicAdd(dWs + ((static_cast<long long>(coo) * a.cin + ci) * 7 + dyy) * 7 + dx, acc[ni][i]);
+        }
+    }
+}
+
 }  // namespace ake_k
