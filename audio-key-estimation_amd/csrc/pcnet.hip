@@ -422,6 +422,50 @@ int run_p2p_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short*
     return AKE_OK;
 }
 
+// the same convolution as a persistent launch (conv_p2p_bf16_ps_kernel): one workgroup per CU walks the row tiles.  Taken for
+// channels-last input, even frame counts and enough tiles to give every CU at least two; returns false when the shape does not
+// qualify (the caller then launches conv_p2p_bf16_kernel)
+bool run_p2p_bf16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const unsigned short* xl, int batch, int H, int T, float* dst_nchw,
+                     int dst_ctot, unsigned short* oh, unsigned short* ol, hipStream_t s, const char* name) {
+    static const bool off = std::getenv("AKE_P2P_PS") != nullptr && std::atoi(std::getenv("AKE_P2P_PS")) == 0;
+    static int n_cus = 0;
+    if (off || T < 2 || (T & 1)) return false;
+    if (!n_cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cus = -1;
+    }
+    if (n_cus < 8) return false;
+    P2pPsArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.xh = xh; a.xl = xl; a.bfrag = n->bf_frags_dev + pc.bf_off; a.bias = n->blob_dev + pc.b_off;
+    a.dst = dst_nchw; a.dst_clip_stride = static_cast<long long>(dst_ctot) * H * T; a.oh = oh; a.ol = ol;
+    a.H = H; a.T = T; a.J = T / 2; a.Tp = 2 * a.J + 6;
+    a.R = std::max(1, std::min(H, 8 * kP2pMT * 16 / a.J));
+    auto plane_of = [&](int R) { return ((R + 6) * a.Tp + 63) / 64 * 64; };
+    auto lds_of = [&](int R) { return (static_cast<size_t>(4) * plane_of(R) + 8 * kP2pMT * kP2pPsStage) * sizeof(uint4); };
+    while (a.R > 1 && (lds_of(a.R) > 156 * 1024 || plane_of(a.R) / 64 > 24)) --a.R;
+    if (lds_of(a.R) > 156 * 1024 || plane_of(a.R) / 64 > 24 || H < a.R + 6) return false;
+    a.plane_pos = plane_of(a.R);
+    a.n_row_tiles = (H + a.R - 1) / a.R;
+    a.n_tiles = a.n_row_tiles * batch;
+    if (a.n_tiles < 2 * n_cus) return false;
+    if (dst_nchw) {   // 16-byte stores of 4 consecutive frames
+        if ((a.R * T) % 4 || (static_cast<long long>(H) * T) % 4 || a.dst_clip_stride % 4 || (reinterpret_cast<uintptr_t>(dst_nchw) & 15)) return false;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return false;
+        attr_set = true;
+    }
+    dim3 grid(n_cus / 8 * 8), block(512);
+    ake::ProfScope ps(name, s);
+    if (dst_nchw) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<false>), grid, block, lds_of(a.R), s, a);
+    else hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<true>), grid, block, lds_of(a.R), s, a);
+    return true;
+}
+
 static const bool g_pc_f32_only = std::getenv("AKE_PC_F32") != nullptr;
 
 // NCHW f32 [clip][C][12][T] -> channels-last split planes [clip][12][T][16] (hi plane, then lo plane, at `planes`)
@@ -1292,6 +1336,9 @@ struct Fwd {
                             return rc;
                     } else {
                         const unsigned short* xh = reinterpret_cast<const unsigned short*>(((j - 1) & 1) ? b.pb[i] : b.pa[i]);
+                        if (run_p2p_bf16_ps(n, n->p2p[i][j], xh, xh + plane, B, P, Ti, last_conv ? out : nullptr, d.out_p, last_conv ? nullptr : oh,
+                                            last_conv ? nullptr : oh + plane, s, "conv_p2p_bf16_kernel"))
+                            continue;
                         if ((rc = run_p2p_bf16(n, n->p2p[i][j], xh, xh + plane, nullptr, B, P, Ti, last_conv ? out : nullptr, d.out_p, last_conv ? nullptr : oh,
                                                last_conv ? nullptr : oh + plane, s, "conv_p2p_bf16_kernel")))
                             return rc;

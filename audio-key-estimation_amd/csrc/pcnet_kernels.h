@@ -718,6 +718,205 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
 }
 
 // ==========================================================================================
+// Persistent form of conv_p2p_bf16_kernel (channels-last planes in; even frame counts).
+//
+// Measured on the kernel above (256 clips, by switching its phases off one at a time): skeleton 39 us + patch loads 40 us +
+// MFMA loop 63 us + stores 19 us = the 161 us of a launch -- the phases ADD, nothing overlaps.  All three memory phases go
+// through the CU's one vector-memory path: the weight fragments streamed from L2 (229 KB per workgroup, 5x the patch), the
+// patch, and 192 two-byte store instructions per workgroup; and a workgroup lives for 16 us, a third of it latency.
+// Here ONE workgroup per CU walks ~29 row tiles:
+//   * the 28 weight fragments (hi | lo, 14 k-steps) live in registers for the whole launch: no weight traffic in the loop;
+//   * the patch of tile k+1 is fetched by LDS-DMA (global_load_lds_dwordx4, circular halos resolved on the per-lane source
+//     address) into the other half of a double buffer while tile k is multiplied;
+//   * the epilogue transposes each 16 x 16 accumulator tile through a wave-private 1 KB LDS slab, so that a tile leaves as
+//     ONE 16-byte store per lane (32 positions x 8 channels x (hi | lo), or 8 channels x 32 consecutive frames of NCHW f32);
+//     the stores of tile k are issued after tile k+1's loads, under its MFMA loop;
+//   * tiles are dealt so that the workgroups of one XCD (blockIdx % 8) hold neighbouring row tiles: halo rows hit that L2.
+// One barrier per tile.
+// ==========================================================================================
+struct P2pPsArgs {
+    const unsigned short* xh;     // [clip][H][T][8]
+    const unsigned short* xl;
+    const uint4* bfrag;           // [14 k-steps][hi|lo][64 lanes] x 8 bf16
+    const float* bias;            // [8]
+    float* dst;                   // NCHW f32 [clip][dst_ctot][H][T] (OUT_CL == false)
+    long long dst_clip_stride;
+    unsigned short* oh;           // channels-last planes (OUT_CL == true)
+    unsigned short* ol;
+    int H, T, R, J, Tp, n_row_tiles, n_tiles, plane_pos;   // plane_pos: (R + 6) * Tp rounded up to 64 positions
+};
+
+constexpr int kP2pPsStage = 80;      // uint4 per M-tile of a wave's staging slab (NCHW form: 8 channels x 36 floats, padded)
+
+template <bool OUT_CL>
+__global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+    constexpr int MT = kP2pMT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int Tp = a.Tp, J = a.J, T = a.T;
+    const int nchunk = a.plane_pos >> 6;                        // 1 KB pieces per plane
+    const int npos = (a.R + 6) * Tp;
+    // tiles of this workgroup: first, first + gridDim.x, ...; workgroups of one XCD take neighbouring tiles
+    const int nwg = gridDim.x, per_xcd = nwg >> 3;
+    const int first = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    // ---- loader: the pieces c = wave, wave + 8, ... of [plane][piece]; lane -> patch position -> (row offset, frame) ----
+    int pk[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int c = wave + 8 * k;
+        const int ci = c >= nchunk ? c - nchunk : c;
+        int i = ci * 64 + lane;
+        i = i < npos ? i : npos - 1;
+        const int rj = i / Tp, f = i - rj * Tp;
+        pk[k] = (rj << 16) | wrap(f - 3, T);
+    }
+    auto issue_loads = [&](int tile, int buf) {
+        const int clip = tile / a.n_row_tiles;
+        const int y0 = (tile - clip * a.n_row_tiles) * a.R;
+        const long long cbase = static_cast<long long>(clip) * a.H * T;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int c = wave + 8 * k;
+            if (c < 2 * nchunk) {
+                const bool lo = c >= nchunk;
+                int row = y0 - 3 + (pk[k] >> 16);
+                row += row < 0 ? a.H : 0;
+                row -= row >= a.H ? a.H : 0;
+                const uint4* src = reinterpret_cast<const uint4*>(lo ? a.xl : a.xh) + cbase + static_cast<long long>(row) * T + (pk[k] & 0xffff);
+                uint4* dstl = lds4 + (buf * 2 + (lo ? 1 : 0)) * a.plane_pos + (lo ? c - nchunk : c) * 64;
+                // inline asm: hipcc orders every later LDS access behind a builtin LDS-DMA with vmcnt(0) (it cannot tell the two buffer
+                // halves apart), which would serialise load and multiply; the wait is placed by hand before the barrier instead
+                const unsigned int lds_dst = static_cast<unsigned int>(reinterpret_cast<unsigned long long>(dstl));   // LDS aperture: low 32 bits = LDS byte address
+                unsigned int keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+            }
+        }
+    };
+    if (first < a.n_tiles) issue_loads(first, 0);
+    // ---- weight fragments: registers, for the whole launch ----
+    uint4 breg[28];
+#pragma unroll
+    for (int i = 0; i < 28; ++i) breg[i] = a.bfrag[i * 64 + lane];
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = (wave * MT + mt) * 16 + r16;
+        m = m < a.R * J ? m : a.R * J - 1;
+        const int r = m / J, j = m - r * J;
+        abase[mt] = r * Tp + 2 * j + q;
+    }
+    const int tau = r16 >> 3, co = r16 & 7;
+    const float bias = a.bias[co];
+    uint4* const stage = lds4 + 4 * a.plane_pos + wave * (MT * kP2pPsStage);
+    typedef float f32x4c __attribute__((ext_vector_type(4)));
+    typedef float f32x2e __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2e __attribute__((ext_vector_type(2)));
+    long long prev_base = 0;          // element offset of the pending tile's first position (channels-last: position index)
+    int prev_mblk = 0;
+    bool has_prev = false;
+    auto store_pending = [&]() {      // the finished tile waits in the staging slab (not in registers: the multiply loop needs them all)
+        uint4 outv[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) outv[mt] = OUT_CL ? stage[mt * kP2pPsStage + lane] : stage[mt * kP2pPsStage + (lane >> 3) * 9 + (lane & 7)];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int mbase = (wave * MT + mt) * 16;
+            if (OUT_CL) {   // lane = (plane, m, tau): position 2 * (mbase + m) + tau of the tile, 8 channels = 16 bytes
+                const int m = mbase + ((lane >> 1) & 15);
+                if (m < prev_mblk) {
+                    uint4* o = reinterpret_cast<uint4*>(lane < 32 ? a.oh : a.ol) + prev_base + 2 * mbase + (lane & 31);
+                    *o = outv[mt];
+                }
+            } else {        // lane = (channel, group of 4 frames)
+                const int m = mbase + 2 * (lane & 7);
+                float* o = a.dst + prev_base + static_cast<long long>(lane >> 3) * a.H * T + 2 * m;
+                if (m + 1 < prev_mblk) *reinterpret_cast<uint4*>(o) = outv[mt];
+                else if (m < prev_mblk) { o[0] = __uint_as_float(outv[mt].x); o[1] = __uint_as_float(outv[mt].y); }
+            }
+        }
+    };
+    int cur = 0;
+    for (int tile = first; tile < a.n_tiles; tile += nwg, cur ^= 1) {
+        // this wave's share of the tile's patch has landed (and its stores have left).  The builtin, not asm: hipcc then knows that
+        // nothing of its own is pending at the loop top and places no vmcnt wait inside the loop that would also drain the LDS-DMA
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        __syncthreads();              // ... every wave's; and every wave is done with the other half
+        if (tile + nwg < a.n_tiles) issue_loads(tile + nwg, cur ^ 1);
+        if (has_prev) store_pending();
+        const uint4* const pH = lds4 + (cur * 2) * a.plane_pos;
+        const uint4* const pL = pH + a.plane_pos;
+        f32x4c acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 14; ++ks) {
+            const int dy = ks >> 1, h = ks & 1;
+            const bf16x8c bh = __builtin_bit_cast(bf16x8c, breg[2 * ks]), bl = __builtin_bit_cast(bf16x8c, breg[2 * ks + 1]);
+            bf16x8c ah[MT], al[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int ad = abase[mt] + dy * Tp + 4 * h;
+                ah[mt] = __builtin_bit_cast(bf16x8c, pH[ad]);
+                al[mt] = __builtin_bit_cast(bf16x8c, pL[ad]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt], 0, 0, 0);
+        }
+        // ---- epilogue: bias + LeakyReLU, transposed into the wave's staging slab ----
+        {
+            const int clip = tile / a.n_row_tiles;
+            const int y0 = (tile - clip * a.n_row_tiles) * a.R;
+            const int rows_here = a.H - y0 < a.R ? a.H - y0 : a.R;
+            prev_mblk = rows_here * J;
+            prev_base = OUT_CL ? static_cast<long long>(clip) * a.H * T + static_cast<long long>(y0) * T
+                               : clip * a.dst_clip_stride + static_cast<long long>(y0) * T;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x = acc[mt][i] + bias;
+                v[i] = x > 0.f ? x : x * kSlope;
+            }
+            if (OUT_CL) {
+                // lanes (co, co ^ 1) trade halves: the even lane keeps rows m = 4q, 4q + 1 of both channels, the odd lane rows 4q + 2, 4q + 3
+                const bool odd = co & 1;
+                const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];
+                const float g0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0xB1, 0xF, 0xF, false));
+                const float g1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0xB1, 0xF, 0xF, false));
+                const float m0 = odd ? v[2] : v[0], m1 = odd ? v[3] : v[1];
+                const f32x2e xa = {odd ? g0 : m0, odd ? m0 : g0};       // (even channel, odd channel) of row ma
+                const f32x2e xb = {odd ? g1 : m1, odd ? m1 : g1};       // ... of row ma + 1
+                const bf16x2e ha = __builtin_convertvector(xa, bf16x2e), hb = __builtin_convertvector(xb, bf16x2e);
+                const bf16x2e la = __builtin_convertvector(xa - __builtin_convertvector(ha, f32x2e), bf16x2e);
+                const bf16x2e lb = __builtin_convertvector(xb - __builtin_convertvector(hb, f32x2e), bf16x2e);
+                unsigned int* st = reinterpret_cast<unsigned int*>(stage + mt * kP2pPsStage);
+                const int ma = 4 * q + (odd ? 2 : 0);
+                const int d = ma * 8 + tau * 4 + (co >> 1);              // [plane][m][tau][co / 2] dwords
+                st[d] = __builtin_bit_cast(unsigned int, ha);
+                st[d + 8] = __builtin_bit_cast(unsigned int, hb);
+                st[128 + d] = __builtin_bit_cast(unsigned int, la);
+                st[128 + d + 8] = __builtin_bit_cast(unsigned int, lb);
+            } else {
+                float* st = reinterpret_cast<float*>(stage + mt * kP2pPsStage);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st[co * 36 + (4 * q + i) * 2 + tau] = v[i];
+            }
+        }
+        has_prev = true;
+    }
+    if (has_prev) store_pending();
+}
+
+// ==========================================================================================
 // Equivariant pitch-class convolution (12 x 7 kernel, rows circular over the 12 pitch classes, time zero-padded or valid;
 // models.py:36-47) on bf16 MFMA with split operands -- the PitchClass2PitchClass stacks and the first convolution of the
 // key / tonic heads.  Same idea as conv_p2p_bf16_kernel: channels-last activations [clip][12][T][16] as bf16 hi / lo planes,

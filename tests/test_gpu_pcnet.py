@@ -184,6 +184,29 @@ def test_batch_larger_than_the_pitch_stream_chunk(gold_default):
     assert torch.equal(ks, key[idx]) and torch.equal(ts, tonic[idx]) and torch.equal(gs, genre[idx])
 
 
+@pytest.mark.parametrize("B,T", [(24, 76), (40, 52), (64, 30), (20, 120)])
+def test_persistent_pitch_conv_equals_per_tile_kernel_and_oracle(gold_default, B, T):
+    """Batches with >= 2 row tiles per CU run the 8 -> 8 pitch convolutions as ONE persistent launch (conv_p2p_bf16_ps_kernel: LDS-DMA
+    double buffer, weights in registers, staged 16-byte stores); smaller batches take conv_p2p_bf16_kernel (one workgroup per tile).
+    Same arithmetic in the same order => bit-identical outputs; partial last row tiles (288 = 20 x 14 + 8 at T = 52) and tile
+    counts that do not divide by the grid are covered by the shapes.  Three clips are also held against the oracle."""
+    net, _ = make_net(gold_default)
+    g = torch.Generator().manual_seed(100 + T)
+    x = (torch.rand((B, 1, 288, T), generator=g) * 2.5).to(DEV)
+    seq = torch.randint(26, T + 1, (B,), generator=g).to(DEV)
+    key, tonic, genre = net(x, seq)
+    last = net.tap("model.1.p2p.layer.8").clone()                 # NCHW f32 output of the stack's last convolution
+    for lo in range(0, B, 4):                                      # 4 clips: far below two tiles per CU -> per-tile kernel
+        ks, ts, gs = net(x[lo:lo + 4], seq[lo:lo + 4])
+        assert torch.equal(net.tap("model.1.p2p.layer.8"), last[lo:lo + 4]), lo
+        assert torch.equal(ks, key[lo:lo + 4]) and torch.equal(ts, tonic[lo:lo + 4]) and torch.equal(gs, genre[lo:lo + 4]), lo
+    idx = [0, B // 2, B - 1]
+    sd = golden_state_dict(gold_default, torch.float64)
+    ref = pcnet_oracle.pcnet_forward(sd, x[idx].cpu().double(), seq[idx].cpu())
+    for a, b in zip((key[idx], tonic[idx], genre[idx]), ref):
+        assert rel_err(a.cpu(), b) < TOL
+
+
 def test_edge_shapes(gold_default):
     net, _ = make_net(gold_default)
     sd = golden_state_dict(gold_default, torch.float64)
