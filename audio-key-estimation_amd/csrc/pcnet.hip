@@ -425,7 +425,7 @@ int run_p2p_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short*
 // the same convolution as a persistent launch (conv_p2p_bf16_ps_kernel): one workgroup per CU walks the row tiles.  Taken for
 // channels-last input, even frame counts and enough tiles to give every CU at least two; returns false when the shape does not
 // qualify (the caller then launches conv_p2p_bf16_kernel)
-bool run_p2p_bf16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const unsigned short* xl, int batch, int H, int T, float* dst_nchw,
+bool run_p2p_bf16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const unsigned short* xl, const Src* nchw, int batch, int H, int T, float* dst_nchw,
                      int dst_ctot, unsigned short* oh, unsigned short* ol, hipStream_t s, const char* name) {
     static const bool off = std::getenv("AKE_P2P_PS") != nullptr && std::atoi(std::getenv("AKE_P2P_PS")) == 0;
     static int n_cus = 0;
@@ -438,6 +438,10 @@ bool run_p2p_bf16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sh
     P2pPsArgs a;
     std::memset(&a, 0, sizeof(a));
     a.xh = xh; a.xl = xl; a.bfrag = n->bf_frags_dev + pc.bf_off; a.bias = n->blob_dev + pc.b_off;
+    if (nchw) {
+        if (dst_nchw || nchw->c0 < 1 || nchw->c0 + nchw->c1 > 8) return false;
+        a.p = nchw->p0; a.c0 = nchw->c0; a.u = nchw->p1 ? nchw->p1 : nchw->p0; a.c1 = nchw->p1 ? nchw->c1 : 0; a.h1 = nchw->h1 > 0 ? nchw->h1 : 1;
+    }
     a.dst = dst_nchw; a.dst_clip_stride = static_cast<long long>(dst_ctot) * H * T; a.oh = oh; a.ol = ol;
     a.H = H; a.T = T; a.J = T / 2; a.Tp = 2 * a.J + 6;
     a.R = std::max(1, std::min(H, 8 * kP2pMT * 16 / a.J));
@@ -454,15 +458,19 @@ bool run_p2p_bf16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sh
     }
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<true, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return false;
         attr_set = true;
     }
     dim3 grid(n_cus / 8 * 8), block(512);
     ake::ProfScope ps(name, s);
-    if (dst_nchw) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<false>), grid, block, lds_of(a.R), s, a);
-    else hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<true>), grid, block, lds_of(a.R), s, a);
+    if (dst_nchw) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<false, 0>), grid, block, lds_of(a.R), s, a);
+    else if (nchw && a.c0 + a.c1 <= 5) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<true, 5>), grid, block, lds_of(a.R), s, a);
+    else if (nchw) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<true, 8>), grid, block, lds_of(a.R), s, a);
+    else hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<true, 0>), grid, block, lds_of(a.R), s, a);
     return true;
 }
 
@@ -1332,11 +1340,12 @@ struct Fwd {
                     unsigned short* oh = reinterpret_cast<unsigned short*>(out);
                     const bool last_conv = j == c.conv_layers - 1;
                     if (j == 0) {   // the stack's input (pitch stream | repeated up_sixth output) is assembled by the kernel's own loader
+                        if (run_p2p_bf16_ps(n, n->p2p[i][0], nullptr, nullptr, &sdesc, B, P, Ti, nullptr, d.out_p, oh, oh + plane, s, "conv_p2p_bf16_kernel")) continue;
                         if ((rc = run_p2p_bf16(n, n->p2p[i][0], nullptr, nullptr, &sdesc, B, P, Ti, nullptr, d.out_p, oh, oh + plane, s, "conv_p2p_bf16_kernel")))
                             return rc;
                     } else {
                         const unsigned short* xh = reinterpret_cast<const unsigned short*>(((j - 1) & 1) ? b.pb[i] : b.pa[i]);
-                        if (run_p2p_bf16_ps(n, n->p2p[i][j], xh, xh + plane, B, P, Ti, last_conv ? out : nullptr, d.out_p, last_conv ? nullptr : oh,
+                        if (run_p2p_bf16_ps(n, n->p2p[i][j], xh, xh + plane, nullptr, B, P, Ti, last_conv ? out : nullptr, d.out_p, last_conv ? nullptr : oh,
                                             last_conv ? nullptr : oh + plane, s, "conv_p2p_bf16_kernel"))
                             continue;
                         if ((rc = run_p2p_bf16(n, n->p2p[i][j], xh, xh + plane, nullptr, B, P, Ti, last_conv ? out : nullptr, d.out_p, last_conv ? nullptr : oh,

@@ -735,8 +735,11 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
 // One barrier per tile.
 // ==========================================================================================
 struct P2pPsArgs {
-    const unsigned short* xh;     // [clip][H][T][8]
+    const unsigned short* xh;     // [clip][H][T][8]   (IN_NCHW == false)
     const unsigned short* xl;
+    const float* p;               // IN_NCHW == true: the stack's input is assembled by the loader, as in conv_p2p_bf16_kernel
+    const float* u;
+    int c0, c1, h1;
     const uint4* bfrag;           // [14 k-steps][hi|lo][64 lanes] x 8 bf16
     const float* bias;            // [8]
     float* dst;                   // NCHW f32 [clip][dst_ctot][H][T] (OUT_CL == false)
@@ -748,8 +751,10 @@ struct P2pPsArgs {
 
 constexpr int kP2pPsStage = 80;      // uint4 per M-tile of a wave's staging slab (NCHW form: 8 channels x 36 floats, padded)
 
-template <bool OUT_CL>
+template <bool OUT_CL, int NIN>        // NIN: 0 = channels-last split planes in; else the number of f32 channels the loader assembles (5: default net, 8: any)
 __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
+    constexpr bool IN_NCHW = NIN > 0;
+    constexpr int NV = IN_NCHW ? NIN : 1;
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
     constexpr int MT = kP2pMT;
     const int lane = threadIdx.x & 63;
@@ -795,7 +800,64 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
             }
         }
     };
-    if (first < a.n_tiles) issue_loads(first, 0);
+    // IN_NCHW: f32 planes -> registers (requested before the multiply loop) -> split-bf16 channels-last patch (written after it);
+    // thread -> the patch positions threadIdx.x, + 512, + 1024
+    float vin[3][NV];
+    int pn[3];
+    if (IN_NCHW) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = threadIdx.x + 512 * k;
+            const int ic = i < npos ? i : npos - 1;
+            const int rj = ic / Tp, f = ic - rj * Tp;
+            pn[k] = (rj << 16) | wrap(f - 3, T);
+        }
+    }
+    auto load_regs = [&](int tile) {      // branch-free (a branch around a load makes hipcc wait for every load at the join)
+        const int clip = tile / a.n_row_tiles;
+        const int y0 = (tile - clip * a.n_row_tiles) * a.R;
+        const int ctot = a.c0 + a.c1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int row = y0 - 3 + (pn[k] >> 16);
+            row += row < 0 ? a.H : 0;
+            row -= row >= a.H ? a.H : 0;
+            const int t = pn[k] & 0xffff;
+            const float* pp = a.p + (static_cast<long long>(clip) * a.c0 * a.H + row) * T + t;
+            const float* pu = a.u + (static_cast<long long>(clip) * a.c1 * a.h1 + row % a.h1) * T + t;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                const int cc = c < ctot ? c : ctot - 1;
+                const float* src = cc < a.c0 ? pp + static_cast<long long>(cc) * a.H * T : pu + static_cast<long long>(cc - a.c0) * a.h1 * T;
+                vin[k][c] = *src;                  // (channels >= ctot re-read the last one; zeroed when the patch is written)
+            }
+        }
+    };
+    auto write_lds = [&](int buf) {
+        uint4* const wH = lds4 + (buf * 2) * a.plane_pos;
+        uint4* const wL = wH + a.plane_pos;
+        const int ctot = a.c0 + a.c1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                const float v = c < ctot ? vin[k][c] : 0.f;
+                const unsigned int hb = bf16_bits(v);
+                hi[c >> 1] |= hb << (16 * (c & 1));
+                lo[c >> 1] |= bf16_bits(v - __uint_as_float(hb << 16)) << (16 * (c & 1));
+            }
+            const int i = threadIdx.x + 512 * k;
+            if (i < npos) {
+                wH[i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                wL[i] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            }
+        }
+    };
+    if (first < a.n_tiles) {
+        if (IN_NCHW) { load_regs(first); write_lds(0); }
+        else issue_loads(first, 0);
+    }
     // ---- weight fragments: registers, for the whole launch ----
     uint4 breg[28];
 #pragma unroll
@@ -811,7 +873,6 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
     const int tau = r16 >> 3, co = r16 & 7;
     const float bias = a.bias[co];
     uint4* const stage = lds4 + 4 * a.plane_pos + wave * (MT * kP2pPsStage);
-    typedef float f32x4c __attribute__((ext_vector_type(4)));
     typedef float f32x2e __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2e __attribute__((ext_vector_type(2)));
     long long prev_base = 0;          // element offset of the pending tile's first position (channels-last: position index)
@@ -838,46 +899,9 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
             }
         }
     };
-    int cur = 0;
-    for (int tile = first; tile < a.n_tiles; tile += nwg, cur ^= 1) {
-        // this wave's share of the tile's patch has landed (and its stores have left).  The builtin, not asm: hipcc then knows that
-        // nothing of its own is pending at the loop top and places no vmcnt wait inside the loop that would also drain the LDS-DMA
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-        __syncthreads();              // ... every wave's; and every wave is done with the other half
-        if (tile + nwg < a.n_tiles) issue_loads(tile + nwg, cur ^ 1);
-        if (has_prev) store_pending();
-        const uint4* const pH = lds4 + (cur * 2) * a.plane_pos;
-        const uint4* const pL = pH + a.plane_pos;
-        f32x4c acc[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 14; ++ks) {
-            const int dy = ks >> 1, h = ks & 1;
-            const bf16x8c bh = __builtin_bit_cast(bf16x8c, breg[2 * ks]), bl = __builtin_bit_cast(bf16x8c, breg[2 * ks + 1]);
-            bf16x8c ah[MT], al[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int ad = abase[mt] + dy * Tp + 4 * h;
-                ah[mt] = __builtin_bit_cast(bf16x8c, pH[ad]);
-                al[mt] = __builtin_bit_cast(bf16x8c, pL[ad]);
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt], 0, 0, 0);
-        }
-        // ---- epilogue: bias + LeakyReLU, transposed into the wave's staging slab ----
-        {
-            const int clip = tile / a.n_row_tiles;
-            const int y0 = (tile - clip * a.n_row_tiles) * a.R;
-            const int rows_here = a.H - y0 < a.R ? a.H - y0 : a.R;
-            prev_mblk = rows_here * J;
-            prev_base = OUT_CL ? static_cast<long long>(clip) * a.H * T + static_cast<long long>(y0) * T
-                               : clip * a.dst_clip_stride + static_cast<long long>(y0) * T;
-        }
+    // bias + LeakyReLU, transposed into the wave's staging slab
+    typedef float f32x4c __attribute__((ext_vector_type(4)));
+    auto epilogue = [&](const f32x4c (&acc)[MT]) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             float v[4];
@@ -911,9 +935,67 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
                 for (int i = 0; i < 4; ++i) st[co * 36 + (4 * q + i) * 2 + tau] = v[i];
             }
         }
+    };
+    // The waves 4..7 run their epilogue one barrier late (the accumulators wait in registers): each SIMD holds one wave of either
+    // half, so one half's epilogue, loads and stores issue under the other half's MFMAs instead of all eight waves leaving the
+    // matrix pipe idle together
+    const bool late = wave >= 4;
+    f32x4c acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
+    int cur = 0;
+    for (int tile = first; tile < a.n_tiles; tile += nwg, cur ^= 1) {
+        // this wave's share of the tile's patch has landed (and its stores have left).  The builtin, not asm: hipcc then knows that
+        // nothing of its own is pending at the loop top and places no vmcnt wait inside the loop that would also drain the LDS-DMA
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        __syncthreads();              // ... every wave's; and every wave is done with the other half
+        const bool more = tile + nwg < a.n_tiles;
+        if (more) {
+            if (IN_NCHW) load_regs(tile + nwg);
+            else issue_loads(tile + nwg, cur ^ 1);
+        }
+        if (has_prev) {
+            if (late) epilogue(acc);
+            store_pending();
+        }
+        const uint4* const pH = lds4 + (cur * 2) * a.plane_pos;
+        const uint4* const pL = pH + a.plane_pos;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 14; ++ks) {
+            const int dy = ks >> 1, h = ks & 1;
+            const bf16x8c bh = __builtin_bit_cast(bf16x8c, breg[2 * ks]), bl = __builtin_bit_cast(bf16x8c, breg[2 * ks + 1]);
+            bf16x8c ah[MT], al[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int ad = abase[mt] + dy * Tp + 4 * h;
+                ah[mt] = __builtin_bit_cast(bf16x8c, pH[ad]);
+                al[mt] = __builtin_bit_cast(bf16x8c, pL[ad]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt], 0, 0, 0);
+        }
+        if (!late) epilogue(acc);
+        if (IN_NCHW && more) write_lds(cur ^ 1);
+        {
+            const int clip = tile / a.n_row_tiles;
+            const int y0 = (tile - clip * a.n_row_tiles) * a.R;
+            const int rows_here = a.H - y0 < a.R ? a.H - y0 : a.R;
+            prev_mblk = rows_here * J;
+            prev_base = OUT_CL ? static_cast<long long>(clip) * a.H * T + static_cast<long long>(y0) * T
+                               : clip * a.dst_clip_stride + static_cast<long long>(y0) * T;
+        }
         has_prev = true;
     }
-    if (has_prev) store_pending();
+    if (has_prev) {
+        if (late) epilogue(acc);
+        store_pending();
+    }
 }
 
 // ==========================================================================================
