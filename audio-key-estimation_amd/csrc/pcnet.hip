@@ -422,56 +422,100 @@ int run_p2p_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short*
     return AKE_OK;
 }
 
-// the same convolution as a persistent launch (conv_p2p_bf16_ps_kernel): one workgroup per CU walks the row tiles.  Taken for
-// channels-last input, even frame counts and enough tiles to give every CU at least two; returns false when the shape does not
-// qualify (the caller then launches conv_p2p_bf16_kernel)
-bool run_p2p_bf16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const unsigned short* xl, const Src* nchw, int batch, int H, int T, float* dst_nchw,
-                     int dst_ctot, unsigned short* oh, unsigned short* ol, hipStream_t s, const char* name) {
-    static const bool off = std::getenv("AKE_P2P_PS") != nullptr && std::atoi(std::getenv("AKE_P2P_PS")) == 0;
+// debug switch (ake_debug_keep_taps): keep every activation that ake_pcnet_tap_* can name in memory, i.e. no fusion across them
+int g_keep_taps = 0;
+
+int device_cus() {
     static int n_cus = 0;
-    if (off || T < 2 || (T & 1)) return false;
     if (!n_cus) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cus = -1;
     }
-    if (n_cus < 8) return false;
+    return n_cus;
+}
+
+// row-tile height of the persistent pitch-conv kernel for H x T maps (0: the shape does not qualify); `semi`: the form fused with the
+// semitone conv (tiles of 3k rows, no staging slabs but a double-buffered output patch)
+int p2p_ps_rows(int H, int T, bool semi, int* plane_pos, size_t* lds) {
+    if (T < 2 || (T & 1) || device_cus() < 8) return 0;
+    const int J = T / 2, Tp = 2 * J + 6;
+    auto plane_of = [&](int R) { return ((R + 6) * Tp + 63) / 64 * 64; };
+    auto lds_of = [&](int R) { return (static_cast<size_t>(4) * plane_of(R) + (semi ? 4 * 8 * kP2pMT * 16 * 2 : 8 * kP2pMT * kP2pPsStage)) * sizeof(uint4); };
+    int R = std::max(1, std::min(H, 8 * kP2pMT * 16 / J));
+    if (semi) R = R / 3 * 3;
+    while (R >= (semi ? 3 : 1) && (lds_of(R) > 156 * 1024 || plane_of(R) / 64 > 24)) R -= semi ? 3 : 1;
+    if (R < (semi ? 3 : 1) || H < R + 6) return 0;
+    if (semi && (H % 3 || (H / 3) % 12)) return 0;
+    if (plane_pos) *plane_pos = plane_of(R);
+    if (lds) *lds = lds_of(R);
+    return R;
+}
+
+// does inference fuse the semitone conv of layer i into the last pitch conv of its stack (the pitch tensor is then never written)?
+// Only in the net's last layer: an inner layer's pitch tensor is also the next layer's pitch stream (time_pool_p, models.py:395).
+bool p2p_fuses_semi(const ake_pcnet* n, int i, int P, int T) {
+    static const bool off = std::getenv("AKE_P2P_PS") != nullptr && std::atoi(std::getenv("AKE_P2P_PS")) == 0;
+    return !off && !g_keep_taps && i == n->cfg.num_layers - 1 && p2p_uses_bf16(n, i, T) && static_cast<size_t>(i) < n->semi.size() && n->semi[i].bf_off >= 0 &&
+           p2p_ps_rows(P, T, true, nullptr, nullptr) > 0;
+}
+
+// the same convolution as a persistent launch (conv_p2p_bf16_ps_kernel): one workgroup per CU walks the row tiles.  Taken for even
+// frame counts and enough tiles to give every CU at least two (always when `semi_pc` asks for the fused semitone conv: `dst` then
+// receives the semitone maps [clip][8][H / 3][T]); returns false when the shape does not qualify (the caller then launches
+// conv_p2p_bf16_kernel)
+bool run_p2p_bf16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const unsigned short* xl, const Src* nchw, int batch, int H, int T, float* dst_nchw,
+                     int dst_ctot, unsigned short* oh, unsigned short* ol, const PackedConv* semi_pc, hipStream_t s, const char* name) {
+    static const bool off = std::getenv("AKE_P2P_PS") != nullptr && std::atoi(std::getenv("AKE_P2P_PS")) == 0;
+    if (off) return false;
     P2pPsArgs a;
     std::memset(&a, 0, sizeof(a));
+    size_t lds = 0;
+    a.R = p2p_ps_rows(H, T, semi_pc != nullptr, &a.plane_pos, &lds);
+    if (a.R <= 0) return false;
+    const int n_cus = device_cus();
     a.xh = xh; a.xl = xl; a.bfrag = n->bf_frags_dev + pc.bf_off; a.bias = n->blob_dev + pc.b_off;
     if (nchw) {
         if (dst_nchw || nchw->c0 < 1 || nchw->c0 + nchw->c1 > 8) return false;
         a.p = nchw->p0; a.c0 = nchw->c0; a.u = nchw->p1 ? nchw->p1 : nchw->p0; a.c1 = nchw->p1 ? nchw->c1 : 0; a.h1 = nchw->h1 > 0 ? nchw->h1 : 1;
     }
-    a.dst = dst_nchw; a.dst_clip_stride = static_cast<long long>(dst_ctot) * H * T; a.oh = oh; a.ol = ol;
+    a.dst = dst_nchw; a.dst_clip_stride = static_cast<long long>(dst_ctot) * (semi_pc ? H / 3 : H) * T; a.oh = oh; a.ol = ol;
+    if (semi_pc) {
+        if (!dst_nchw || semi_pc->bf_off < 0) return false;
+        a.sfrag = n->bf_frags_dev + semi_pc->bf_off; a.sbias = n->blob_dev + semi_pc->b_off;
+    }
     a.H = H; a.T = T; a.J = T / 2; a.Tp = 2 * a.J + 6;
-    a.R = std::max(1, std::min(H, 8 * kP2pMT * 16 / a.J));
-    auto plane_of = [&](int R) { return ((R + 6) * a.Tp + 63) / 64 * 64; };
-    auto lds_of = [&](int R) { return (static_cast<size_t>(4) * plane_of(R) + 8 * kP2pMT * kP2pPsStage) * sizeof(uint4); };
-    while (a.R > 1 && (lds_of(a.R) > 156 * 1024 || plane_of(a.R) / 64 > 24)) --a.R;
-    if (lds_of(a.R) > 156 * 1024 || plane_of(a.R) / 64 > 24 || H < a.R + 6) return false;
-    a.plane_pos = plane_of(a.R);
     a.n_row_tiles = (H + a.R - 1) / a.R;
     a.n_tiles = a.n_row_tiles * batch;
-    if (a.n_tiles < 2 * n_cus) return false;
-    if (dst_nchw) {   // 16-byte stores of 4 consecutive frames
+    if (!semi_pc && a.n_tiles < 2 * n_cus) return false;
+    if (dst_nchw && !semi_pc) {   // 16-byte stores of 4 consecutive frames
         if ((a.R * T) % 4 || (static_cast<long long>(H) * T) % 4 || a.dst_clip_stride % 4 || (reinterpret_cast<uintptr_t>(dst_nchw) & 15)) return false;
     }
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<true, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return false;
+        const void* fns[] = {reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<1, 0>), reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<1, 5>),
+                             reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<1, 8>), reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<0, 0>),
+                             reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<2, 0>)};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
         attr_set = true;
     }
-    dim3 grid(n_cus / 8 * 8), block(512);
+    dim3 grid(std::min(n_cus / 8 * 8, (a.n_tiles + 7) / 8 * 8)), block(512);
     ake::ProfScope ps(name, s);
-    if (dst_nchw) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<false, 0>), grid, block, lds_of(a.R), s, a);
-    else if (nchw && a.c0 + a.c1 <= 5) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<true, 5>), grid, block, lds_of(a.R), s, a);
-    else if (nchw) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<true, 8>), grid, block, lds_of(a.R), s, a);
-    else hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<true, 0>), grid, block, lds_of(a.R), s, a);
+    if (semi_pc) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<2, 0>), grid, block, lds, s, a);
+    else if (dst_nchw) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<0, 0>), grid, block, lds, s, a);
+    else if (nchw && a.c0 + a.c1 <= 5) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<1, 5>), grid, block, lds, s, a);
+    else if (nchw) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<1, 8>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<1, 0>), grid, block, lds, s, a);
     return true;
+}
+
+// semitone maps [clip][C][S][T] -> channels [coff, coff + C) of the concat buffer [clip][ctot][12][T]: max over the octaves
+int run_fold_max(const float* smap, int C, int S, int batch, int T, float* dst, int dst_ctot, int dst_coff, hipStream_t s) {
+    const long long total = static_cast<long long>(batch) * C * 12 * T;
+    ake::ProfScope ps("fold_max_kernel", s);
+    hipLaunchKernelGGL(fold_max_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, smap, C, S, T, dst,
+                       static_cast<long long>(dst_ctot) * 12 * T, dst_coff, total);
+    return AKE_OK;
 }
 
 static const bool g_pc_f32_only = std::getenv("AKE_PC_F32") != nullptr;
@@ -1040,6 +1084,13 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
         pc->bf_off = -1;
         if ((pc->kh == 12 || pc->kh == 2) && pc->kw == 7 && pc->cout == 1 && pc->co == 1 && pc->cin == 32) { pc->bf_off = static_cast<long long>(count); count += static_cast<size_t>(pc->kh) * 22 * 2 * 64; }
     }
+    for (size_t i = 1; i < n->semi.size(); ++i) {            // semitone convs that follow an 8-channel pitch stack: fused into its last conv
+        PackedConv& pc = n->semi[i];
+        pc.bf_off = -1;
+        if (pc.cin == 8 && pc.co == 8 && pc.groups == 1 && i < n->p2p.size() && !n->p2p[i].empty() && n->p2p[i].back().bf_off >= 0) {
+            pc.bf_off = static_cast<long long>(count); count += 6 * 64;
+        }
+    }
     if (count == 0) return AKE_OK;
     if (n->bf_frags_count != count) {
         if (n->bf_frags_dev) { (void)hipFree(n->bf_frags_dev); n->bf_frags_dev = nullptr; }
@@ -1057,6 +1108,9 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
             hipLaunchKernelGGL(pack_pc_bf16_kernel, dim3((pc->kh * 4 * NT * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
                                n->bf_frags_dev + pc->bf_off, pc->cin, pc->cout, pc->co, NT, pc->kh);
         }
+    for (size_t i = 1; i < n->semi.size(); ++i)
+        if (n->semi[i].bf_off >= 0)
+            hipLaunchKernelGGL(pack_semi_bf16_kernel, dim3(1), dim3(192), 0, s, n->blob_dev + n->semi[i].w_off, n->bf_frags_dev + n->semi[i].bf_off);
     for (const PackedConv* pc : h1)
         if (pc->bf_off >= 0)
             hipLaunchKernelGGL(pack_head1_bf16_kernel, dim3((pc->kh * 22 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
@@ -1332,6 +1386,7 @@ struct Fwd {
             // activations between them are channels-last split planes that live in the same ping-pong buffers (32 B per position
             // either way: 8 f32 channels, or 8 bf16 hi + 8 bf16 lo)
             const bool bf = !train && p2p_uses_bf16(n, i, Ti);
+            bool fused_semi = false;
             const size_t plane = static_cast<size_t>(B) * P * Ti * 8;                 // bf16 elements per plane
             for (int j = 0; j < c.conv_layers; ++j) {
                 out = train ? b.pst[i][j] : ((j & 1) ? b.pb[i] : b.pa[i]);
@@ -1340,13 +1395,18 @@ struct Fwd {
                     unsigned short* oh = reinterpret_cast<unsigned short*>(out);
                     const bool last_conv = j == c.conv_layers - 1;
                     if (j == 0) {   // the stack's input (pitch stream | repeated up_sixth output) is assembled by the kernel's own loader
-                        if (run_p2p_bf16_ps(n, n->p2p[i][0], nullptr, nullptr, &sdesc, B, P, Ti, nullptr, d.out_p, oh, oh + plane, s, "conv_p2p_bf16_kernel")) continue;
+                        if (run_p2p_bf16_ps(n, n->p2p[i][0], nullptr, nullptr, &sdesc, B, P, Ti, nullptr, d.out_p, oh, oh + plane, nullptr, s, "conv_p2p_bf16_kernel")) continue;
                         if ((rc = run_p2p_bf16(n, n->p2p[i][0], nullptr, nullptr, &sdesc, B, P, Ti, nullptr, d.out_p, oh, oh + plane, s, "conv_p2p_bf16_kernel")))
                             return rc;
                     } else {
                         const unsigned short* xh = reinterpret_cast<const unsigned short*>(((j - 1) & 1) ? b.pb[i] : b.pa[i]);
+                        if (last_conv && p2p_fuses_semi(n, i, P, Ti) &&
+                            run_p2p_bf16_ps(n, n->p2p[i][j], xh, xh + plane, nullptr, B, P, Ti, out, d.out_p, nullptr, nullptr, &n->semi[i], s, "conv_p2p_bf16_kernel")) {
+                            fused_semi = true;    // `out` holds the semitone maps [clip][8][P / 3][T], not the pitch tensor
+                            continue;
+                        }
                         if (run_p2p_bf16_ps(n, n->p2p[i][j], xh, xh + plane, nullptr, B, P, Ti, last_conv ? out : nullptr, d.out_p, last_conv ? nullptr : oh,
-                                            last_conv ? nullptr : oh + plane, s, "conv_p2p_bf16_kernel"))
+                                            last_conv ? nullptr : oh + plane, nullptr, s, "conv_p2p_bf16_kernel"))
                             continue;
                         if ((rc = run_p2p_bf16(n, n->p2p[i][j], xh, xh + plane, nullptr, B, P, Ti, last_conv ? out : nullptr, d.out_p, last_conv ? nullptr : oh,
                                                last_conv ? nullptr : oh + plane, s, "conv_p2p_bf16_kernel")))
@@ -1361,7 +1421,9 @@ struct Fwd {
                 in_aff = out_aff;
             }
             // models.py:386-392  pool_semi -> fold, written next to pc in the concat buffer
-            if ((rc = semi(i, out, out_aff, B, P, Ti, cat, ctot, d.prev_pc, train ? b.aff_cat[i] + 3 * d.prev_pc : nullptr))) return rc;
+            if (fused_semi) {
+                if ((rc = run_fold_max(out, d.out_p, P / 3, B, Ti, cat, ctot, d.prev_pc, s))) return rc;
+            } else if ((rc = semi(i, out, out_aff, B, P, Ti, cat, ctot, d.prev_pc, train ? b.aff_cat[i] + 3 * d.prev_pc : nullptr))) return rc;
             if (last) return AKE_OK;                             // pc2pc + pooling + heads run batch-wide
             // inner layers of deeper nets: pc2pc, then both time pools (models.py:393-396)
             const float* psrc = cat;
@@ -1643,6 +1705,10 @@ static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frame
             }
             if (i >= 1 && nm == m + "p2p.layer." + std::to_string(3 * j + 2)) {
                 if (j < last_j - 1) break;
+                if (j == last_j && p2p_fuses_semi(n, i, P, Ti)) {
+                    ake::set_error("tap: '%s' is fused with the semitone conv that follows it (never written); ake_debug_keep_taps(1) before the forward keeps it", name);
+                    return AKE_ERR_INVALID;
+                }
                 // inference keeps the stack's intermediate activations as channels-last split-bf16 planes (conv_p2p_bf16_kernel)
                 if (j < last_j && p2p_uses_bf16(n, i, Ti) && channels_last) *channels_last = 1;
                 return set((j & 1) ? b.pb[i] : b.pa[i], d.out_p, P, Ti);
@@ -1658,6 +1724,12 @@ static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frame
     if (nm == "genre_map" && c.genre) return set(b.map_g, 1, 11, Tm);
     ake::set_error("tap: '%s' is not a materialised activation", name);
     return AKE_ERR_INVALID;
+}
+
+int ake_debug_keep_taps(int on) {
+    const int old = g_keep_taps;
+    g_keep_taps = on != 0;
+    return old;
 }
 
 int ake_pcnet_tap_info(const ake_pcnet* n, const char* name, int batch, int frames, int64_t shape[4]) {

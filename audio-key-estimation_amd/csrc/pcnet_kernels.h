@@ -742,17 +742,26 @@ struct P2pPsArgs {
     int c0, c1, h1;
     const uint4* bfrag;           // [14 k-steps][hi|lo][64 lanes] x 8 bf16
     const float* bias;            // [8]
-    float* dst;                   // NCHW f32 [clip][dst_ctot][H][T] (OUT_CL == false)
+    float* dst;                   // OUT == 0: NCHW f32 [clip][dst_ctot][H][T];  OUT == 2: semitone maps [clip][8][H / 3][T]
     long long dst_clip_stride;
-    unsigned short* oh;           // channels-last planes (OUT_CL == true)
+    unsigned short* oh;           // OUT == 1: channels-last planes
     unsigned short* ol;
+    const uint4* sfrag;           // OUT == 2: B fragments of the semitone conv [3 dy][hi|lo][64 lanes] x 8 bf16, and its bias [8]
+    const float* sbias;
     int H, T, R, J, Tp, n_row_tiles, n_tiles, plane_pos;   // plane_pos: (R + 6) * Tp rounded up to 64 positions
 };
 
 constexpr int kP2pPsStage = 80;      // uint4 per M-tile of a wave's staging slab (NCHW form: 8 channels x 36 floats, padded)
 
-template <bool OUT_CL, int NIN>        // NIN: 0 = channels-last split planes in; else the number of f32 channels the loader assembles (5: default net, 8: any)
+// OUT: 0 = NCHW f32, 1 = channels-last split planes (next conv of the stack), 2 = the stack's last conv FUSED with the semitone conv
+//   that follows it (3x3, stride (3,1), time circular + BN + LeakyReLU; models.py:337-339, 386-388): the activated tile (R = 3k rows)
+//   stays in LDS as split planes [plane][m][tau][8 ch] = position-major, the semitone conv runs over it on the same MFMA form
+//   (m = (semitone row, frame pair), n = (tau, co), k-step = one of its 3 rows: 4 positions x 8 channels, the 4th tap zero), one
+//   M-tile per wave, and only the semitone maps [clip][8][H / 3][T] go to memory: the 8 x H x T pitch tensor is never written.
+// NIN: 0 = channels-last split planes in; else the number of f32 channels the loader assembles (5: default net, 8: any)
+template <int OUT, int NIN>
 __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
+    constexpr bool OUT_CL = OUT == 1, OUT_SEMI = OUT == 2;
     constexpr bool IN_NCHW = NIN > 0;
     constexpr int NV = IN_NCHW ? NIN : 1;
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
@@ -872,7 +881,9 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
     }
     const int tau = r16 >> 3, co = r16 & 7;
     const float bias = a.bias[co];
-    uint4* const stage = lds4 + 4 * a.plane_pos + wave * (MT * kP2pPsStage);
+    uint4* const stage = lds4 + 4 * a.plane_pos + wave * (MT * kP2pPsStage);          // OUT 0 / 1: wave-private slabs
+    uint4* const opatch = lds4 + 4 * a.plane_pos;                                      // OUT 2: [2 buffers][hi|lo][384 m][2 tau] positions
+    constexpr int kOP = 8 * MT * 16 * 2;                                               // positions per plane of the output patch
     typedef float f32x2e __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2e __attribute__((ext_vector_type(2)));
     long long prev_base = 0;          // element offset of the pending tile's first position (channels-last: position index)
@@ -901,7 +912,7 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
     };
     // bias + LeakyReLU, transposed into the wave's staging slab
     typedef float f32x4c __attribute__((ext_vector_type(4)));
-    auto epilogue = [&](const f32x4c (&acc)[MT]) {
+    auto epilogue = [&](const f32x4c (&acc)[MT], int obuf) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             float v[4];
@@ -910,7 +921,7 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
                 const float x = acc[mt][i] + bias;
                 v[i] = x > 0.f ? x : x * kSlope;
             }
-            if (OUT_CL) {
+            if (OUT_CL || OUT_SEMI) {
                 // lanes (co, co ^ 1) trade halves: the even lane keeps rows m = 4q, 4q + 1 of both channels, the odd lane rows 4q + 2, 4q + 3
                 const bool odd = co & 1;
                 const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];
@@ -922,13 +933,16 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
                 const bf16x2e ha = __builtin_convertvector(xa, bf16x2e), hb = __builtin_convertvector(xb, bf16x2e);
                 const bf16x2e la = __builtin_convertvector(xa - __builtin_convertvector(ha, f32x2e), bf16x2e);
                 const bf16x2e lb = __builtin_convertvector(xb - __builtin_convertvector(hb, f32x2e), bf16x2e);
-                unsigned int* st = reinterpret_cast<unsigned int*>(stage + mt * kP2pPsStage);
+                // OUT 1: the M-tile's own slab; OUT 2: the tile-wide patch, m counted over the tile (= position 2m + tau: T = 2J)
+                unsigned int* st = OUT_SEMI ? reinterpret_cast<unsigned int*>(opatch + obuf * 2 * kOP) + (wave * MT + mt) * 128
+                                            : reinterpret_cast<unsigned int*>(stage + mt * kP2pPsStage);
+                constexpr int lo_plane = OUT_SEMI ? kOP * 4 : 128;       // dwords from the hi plane to the lo plane
                 const int ma = 4 * q + (odd ? 2 : 0);
                 const int d = ma * 8 + tau * 4 + (co >> 1);              // [plane][m][tau][co / 2] dwords
                 st[d] = __builtin_bit_cast(unsigned int, ha);
                 st[d + 8] = __builtin_bit_cast(unsigned int, hb);
-                st[128 + d] = __builtin_bit_cast(unsigned int, la);
-                st[128 + d + 8] = __builtin_bit_cast(unsigned int, lb);
+                st[lo_plane + d] = __builtin_bit_cast(unsigned int, la);
+                st[lo_plane + d + 8] = __builtin_bit_cast(unsigned int, lb);
             } else {
                 float* st = reinterpret_cast<float*>(stage + mt * kP2pPsStage);
 #pragma unroll
@@ -936,10 +950,44 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
             }
         }
     };
+    // ---- OUT 2: semitone conv over the finished tile (one M-tile of 16 (semitone row, frame pair) positions per wave) ----
+    uint4 sreg[6];
+    float sbias = 0.f;
+    int sbase = 0;
+    if (OUT_SEMI) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sreg[i] = a.sfrag[i * 64 + lane];
+        sbias = a.sbias[co];
+        int ms = wave * 16 + r16;
+        ms = ms < (a.R / 3) * J ? ms : (a.R / 3) * J - 1;
+        const int srow = ms / J, sj = ms - srow * J;
+        sbase = 3 * srow * T + wrap(2 * sj - 1 + q, T);               // A[m][k = (position q, ci)] = X[3s + dy][2j - 1 + q][ci]
+    }
+    auto semi_stage = [&](int obuf, long long base, int mblk) {      // base: element offset of (clip, channel 0, first semitone row) in dst
+        const uint4* const oH = opatch + obuf * 2 * kOP;
+        const uint4* const oL = oH + kOP;
+        f32x4c sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const bf16x8c ah = __builtin_bit_cast(bf16x8c, oH[sbase + dy * T]), al = __builtin_bit_cast(bf16x8c, oL[sbase + dy * T]);
+            const bf16x8c bh = __builtin_bit_cast(bf16x8c, sreg[2 * dy]), bl = __builtin_bit_cast(bf16x8c, sreg[2 * dy + 1]);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, sacc, 0, 0, 0);
+        }
+        const int S = a.H / 3;
+        float* const o = a.dst + base + static_cast<long long>(co) * S * T + tau;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                 // D[m = 4q + i][n = (tau, co)]: semitone position 2m + tau of the tile
+            const int m = wave * 16 + 4 * q + i;
+            const float x = sacc[i] + sbias;
+            if (3 * m < mblk) o[2 * m] = x > 0.f ? x : x * kSlope;
+        }
+    };
     // The waves 4..7 run their epilogue one barrier late (the accumulators wait in registers): each SIMD holds one wave of either
     // half, so one half's epilogue, loads and stores issue under the other half's MFMAs instead of all eight waves leaving the
     // matrix pipe idle together
-    const bool late = wave >= 4;
+    const bool late = !OUT_SEMI && wave >= 4;
     f32x4c acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
@@ -955,8 +1003,11 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
             else issue_loads(tile + nwg, cur ^ 1);
         }
         if (has_prev) {
-            if (late) epilogue(acc);
-            store_pending();
+            if (OUT_SEMI) semi_stage(cur ^ 1, prev_base, prev_mblk);
+            else {
+                if (late) epilogue(acc, 0);
+                store_pending();
+            }
         }
         const uint4* const pH = lds4 + (cur * 2) * a.plane_pos;
         const uint4* const pL = pH + a.plane_pos;
@@ -980,7 +1031,7 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt], 0, 0, 0);
         }
-        if (!late) epilogue(acc);
+        if (!late) epilogue(acc, cur);
         if (IN_NCHW && more) write_lds(cur ^ 1);
         {
             const int clip = tile / a.n_row_tiles;
@@ -988,13 +1039,19 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
             const int rows_here = a.H - y0 < a.R ? a.H - y0 : a.R;
             prev_mblk = rows_here * J;
             prev_base = OUT_CL ? static_cast<long long>(clip) * a.H * T + static_cast<long long>(y0) * T
-                               : clip * a.dst_clip_stride + static_cast<long long>(y0) * T;
+                      : OUT_SEMI ? clip * a.dst_clip_stride + static_cast<long long>(y0 / 3) * T
+                                 : clip * a.dst_clip_stride + static_cast<long long>(y0) * T;
         }
         has_prev = true;
     }
     if (has_prev) {
-        if (late) epilogue(acc);
-        store_pending();
+        if (OUT_SEMI) {
+            __syncthreads();          // every wave's share of the last tile is in the output patch
+            semi_stage(cur ^ 1, prev_base, prev_mblk);
+        } else {
+            if (late) epilogue(acc, 0);
+            store_pending();
+        }
     }
 }
 
@@ -1348,6 +1405,44 @@ __global__ void pack_p2p_bf16_kernel(const float* __restrict__ w, uint4* __restr
     }
     out[(2 * ks + 0) * 64 + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
     out[(2 * ks + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+// B fragments of the semitone conv fused into conv_p2p_bf16_ps_kernel<2, ...>, from its eval pack [ci < 8][3 dy][3 dx][8 co]:
+// k-step = dy, k = (position qq, ci), n = (tau, co), tap dx = qq - tau (the 4th position of either frame carries zero weights)
+__global__ void pack_semi_bf16_kernel(const float* __restrict__ w, uint4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (dy, lane)
+    if (i >= 3 * 64) return;
+    const int dy = i / 64, lane = i - dy * 64;
+    const int n = lane & 15, qq = lane >> 4;
+    const int tau = n >> 3, co = n & 7;
+    const int dx = qq - tau;
+    unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+    for (int ci = 0; ci < 8; ++ci) {
+        float v = 0.f;
+        if (dx >= 0 && dx < 3) v = w[((ci * 3 + dy) * 3 + dx) * 8 + co];
+        const unsigned int hb = bf16_bits(v);
+        const unsigned int lb = bf16_bits(v - __uint_as_float(hb << 16));
+        hi[ci >> 1] |= hb << (16 * (ci & 1));
+        lo[ci >> 1] |= lb << (16 * (ci & 1));
+    }
+    out[(2 * dy + 0) * 64 + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    out[(2 * dy + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+// Pitch2PitchClassPool (models.py:95-106) of ready semitone maps [clip][C][S][T], S a multiple of 12: max over the octaves
+__global__ void fold_max_kernel(const float* __restrict__ smap, int C, int S, int T, float* __restrict__ dst, long long dst_clip_stride, int dst_coff,
+                                long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;   // (clip, c, p, t)
+    if (i >= total) return;
+    const int t = static_cast<int>(i % T);
+    long long r = i / T;
+    const int p = static_cast<int>(r % 12); r /= 12;
+    const int c = static_cast<int>(r % C);
+    const long long clip = r / C;
+    const float* src = smap + ((clip * C + c) * S + p) * T + t;
+    float best = -INFINITY;
+    for (int o = 0; o < S / 12; ++o) best = fmaxf(best, src[static_cast<long long>(12 * o) * T]);
+    dst[clip * dst_clip_stride + (static_cast<long long>(dst_coff + c) * 12 + p) * T + t] = best;
 }
 
 // ==========================================================================================

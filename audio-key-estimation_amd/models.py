@@ -466,6 +466,12 @@ class PitchClassNet(LightningModule):
             bn.num_batches_tracked += 1
         # the device copy of the weights does not depend on the running statistics in train mode; eval re-syncs lazily
 
+    @staticmethod
+    def keep_taps(on=True):
+        """Debug: keep every activation that `tap` can name in memory (inference otherwise fuses the semitone conv into the last
+        pitch conv of a stack and never writes `model.i.p2p.layer.8`).  Process-wide; returns the previous setting."""
+        return bool(_lib.lib().ake_debug_keep_taps(1 if on else 0))
+
     def tap(self, name):
         """Intermediate activation of the last forward (debug / bisecting): reference module path -> tensor."""
         B, Tn = self._last_shape

@@ -236,7 +236,7 @@ def main():
     traffic_src, traffic = pmc_traffic()
     p2p_traffic = cqt_traffic = None
     if B == 256 and traffic:
-        bf_rows = [v for k, v in traffic.items() if k.startswith("conv_p2p_bf16_kernel")]
+        bf_rows = [v for k, v in traffic.items() if k.startswith("conv_p2p_bf16")]
         p2p_traffic = round(sum(v["hbm_bytes"] * v["dispatches"] for v in bf_rows) / max(1, sum(v["dispatches"] for v in bf_rows))) if bf_rows else None
         cqt_traffic = sum(v["hbm_bytes"] for k, v in traffic.items() if k.startswith("cqt_")) or None
     line = {

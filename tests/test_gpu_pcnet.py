@@ -59,6 +59,23 @@ def test_every_layer_against_reference_taps(gold_default, gold_taps):
     outs = net(x, torch.from_numpy(gold_taps["seq_length"]).to(DEV))
     for got, n in zip(outs, ("key", "tonic", "genre")):
         assert rel_err(got.cpu(), gold_taps[n]) < TOL
+    # inference fuses the semitone conv into the stack's last pitch conv: that conv's output is never written ...
+    with pytest.raises(ake_amd._lib.AkeError, match="fused with the semitone conv"):
+        net.tap("model.1.p2p.layer.8")
+    fused_cat = net.tap("model.1.cat").clone()
+    # ... unless the debug switch keeps every nameable activation in memory (the unfused kernels: f32 semitone conv)
+    was = net.keep_taps(True)
+    try:
+        outs = net(x, torch.from_numpy(gold_taps["seq_length"]).to(DEV))
+        _check_taps(net, outs, gold_taps)
+        assert rel_err(fused_cat.cpu(), net.tap("model.1.cat").cpu()) < 2e-5
+    finally:
+        net.keep_taps(was)
+
+
+def _check_taps(net, outs, gold_taps):
+    for got, n in zip(outs, ("key", "tonic", "genre")):
+        assert rel_err(got.cpu(), gold_taps[n]) < TOL
     # (the first conv of a 3-conv stack is overwritten by the third: ping-pong buffers; its effect is covered by the next tap)
     direct = ["model.0.pool", "model.0.pc2pc.layer.2", "model.0.pc2pc.layer.5", "model.1.up_sixth_a",
               "model.1.p2p.layer.5", "model.1.p2p.layer.8", "model.1.pc2pc.layer.5", "model.1.pc2pc.layer.8",
@@ -195,10 +212,10 @@ def test_persistent_pitch_conv_equals_per_tile_kernel_and_oracle(gold_default, B
     x = (torch.rand((B, 1, 288, T), generator=g) * 2.5).to(DEV)
     seq = torch.randint(26, T + 1, (B,), generator=g).to(DEV)
     key, tonic, genre = net(x, seq)
-    last = net.tap("model.1.p2p.layer.8").clone()                 # NCHW f32 output of the stack's last convolution
+    last = net.tap("model.1.cat").clone()                          # [pitch-class stream | folded semitone maps of the pitch stack]
     for lo in range(0, B, 4):                                      # 4 clips: far below two tiles per CU -> per-tile kernel
         ks, ts, gs = net(x[lo:lo + 4], seq[lo:lo + 4])
-        assert torch.equal(net.tap("model.1.p2p.layer.8"), last[lo:lo + 4]), lo
+        assert torch.equal(net.tap("model.1.cat"), last[lo:lo + 4]), lo
         assert torch.equal(ks, key[lo:lo + 4]) and torch.equal(ts, tonic[lo:lo + 4]) and torch.equal(gs, genre[lo:lo + 4]), lo
     idx = [0, B // 2, B - 1]
     sd = golden_state_dict(gold_default, torch.float64)
