@@ -1325,11 +1325,53 @@ struct Fwd {
                                coff, total);
     }
 
+    // inference, default family: the whole of phase A as one launch, one workgroup per clip (layer0_fused_kernel)
+    bool layer0_fused(const float* mel, int B) {
+        static const bool off = std::getenv("AKE_L0_FUSED") != nullptr && std::atoi(std::getenv("AKE_L0_FUSED")) == 0;
+        const auto& c = n->cfg;
+        const int P = c.pitches, T0 = b.Tl[0], NF = c.n_filters;
+        if (off || NF < 2 || NF > 4 || c.conv_layers < 1 || c.conv_layers > 4 || c.kernel_size != 7 || P % 36 || T0 < 1) return false;
+        const PackedConv& sp = n->semi[0];
+        if (sp.cin != 1 || sp.co != 1) return false;
+        for (int j = 0; j < c.conv_layers; ++j) {
+            const PackedConv& pc = n->pc2pc[0][j];
+            if (pc.co != 4 || pc.groups != 1 || pc.kh != 12 || pc.kw != 7 || pc.cout != NF || pc.cin != (j == 0 ? 1 : NF)) return false;
+        }
+        const LayerDims& d1 = n->dims[1];
+        if (d1.prev_pc != NF) return false;
+        Layer0Args a;
+        std::memset(&a, 0, sizeof(a));
+        a.RP = 4 * ((T0 + 3) / 4) + 8;
+        const size_t lds = (static_cast<size_t>(9) * 12 * a.RP + static_cast<size_t>(P) * T0) * sizeof(float);   // maps + the clip's CQT
+        if (lds > 150 * 1024 || (static_cast<long long>(P) * T0) % 4 || (reinterpret_cast<uintptr_t>(mel) & 15)) return false;
+        a.mel = mel; a.sw = n->blob_dev + sp.w_off; a.sb = n->blob_dev + sp.b_off;
+        const int ctot1 = d1.prev_pc + d1.out_p;
+        for (int j = 0; j < c.conv_layers; ++j) {
+            const PackedConv& pc = n->pc2pc[0][j];
+            const bool lastj = j == c.conv_layers - 1;
+            a.w[j] = n->blob_dev + pc.w_off; a.b[j] = n->blob_dev + pc.b_off;
+            a.dst[j] = lastj ? b.cat[1] : ((j & 1) ? b.pcb[0] : b.pca[0]);
+            a.dst_clip_stride[j] = static_cast<long long>(lastj ? ctot1 : NF) * 12 * T0;
+        }
+        a.uw = n->blob_dev + n->up[1].w_off; a.ub = n->blob_dev + n->up[1].b_off;
+        a.fold0 = b.fold0; a.psix = b.psix[1];
+        a.H = P; a.T = T0; a.NF = NF; a.n_conv = c.conv_layers;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(layer0_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return false;
+            attr_set = true;
+        }
+        ake::ProfScope ps("layer0_fused_kernel", s);
+        hipLaunchKernelGGL(layer0_fused_kernel, dim3(B), dim3(512), lds, s, a);
+        return true;
+    }
+
     // Phase A, whole batch: layer 0 (models.py:361-369) and layer 1's up_sixth (models.py:372-374).
     int entry(const float* mel, int B) {
         const auto& c = n->cfg;
         const int L = c.num_layers, P = c.pitches, T0 = b.Tl[0];
         int rc;
+        if (!train && L > 1 && layer0_fused(mel, B)) return AKE_OK;
         if ((rc = semi(0, mel, nullptr, B, P, T0, b.fold0, 1, 0, nullptr))) return rc;
         if (L == 1) return AKE_OK;                               // its pc2pc runs in the tail
         const LayerDims& d1 = n->dims[1];

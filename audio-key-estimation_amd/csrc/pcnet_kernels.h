@@ -1446,6 +1446,160 @@ __global__ void fold_max_kernel(const float* __restrict__ smap, int C, int S, in
 }
 
 // ==========================================================================================
+// Layer 0 of the net in ONE launch (inference; models.py:361-374): semitone conv (1 channel) + octave fold, the
+// PitchClass2PitchClass stack 1 -> NF -> NF -> NF (12 x 7, pitch classes circular, time zero-padded; NF <= 4), and layer 1's
+// up_sixth (ConvTranspose (3,1)).  All of it is 2.9 M MAC on a 12 x T map per clip: five launches of 15-30 us each were
+// mostly launch and tail.  One workgroup per clip keeps every map in LDS ([ch][12][T + 6 zero pad], 16-byte aligned rows);
+// thread = (output-channel pair, pitch class, strip of 4 frames): 3 aligned 16-byte LDS reads feed 56 FMAs, the weights are
+// wave-uniform (scalar loads).  The taps of the reference modules (fold output, conv outputs) are still written.
+// ==========================================================================================
+struct Layer0Args {
+    const float* mel;            // [clip][1][H][T]
+    const float* sw;             // semitone conv pack [1][3][3][1] and bias
+    const float* sb;
+    const float* w[4];           // conv packs [ci][12][7][4 co] and biases (BatchNorm folded)
+    const float* b[4];
+    float* dst[4];               // conv outputs [clip][dst_ctot][12][T] (the last one: channels [0, NF) of layer 1's concat buffer)
+    long long dst_clip_stride[4];
+    const float* uw;             // up_sixth pack [ci][co][3] and bias
+    const float* ub;
+    float* fold0;                // [clip][1][12][T]
+    float* psix;                 // [clip][NF][36][T]
+    int H, T, RP, NF, n_conv;    // RP: LDS row pitch in floats (T + 6 rounded up to 4)
+};
+
+__global__ __launch_bounds__(512) void layer0_fused_kernel(Layer0Args a) {
+    extern __shared__ __attribute__((aligned(16))) float l0[];
+    const int clip = blockIdx.x, tid = threadIdx.x;
+    const int T = a.T, RP = a.RP, NF = a.NF;
+    float* const f0 = l0;                        // [12][RP]
+    float* const actA = l0 + 12 * RP;            // [4][12][RP]
+    float* const actB = actA + 4 * 12 * RP;
+    for (int i = tid; i < 9 * 12 * RP; i += 512) l0[i] = 0.f;
+    __syncthreads();
+    // ---- semitone conv + BN + LeakyReLU + octave fold (models.py:313-315, 95-106) ----
+    // the clip's CQT (H x T floats) is streamed into LDS first: every load in flight at once, instead of eight dependent round trips
+    {
+        float* const ml = actB + 4 * 12 * RP;                      // [H][T]
+        const float4* mel4 = reinterpret_cast<const float4*>(a.mel + static_cast<long long>(clip) * a.H * T);
+        const int n4 = a.H * T / 4;                                // (the launcher requires H * T % 4 == 0)
+        for (int i = tid; i < n4; i += 512) reinterpret_cast<float4*>(ml)[i] = mel4[i];
+        __syncthreads();
+        float w9[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) w9[i] = a.sw[i];
+        const float sb = a.sb[0];
+        const int n_oct = a.H / 36;
+        for (int i = tid; i < 12 * T; i += 512) {
+            const int p = i / T, t = i - p * T;
+            const int tm = t == 0 ? T - 1 : t - 1, tp = t == T - 1 ? 0 : t + 1;
+            float best = -INFINITY;
+            for (int o = 0; o < n_oct; ++o) {
+                const float* r = ml + 3 * (p + 12 * o) * T;
+                float acc = 0.f;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    acc = fmaf(r[dy * T + tm], w9[dy * 3 + 0], acc);
+                    acc = fmaf(r[dy * T + t], w9[dy * 3 + 1], acc);
+                    acc = fmaf(r[dy * T + tp], w9[dy * 3 + 2], acc);
+                }
+                float v = acc + sb;
+                v = v > 0.f ? v : v * kSlope;
+                best = fmaxf(best, v);
+            }
+            f0[p * RP + 3 + t] = best;
+            a.fold0[(static_cast<long long>(clip) * 12 + p) * T + t] = best;
+        }
+    }
+    __syncthreads();
+    // ---- the convolution stack ----
+    const int nst = (T + 3) / 4;                                   // strips of 4 frames per row
+    const int cp = __builtin_amdgcn_readfirstlane(tid >> 8);       // output channels 2cp, 2cp + 1 (wave-uniform)
+    const int item = tid & 255;
+    const float* in = f0;
+    float* out = actA;
+    int cin = 1;
+    for (int j = 0; j < a.n_conv; ++j) {
+        // the weights through the constant address space: hipcc then knows that the kernel's own stores cannot change them and
+        // fetches them with scalar loads (as plain global pointers they became 14 vector loads + waits per 56 FMAs)
+        typedef const float __attribute__((address_space(4))) cfloat;
+        cfloat* w = (cfloat*)(a.w[j] + 2 * cp);
+        for (int it = item; it < 12 * nst; it += 256) {
+            const int p = it / nst, t0 = 4 * (it - p * nst);
+            float acc[2][4];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[c][k] = 0.f;
+            for (int ci = 0; ci < cin; ++ci) {
+#pragma unroll 4
+                for (int dy = 0; dy < 12; ++dy) {   // (unrolled: the scalar weight loads of four rows are requested together)
+                    int row = p + dy;
+                    row -= row >= 12 ? 12 : 0;
+                    const float4* rp = reinterpret_cast<const float4*>(in + (ci * 12 + row) * RP + t0);   // padded index t0 = frame t0 - 3
+                    const float4 x0 = rp[0], x1 = rp[1], x2 = rp[2];
+                    const float x[12] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
+                    cfloat* wr = w + (ci * 12 + dy) * 28;
+#pragma unroll
+                    for (int dx = 0; dx < 7; ++dx) {
+                        const float w0 = wr[dx * 4], w1 = wr[dx * 4 + 1];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            acc[0][k] = fmaf(x[k + dx], w0, acc[0][k]);
+                            acc[1][k] = fmaf(x[k + dx], w1, acc[1][k]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int co = 2 * cp + c;
+                if (co < NF) {
+                    const float bias = a.b[j][co];
+                    float* g = a.dst[j] + clip * a.dst_clip_stride[j] + (static_cast<long long>(co) * 12 + p) * T;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (t0 + k < T) {
+                            float v = acc[c][k] + bias;
+                            v = v > 0.f ? v : v * kSlope;
+                            out[(co * 12 + p) * RP + 3 + t0 + k] = v;
+                            g[t0 + k] = v;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        in = out;
+        out = out == actA ? actB : actA;
+        cin = NF;
+    }
+    // ---- layer 1's up_sixth + BN + LeakyReLU (models.py:325-327): out[co][3p + jj][t] = lrelu(b[co] + sum_ci in[ci][p][t] w[ci][co][jj]) ----
+    if (a.psix) {   // thread = (pitch class, frame): the 4 inputs once, then the NF x 3 outputs with wave-uniform (scalar) weights
+        typedef const float __attribute__((address_space(4))) cfloat;
+        cfloat* uw = (cfloat*)a.uw;
+        cfloat* ub = (cfloat*)a.ub;
+        float* ps = a.psix + static_cast<long long>(clip) * NF * 36 * T;
+        for (int i = tid; i < 12 * T; i += 512) {
+            const int p = i / T, t = i - p * T;
+            float x[4];
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) x[ci] = in[(ci * 12 + p) * RP + 3 + t];       // channels >= NF are zero
+            for (int co = 0; co < NF; ++co) {
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    float acc = ub[co];
+#pragma unroll
+                    for (int ci = 0; ci < 4; ++ci)
+                        if (ci < NF) acc = fmaf(x[ci], uw[(ci * NF + co) * 3 + jj], acc);
+                    ps[(static_cast<long long>(co) * 36 + 3 * p + jj) * T + t] = acc > 0.f ? acc : acc * kSlope;
+                }
+            }
+        }
+    }
+}
+
+// ==========================================================================================
 // Training-mode forward helpers (BatchNorm with batch statistics, nn.BatchNorm2d in train(), models.py:196 etc.)
 // ==========================================================================================
 
