@@ -249,15 +249,17 @@ def main():
                    "clips_per_gpu": B, "n_samples": N_SAMPLES, "frames": T_FRAMES, "weights": "tests/golden/pcnet_default.npz (seeded)",
                    "parallelism": f"clip-sharded x{world}, no data-path collective"},
         "roofline": {"bound": "mfma",
-                     "kernel": "conv_p2p_bf16_kernel (7x7 circular pitch convolution, 8 channels, split-bf16 operands on v_mfma_f32_16x16x32_bf16 "
-                               "with f32 accumulation: 3 MFMA products per algorithmic MAC), 3 launches per step",
+                     "kernel": "conv_p2p_bf16_ps_kernel (persistent 7x7 circular pitch convolution, 8 channels, split-bf16 operands on "
+                               "v_mfma_f32_16x16x32_bf16 with f32 accumulation: 3 MFMA products per algorithmic MAC), 3 launches per step; the third "
+                               "also runs the semitone conv on its output tile and writes only the semitone maps",
                      "achieved": round(achieved, 2) if achieved else None, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_BF16_TFLOPS, 4) if achieved else None,
                      "mfma_products_per_mac": 3,
                      "frac_of_split_ceiling": round(3 * achieved / PEAK_BF16_TFLOPS, 4) if achieved else None,
                      "traffic": p2p_traffic,
                      "traffic_source": f"profiles/{traffic_src}: mean HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE" if p2p_traffic else None,
-                     "algorithmic_bytes_per_launch": B * (8 + 8) * P * T_FRAMES * 4,
+                     # mean over the three launches: (1 CQT + 4 x 36-row up_sixth channels -> 8 channels), (8 -> 8), (8 -> 8 semitone channels of P / 3 rows)
+                     "algorithmic_bytes_per_launch": B * T_FRAMES * 4 * ((P + 4 * 36 + 8 * P) + (8 * P + 8 * P) + (8 * P + 8 * P // 3)) // 3,
                      "avg_launch_ms": round(p2p_ms / p2p_n, 4) if p2p_n else None, "launches_per_step": launches_per_step,
                      "algorithmic_flops_per_clip": 2 * P2P_MACS_PER_CLIP},
         "roofline_cqt": {"bound": "hbm", "kernels": " + ".join(sorted(k for k in prof_all if k.startswith("cqt_"))), "achieved": round(cqt_gbs, 1) if cqt_gbs else None,
