@@ -50,6 +50,8 @@ SYMBOLS = {
     "ake_pcnet_finalize": (_I, [_P]),
     "ake_pcnet_workspace_bytes": (_SZ, [_P, _I, _I]),
     "ake_pcnet_forward_f32": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "ake_pcnet_local_frames": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "ake_pcnet_forward_local_f32": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "ake_pcnet_num_bn": (_I, [_P]),
     "ake_pcnet_bn_info": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_I), C.POINTER(_I)]),
     "ake_pcnet_train_workspace_bytes": (_SZ, [_P, _I, _I]),

@@ -254,6 +254,7 @@ bool choose_tile(bool fullrows, int cin, int H, int KH, int T_out, int TB, int K
         const int n_tt_eff = (T_out + TT - 1) / TT;
         const int J = (TT + TB - 1) / TB;
         const int Tp = (TB * J - TB + KU + 3) / 4 * 4;
+        if (Tp > 192) continue;                                          // the kernel's loader walks a patch row in at most 3 x 64 frames
         for (int R = fullrows ? H : 1; R <= (fullrows ? H : std::min(H, 64)); ++R) {
             if (R * J > cap) break;
             const int R_in = R + KH - 1;                                 // the row halo is always materialised
@@ -718,9 +719,10 @@ int ake_pcnet_default_config(ake_pcnet_config* cfg, int octaves, int genre) {
 int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
     AKE_REQUIRE(cfg && out, AKE_ERR_INVALID, "ake_pcnet_create: null argument");
     const ake_pcnet_config& c = *cfg;
-    AKE_REQUIRE(!(c.resblock || c.denseblock || c.stay_sixth || c.only_semitones || c.p2pc_conv || c.pc2p_mem || c.local),
+    AKE_REQUIRE(!(c.resblock || c.denseblock || c.stay_sixth || c.only_semitones || c.p2pc_conv || c.pc2p_mem),
                 AKE_ERR_UNSUPPORTED,
-                "pcnet: resblock/denseblock/stay_sixth/only_semitones/p2pc_conv/pc2p_mem/local variants are not built");
+                "pcnet: resblock/denseblock/stay_sixth/only_semitones/p2pc_conv/pc2p_mem variants are not built");
+    AKE_REQUIRE(c.local >= 0, AKE_ERR_INVALID, "pcnet: local = pooling window of the --local heads (0: off)");
     AKE_REQUIRE(c.pitch_classes == 12, AKE_ERR_UNSUPPORTED, "pcnet: pitch_classes must be 12");
     AKE_REQUIRE(c.pitches > 0 && c.pitches % 36 == 0, AKE_ERR_INVALID, "pcnet: pitches must be a multiple of 36");
     AKE_REQUIRE(c.kernel_size == 7, AKE_ERR_UNSUPPORTED, "pcnet: only kernel_size 7 is built");
@@ -729,6 +731,7 @@ int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
     AKE_REQUIRE(c.time_pool_size >= 1, AKE_ERR_INVALID, "pcnet: bad time_pool_size");
     auto* n = new ake_pcnet();
     n->cfg = c;
+    if (c.local > 0) n->cfg.time_pool_size = 1;           // --local: the layers do not pool over time (models.py:348, 394)
     if (const char* e = std::getenv("AKE_PCNET_CHUNK")) n->chunk_clips = std::max(1, std::atoi(e));
     const int nf = c.n_filters, L = c.num_layers, k = c.kernel_size;
     n->dims.resize(L);
@@ -1607,6 +1610,18 @@ struct Fwd {
             }
             Tm = Tcur;
         }
+        if (c.local > 0) {   // ---- --local: sliding-window max over the maps, per-frame outputs (models.py:720-722, 805-810) ----
+            AKE_REQUIRE(Tm >= c.local, AKE_ERR_INVALID, "pcnet --local: %d map frames are fewer than the pooling window %d", Tm, c.local);
+            LocalPoolArgs la;
+            std::memset(&la, 0, sizeof(la));
+            la.maps[0] = b.map_k; la.maps[1] = b.map_t; la.maps[2] = c.genre ? b.map_g : nullptr;
+            la.outs[0] = key_out; la.outs[1] = tonic_out; la.outs[2] = genre_out;
+            la.Tm = Tm; la.Tq = Tm - c.local + 1; la.W = c.local; la.batch = B;
+            ake::ProfScope ps("local_pool_kernel", s);
+            hipLaunchKernelGGL(local_pool_kernel, dim3(static_cast<unsigned>((static_cast<long long>(B) * 12 * Tm + 255) / 256), 3), dim3(256), 0, s, la);
+            AKE_HIP_CHECK(hipGetLastError());
+            return AKE_OK;
+        }
         // ---- masked temporal mean, sigmoid (models.py:754-804) ----
         PoolHeadArgs pa;
         std::memset(&pa, 0, sizeof(pa));
@@ -1670,6 +1685,7 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     AKE_REQUIRE(n && mel && key_out && d_key && d_tonic && grads_out, AKE_ERR_INVALID, "pcnet backward: null argument");
     AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
     AKE_REQUIRE(!n->cfg.genre || d_genre, AKE_ERR_INVALID, "pcnet backward: genre head enabled but d_genre is null");
+    AKE_REQUIRE(n->cfg.local == 0, AKE_ERR_UNSUPPORTED, "pcnet: training a --local net is not built");
     Buffers b;
     int rc = plan_buffers(n, batch, batch, frames, workspace, &b, true);
     if (rc) return rc;
@@ -1689,15 +1705,33 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     return AKE_OK;
 }
 
+int ake_pcnet_local_frames(const ake_pcnet* n, int frames, int* pooled_frames, int* map_frames) {
+    AKE_REQUIRE(n && n->cfg.local > 0, AKE_ERR_STATE, "pcnet: the net was not created with local > 0");
+    int t = frames;
+    for (int i = 1; i < n->cfg.num_layers; ++i) t /= n->cfg.time_pool_size;
+    t -= (n->cfg.kernel_size - 1) * n->cfg.head_layers;
+    if (map_frames) *map_frames = t;
+    if (pooled_frames) *pooled_frames = t - n->cfg.local + 1;
+    return AKE_OK;
+}
+
+int ake_pcnet_forward_local_f32(const ake_pcnet* n, const float* mel, int batch, int frames, float* key_out, float* tonic_out, float* genre_out,
+                                void* workspace, size_t ws_bytes, ake_stream_t stream) {
+    AKE_REQUIRE(n && n->cfg.local > 0, AKE_ERR_STATE, "pcnet: the net was not created with local > 0");
+    return forward_impl(n, false, mel, batch, frames, nullptr, key_out, tonic_out, genre_out, nullptr, workspace, ws_bytes, stream);
+}
+
 int ake_pcnet_forward_f32(const ake_pcnet* n, const float* mel, int batch, int frames, const int64_t* seq_length,
                           float* key_out, float* tonic_out, float* genre_out, void* workspace, size_t ws_bytes,
                           ake_stream_t stream) {
+    AKE_REQUIRE(!n || n->cfg.local == 0, AKE_ERR_STATE, "pcnet: a --local net returns per-frame outputs: call ake_pcnet_forward_local_f32");
     return forward_impl(n, false, mel, batch, frames, seq_length, key_out, tonic_out, genre_out, nullptr, workspace, ws_bytes, stream);
 }
 
 int ake_pcnet_forward_train_f32(const ake_pcnet* n, const float* mel, int batch, int frames, const int64_t* seq_length,
                                 float* key_out, float* tonic_out, float* genre_out, float* bn_stats_out, void* workspace,
                                 size_t ws_bytes, ake_stream_t stream) {
+    AKE_REQUIRE(!n || n->cfg.local == 0, AKE_ERR_UNSUPPORTED, "pcnet: training a --local net (per-frame losses, models.py:861-876) is not built");
     return forward_impl(n, true, mel, batch, frames, seq_length, key_out, tonic_out, genre_out, bn_stats_out, workspace, ws_bytes, stream);
 }
 

@@ -1599,6 +1599,33 @@ __global__ __launch_bounds__(512) void layer0_fused_kernel(Layer0Args a) {
     }
 }
 
+// --local (models.py:720-722, 805-810): the key / tonic heads end in MaxPool2d((1, W), stride 1) and the maps are returned per
+// frame.  The reference then *reshapes* [B][1][12][T'] to (B, T', 12) -- the same bytes -- so the outputs are written in the maps'
+// own order: out[(clip * 12 + p) * Tq + t] = max_{w < W} map[(clip * 12 + p) * Tm + t + w]; sigmoid on key; genre is the map itself.
+struct LocalPoolArgs {
+    const float* maps[3];     // key, tonic, genre (genre may be null)
+    float* outs[3];
+    int Tm, Tq, W, batch;
+};
+
+__global__ void local_pool_kernel(LocalPoolArgs a) {
+    const int which = blockIdx.y;
+    if (!a.maps[which]) return;
+    const int rows = which == 2 ? 11 : 12;
+    const int To = which == 2 ? a.Tm : a.Tq;
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= static_cast<long long>(a.batch) * rows * To) return;
+    const int t = static_cast<int>(i % To);
+    const long long row = i / To;
+    const float* m = a.maps[which] + row * a.Tm + t;
+    float v = m[0];
+    if (which < 2) {
+        for (int w = 1; w < a.W; ++w) v = fmaxf(v, m[w]);
+        if (which == 0) v = 1.f / (1.f + expf(-v));
+    }
+    a.outs[which][i] = v;
+}
+
 // ==========================================================================================
 // Training-mode forward helpers (BatchNorm with batch statistics, nn.BatchNorm2d in train(), models.py:196 etc.)
 // ==========================================================================================

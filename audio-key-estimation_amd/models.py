@@ -22,7 +22,7 @@ from . import _lib
 from .lightning_shim import LightningModule
 from .metrics import mirex_score as _mirex_score
 
-_VARIANT_FLAGS = ("resblock", "denseblock", "stay_sixth", "only_semitones", "p2pc_conv", "pc2p_mem", "local")
+_VARIANT_FLAGS = ("resblock", "denseblock", "stay_sixth", "only_semitones", "p2pc_conv", "pc2p_mem")
 
 
 class EquivariantPitchClassConvolutionSimple(nn.Module):
@@ -140,6 +140,15 @@ class PitchClassNet(LightningModule):
                 raise NotImplementedError(f"--{flag} selects a non-default architecture variant that the HIP path does not build "
                                           "(SURVEY.md section 2.1); only the default PitchClassNet family is available")
         nf, k = self.n_filters, kernel_size
+        # --local (sliding-window key tracking, models.py:720-722): no time pooling in the layers, the key / tonic heads end in
+        # MaxPool2d((1, W), stride 1) -- parameter-free, so the state_dict is the default net's.  Inference only here.
+        self.local = bool(_opt_get(opt, "local", False))
+        self.local_window = 0
+        if self.local:
+            self.local_window = int(_opt_get(opt, "frames", 5) * _opt_get(opt, "loc_window_size", 10)
+                                    - _opt_get(opt, "head_layers", 2) * (kernel_size - 1))
+            if self.local_window < 1:
+                raise ValueError("--local: frames * loc_window_size must exceed head_layers * (kernel_size - 1)")
         self.model = nn.Sequential(*[PitchClassNetLayer(i, nf, k, self.conv_layers) for i in range(num_layers)])
         final = nf if num_layers == 1 else self.model[num_layers - 1].out_pc          # models.py:694-710
         self.head_layers = _opt_get(opt, "head_layers", 2)
@@ -185,6 +194,7 @@ class PitchClassNet(LightningModule):
         c.time_pool_size = _opt_get(self.opt, "time_pool_size", 2)
         c.genre = 1 if self.genre else 0
         c.max_pool = 1 if _opt_get(self.opt, "max_pool", False) else 0
+        c.local = self.local_window
         return c
 
     def _layout(self):
@@ -341,6 +351,8 @@ class PitchClassNet(LightningModule):
         out_dtype = mel.dtype if mel.is_floating_point() else torch.float32
         x = mel.to(device=device, dtype=torch.float32).contiguous()
         B, _, _, Tn = x.shape
+        if self.local:
+            return self._forward_local(x, out_dtype)
         seq = None
         if seq_length is not None:
             seq = torch.as_tensor(seq_length).to(device=device, dtype=torch.int64).reshape(-1)
@@ -372,6 +384,31 @@ class PitchClassNet(LightningModule):
         if self.genre:
             return key.to(out_dtype), tonic.to(out_dtype), genre.to(out_dtype)               # models.py:813
         return key.to(out_dtype), tonic.to(out_dtype)                                         # models.py:815
+
+    def _forward_local(self, x, out_dtype):
+        """--local (models.py:805-810): per-frame outputs key (B, T', 12) with sigmoid, tonic (B, T', 12), genre (B, Tm, 11); the
+        shapes are the reference's ``reshape`` of the (B, 1, rows, frames) maps -- a reinterpretation, not a transpose."""
+        if self.training:
+            raise NotImplementedError("training a --local net (per-frame losses, models.py:861-876) is not built on the HIP path")
+        device = x.device
+        B, _, _, Tn = x.shape
+        L = _lib.lib()
+        tq, tm = C.c_int(), C.c_int()
+        _lib.check(L.ake_pcnet_local_frames(self._h, Tn, C.byref(tq), C.byref(tm)), "ake_pcnet_local_frames")
+        if tq.value < 1:
+            raise _lib.AkeError(f"--local: {Tn} frames leave {tm.value} map frames, fewer than the pooling window {self.local_window}")
+        key = torch.empty((B, tq.value, 12), dtype=torch.float32, device=device)
+        tonic = torch.empty((B, tq.value, 12), dtype=torch.float32, device=device)
+        genre = torch.empty((B, tm.value, 11), dtype=torch.float32, device=device) if self.genre else None
+        with torch.cuda.device(device):
+            ws = self._workspace(L.ake_pcnet_workspace_bytes(self._h, B, Tn), device)
+            _lib.check(L.ake_pcnet_forward_local_f32(self._h, x.data_ptr(), B, Tn, key.data_ptr(), tonic.data_ptr(),
+                                                     genre.data_ptr() if genre is not None else None, ws.data_ptr(), ws.numel(),
+                                                     torch.cuda.current_stream().cuda_stream), "ake_pcnet_forward_local_f32")
+        self._last_shape = (B, Tn)
+        if self.genre:
+            return key.to(out_dtype), tonic.to(out_dtype), genre.to(out_dtype)
+        return key.to(out_dtype), tonic.to(out_dtype)
 
     def _forward_train_raw(self, x, seq):
         """x (B,1,P,T) float32 contiguous on the device -> float32 outputs; updates the BatchNorm running statistics."""

@@ -100,7 +100,11 @@ typedef struct ake_pcnet_config {
     int max_pool;       /* opt.max_pool (models.py:766-797, sample-0 quirk kept) */
     /* Non-default architecture variants (models.py:108-133,145-166,402-648): must be 0,
      * ake_pcnet_create returns AKE_ERR_UNSUPPORTED otherwise. */
-    int resblock, denseblock, stay_sixth, only_semitones, p2pc_conv, pc2p_mem, local;
+    int resblock, denseblock, stay_sixth, only_semitones, p2pc_conv, pc2p_mem;
+    /* opt.local (sliding-window key tracking, models.py:720-722): 0 = off, else the heads' pooling window
+     * W = opt.frames * opt.loc_window_size - head_layers * (kernel_size - 1).  The layers then do not pool over time
+     * (models.py:348, 394: time_pool_size is ignored) and the forward is ake_pcnet_forward_local_f32.  Inference only. */
+    int local;
 } ake_pcnet_config;
 
 int ake_pcnet_default_config(ake_pcnet_config* cfg, int octaves, int genre);
@@ -139,6 +143,16 @@ size_t ake_pcnet_workspace_bytes(const ake_pcnet* net, int batch, int frames);
 int ake_pcnet_forward_f32(const ake_pcnet* net, const float* mel_dev, int batch, int frames,
                           const int64_t* seq_length_dev, float* key_out_dev, float* tonic_out_dev,
                           float* genre_out_dev, void* workspace, size_t workspace_bytes, ake_stream_t stream);
+
+/* --local forward (net created with cfg.local = W > 0; models.py:805-810).  Tm = frames - head_layers * (kernel_size - 1) map
+ * frames, Tq = Tm - W + 1 pooled frames (ake_pcnet_local_frames).  Outputs, in the reference's memory order (it *reshapes*
+ * [B][1][12][Tq] to (B, Tq, 12) -- same bytes):
+ *   key_out_dev, tonic_out_dev : [batch][12 * Tq]   sliding max over W frames of the head maps; sigmoid on key
+ *   genre_out_dev              : [batch][11 * Tm]   the genre head's map */
+int ake_pcnet_local_frames(const ake_pcnet* net, int frames, int* pooled_frames, int* map_frames);
+int ake_pcnet_forward_local_f32(const ake_pcnet* net, const float* mel_dev, int batch, int frames, float* key_out_dev,
+                                float* tonic_out_dev, float* genre_out_dev, void* workspace, size_t workspace_bytes,
+                                ake_stream_t stream);
 
 /* Training-mode forward: BatchNorm uses the statistics of this batch (nn.BatchNorm2d in train(), as
  * equivariance_test.py:178 runs the net and as training_step does, models.py:952).  Convolutions keep their raw

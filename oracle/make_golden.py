@@ -255,6 +255,24 @@ def main():
                  step_metrics=np.array([float(v) for v in out[1:]], np.float32))
     np.savez_compressed(os.path.join(GOLD, "mirex_loss_cases.npz"), **cases)
 
+    # ---------------------------------------------------------------- E: --local (sliding-window key tracking), B=2, T=120
+    print("E: --local heads (MaxPool2d((1, 38), stride 1) + per-frame reshape), weights of A, B=2, T=120")
+    opt_l = default_opt(local=True)
+    torch.manual_seed(0)
+    net_l = models.PitchClassNet(opt_l.octaves * 36, 12, opt_l.num_layers, opt_l.kernel_size, opt_l, window_size=opt_l.window_size).double()
+    net_l.load_state_dict(sd, strict=True)             # the pooling layers carry no parameters: same keys as the default net
+    net_l.eval()
+    gl = torch.Generator().manual_seed(321)
+    xl = (torch.rand((2, 1, 288, 120), generator=gl) * 2.5).float()
+    W = opt_l.frames * opt_l.loc_window_size - opt_l.head_layers * (opt_l.kernel_size - 1)
+    kl, tl, gnl = net_l(xl.double(), torch.tensor([120, 120]))
+    okl, otl, ogl = pcnet_oracle.pcnet_forward(sd, xl.double(), torch.tensor([120, 120]), local_window=W)
+    report["checks"]["E_key"] = check("local key", okl, kl, 1e-12)
+    report["checks"]["E_tonic"] = check("local tonic", otl, tl, 1e-12)
+    report["checks"]["E_genre"] = check("local genre", ogl, gnl, 1e-12)
+    np.savez_compressed(os.path.join(GOLD, "pcnet_local_T120.npz"), x=xl.numpy(), window=np.int64(W),
+                        key=kl.numpy(), tonic=tl.numpy(), genre=gnl.numpy())
+
     with open(os.path.join(GOLD, "PROVENANCE.json"), "w") as f:
         json.dump(report, f, indent=1)
     print("wrote", sorted(os.listdir(GOLD)))

@@ -226,14 +226,20 @@ def _genre_head(pc, sd, training=False):
 def pcnet_forward(sd: Dict[str, torch.Tensor], mel: torch.Tensor, seq_length: Optional[torch.Tensor],
                   kernel_size: int = 7, head_layers: int = 2, time_pool_size: int = 2,
                   genre: Optional[bool] = None, max_pool: bool = False, training: bool = False,
-                  taps: Optional[dict] = None) -> Tuple[torch.Tensor, ...]:
-    """PitchClassNet.forward, models.py:747-817 (``opt.local`` False).
+                  taps: Optional[dict] = None, local_window: Optional[int] = None) -> Tuple[torch.Tensor, ...]:
+    """PitchClassNet.forward, models.py:747-817.
 
     Returns ``(key_out, tonic_out[, genre_out])`` exactly as the reference:
     sigmoid on key only (:802), 2-tuple when there is no genre head (:815).
+
+    ``local_window`` = ``opt.frames * opt.loc_window_size - head_layers * (kernel_size - 1)`` selects ``--local``
+    (models.py:720-722, 805-810): the key / tonic heads end in ``MaxPool2d((1, W), stride=1)`` and the maps are returned per
+    frame -- *reshaped*, not transposed, to ``(B, T', 12)`` (the reference's ``reshape``, kept as it is), genre ``(B, Tm, 11)``.
     """
     if genre is None:
         genre = "genre_classifier.0.weight" in sd
+    if local_window is not None:
+        time_pool_size = 1                                                           # :348, :394 -- no time pooling with --local
     p, pc, num_layers = forward_features(sd, mel, time_pool_size, training, taps)   # :749
     tonic = _equiv_head(pc, sd, "tonic_classifier", training)                        # :750
     key = _equiv_head(pc, sd, "key_classifier", training)                            # :751
@@ -242,6 +248,14 @@ def pcnet_forward(sd: Dict[str, torch.Tensor], mel: torch.Tensor, seq_length: Op
         taps["tonic_map"], taps["key_map"] = tonic, key
         if genre:
             taps["genre_map"] = gen
+    if local_window is not None:                                                     # :720-722, :805-810
+        tonic = F.max_pool2d(tonic, kernel_size=(1, local_window), stride=1)
+        key = F.max_pool2d(key, kernel_size=(1, local_window), stride=1)
+        tonic_out = tonic.reshape(tonic.shape[0], tonic.shape[3], tonic.shape[2])
+        key_out = torch.sigmoid(key.reshape(key.shape[0], key.shape[3], key.shape[2]))
+        if genre:
+            return key_out, tonic_out, gen.reshape(gen.shape[0], gen.shape[3], gen.shape[2])
+        return key_out, tonic_out
 
     def pool_all(x):
         return x.max(dim=-1).values if max_pool else x.mean(dim=-1)

@@ -46,6 +46,11 @@ def gold_guard():
 
 
 @pytest.fixture(scope="session")
+def gold_local():
+    return load_golden("pcnet_local_T120.npz")
+
+
+@pytest.fixture(scope="session")
 def gold_mirex():
     return load_golden("mirex_loss_cases.npz")
 

@@ -87,10 +87,26 @@ def test_set_tensor_validation_and_strict_finalize(gold_default):
     lib.ake_pcnet_destroy(h)
 
 
-@pytest.mark.parametrize("flag", ["resblock", "denseblock", "stay_sixth", "only_semitones", "p2pc_conv", "pc2p_mem", "local"])
+@pytest.mark.parametrize("flag", ["resblock", "denseblock", "stay_sixth", "only_semitones", "p2pc_conv", "pc2p_mem"])
 def test_variant_flags_are_refused(flag):
     rc, h = _create({flag: 1})
     assert rc == -5 and b"not built" in _lib.lib().ake_last_error()
+
+
+def test_local_config_is_the_pooling_window():
+    """cfg.local = W > 0 builds the --local net (same tensors as the default net; models.py:720-722 adds parameter-free pooling):
+    frame arithmetic without time pooling, and the clip-level entry point is refused."""
+    lib = _lib.lib()
+    rc, h = _create({"local": 38})
+    assert rc == 0
+    rc0, h0 = _create()
+    assert lib.ake_pcnet_num_tensors(h) == lib.ake_pcnet_num_tensors(h0)
+    tq, tm = C.c_int(), C.c_int()
+    assert lib.ake_pcnet_local_frames(h, 120, C.byref(tq), C.byref(tm)) == 0 and (tq.value, tm.value) == (71, 108)
+    assert lib.ake_pcnet_local_frames(h0, 120, C.byref(tq), C.byref(tm)) == -3          # AKE_ERR_STATE: not a --local net
+    rc, _ = _create({"local": -1})
+    assert rc == -1
+    lib.ake_pcnet_destroy(h); lib.ake_pcnet_destroy(h0)
 
 
 def test_workspace_queries_need_no_gpu():

@@ -224,11 +224,36 @@ def test_persistent_pitch_conv_equals_per_tile_kernel_and_oracle(gold_default, B
         assert rel_err(a.cpu(), b) < TOL
 
 
+def test_local_heads_against_reference_fixture(gold_default, gold_local):
+    """--local (models.py:720-722, 805-810): same state_dict, per-frame key / tonic / genre; the fixture is the
+    reference's own output with opt.local.  A long song (T = 1500, time-tiled kernels) is checked against the oracle."""
+    net, opt = make_net(gold_default, local=True)
+    assert net.local_window == int(gold_local["window"]) == 38
+    x = torch.from_numpy(gold_local["x"]).to(DEV)
+    key, tonic, genre = net(x, torch.tensor([120, 120]))
+    assert key.shape == (2, 71, 12) and tonic.shape == (2, 71, 12) and genre.shape == (2, 108, 11)
+    assert rel_err(key.cpu(), gold_local["key"]) < TOL
+    assert rel_err(tonic.cpu(), gold_local["tonic"]) < TOL
+    assert rel_err(genre.cpu(), gold_local["genre"]) < TOL
+    g = torch.Generator().manual_seed(77)
+    xl = torch.rand((1, 1, 288, 1500), generator=g) * 2.5
+    ref = pcnet_oracle.pcnet_forward(golden_state_dict(gold_default, torch.float64), xl.double(), None, local_window=38)
+    got = net(xl.to(DEV), None)
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and rel_err(a.cpu(), b) < TOL
+    with pytest.raises(ake_amd._lib.AkeError, match="pooling window"):
+        net(torch.zeros(1, 1, 288, 40, device=DEV), None)
+    with pytest.raises(NotImplementedError):
+        net.train()(x, None)
+
+
 def test_edge_shapes(gold_default):
     net, _ = make_net(gold_default)
     sd = golden_state_dict(gold_default, torch.float64)
     g = torch.Generator().manual_seed(1)
-    for B, T in ((1, 26), (1, 27), (2, 33), (1, 151), (1, 300)):        # minimum length, odd lengths, long clips (time tiling)
+    # minimum length, odd lengths, long clips (time tiling; from 500 frames on the heads' 32 -> 1 conv needs more than one time tile:
+    # its patch rows were once wider than the loader's 192 frames, and the last frames of the maps came out wrong)
+    for B, T in ((1, 26), (1, 27), (2, 33), (1, 151), (1, 300), (1, 500), (2, 1000), (1, 1501)):
         x = torch.rand((B, 1, 288, T), generator=g) * 2.5
         ref = pcnet_oracle.pcnet_forward(sd, x.double(), None)
         got = net(x.to(DEV), None)

@@ -62,10 +62,20 @@ def test_forward_fails_loudly_without_a_gpu_tensor():
         net.train()(torch.zeros(1, 1, 288, 76), None)            # the train-mode forward is HIP-only as well
 
 
-@pytest.mark.parametrize("flag", ["resblock", "denseblock", "stay_sixth", "only_semitones", "p2pc_conv", "pc2p_mem", "local"])
+@pytest.mark.parametrize("flag", ["resblock", "denseblock", "stay_sixth", "only_semitones", "p2pc_conv", "pc2p_mem"])
 def test_variant_flags_raise(flag):
     with pytest.raises(NotImplementedError):
         ake_amd.PitchClassNet(288, 12, 2, 7, Namespace(**{flag: True}))
+
+
+def test_local_flag_keeps_the_state_dict_and_sets_the_window():
+    """--local (models.py:720-722): parameter-free pooling after the heads => same state_dict keys; W = frames * loc_window_size - 12."""
+    a = ake_amd.PitchClassNet(288, 12, 2, 7, Namespace(genre=True))
+    b = ake_amd.PitchClassNet(288, 12, 2, 7, Namespace(genre=True, local=True, frames=5, loc_window_size=10, head_layers=2))
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+    assert b.local and b.local_window == 38 and a.local_window == 0
+    with pytest.raises(ValueError):
+        ake_amd.PitchClassNet(288, 12, 2, 7, Namespace(local=True, frames=1, loc_window_size=10))
 
 
 def test_configure_optimizers_contract():

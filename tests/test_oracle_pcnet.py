@@ -84,6 +84,20 @@ def test_circular_roll_on_training_geometry(gold_default):
     assert (g1 - g0).abs().max() > 1e-9
 
 
+def test_local_heads_against_reference_fixture(gold_default, gold_local):
+    """--local (models.py:348, 394, 720-722, 805-810): no time pooling, MaxPool2d((1, 38), stride 1) after the key / tonic heads,
+    per-frame outputs in the reference's reshape order; fixture from the reference run with opt.local on the default weights."""
+    sd = golden_state_dict(gold_default, torch.float64)
+    x = torch.from_numpy(gold_local["x"]).double()
+    W = int(gold_local["window"])
+    assert W == 5 * 10 - 2 * 6
+    k, t, g = pcnet_oracle.pcnet_forward(sd, x, None, local_window=W)
+    assert k.shape == (2, 120 - 12 - W + 1, 12) and g.shape == (2, 108, 11)
+    assert np.abs(k.numpy() - gold_local["key"]).max() <= 1e-12
+    assert np.abs(t.numpy() - gold_local["tonic"]).max() <= 1e-12
+    assert np.abs(g.numpy() - gold_local["genre"]).max() <= 1e-12
+
+
 def test_max_pool_quirk(gold_default):
     """--max_pool with seq_length: only sample 0 takes the max (models.py:764-785)."""
     sd = golden_state_dict(gold_default, torch.float64)
