@@ -126,15 +126,16 @@ class WaveformLoader(DatasetLoader):
         return None if self.genres is None else self.genres[file_id]
 
 
-def cqt_features(waveforms: torch.Tensor, rate: int, opt) -> torch.Tensor:
-    """(B, n) waveforms -> log-CQT (B, 36*octaves, T) float32 on the GPU (KeyDataset.py:485-499)."""
+def cqt_features(waveforms: torch.Tensor, rate: int, opt, lengths=None) -> torch.Tensor:
+    """(B, n) waveforms -> log-CQT (B, 36*octaves, T) float32 on the GPU (KeyDataset.py:485-499); ``lengths``: samples per row of
+    a ragged batch (clip i then has ``1 + lengths[i] // hop`` frames, zeros after them)."""
     frames = getattr(opt, "frames", 5)
     if frames <= 0:
         raise NotImplementedError("opt.frames == 0 (fixed 592-frame windows, KeyDataset.py:490,501-503) is not built")
     if getattr(opt, "only_semitones", False) or getattr(opt, "multi_scale", False):
         raise NotImplementedError("--only_semitones / --multi_scale CQTs are not built (SURVEY.md section 2.1)")
     plan = get_plan(rate, hop_for(rate, frames), 36 * getattr(opt, "octaves", 8), 36)
-    return plan.logmag(waveforms)
+    return plan.logmag(waveforms, lengths=lengths)
 
 
 class KeyDataset:
@@ -149,7 +150,8 @@ class KeyDataset:
         self.seq_length_max = 0
         self.cqt_batch = cqt_batch
         if getattr(opt, "local", False):
-            raise NotImplementedError("--local (sliding-window key tracking) is not built (SURVEY.md section 8f)")
+            raise NotImplementedError("--local datasets (per-frame labels, KeyDataset.py:443-454) are not built; PitchClassNet(opt.local) "
+                                      "inference is (SURVEY.md section 8f)")
 
     def __len__(self):
         return len(self.filenames)
@@ -177,19 +179,30 @@ class KeyDataset:
         print("Length of Data: " + str(len(self.mel)))
 
     def store_content(self):
-        """All clips -> CQT on the GPU, batched by (sample rate, length); labels per clip (KeyDataset.py:121-138)."""
+        """All clips -> CQT on the GPU, batched by sample rate: clips of different lengths share a launch (ragged batch, sorted by
+        length so that a batch pads little); every clip keeps its own frame count; labels per clip (KeyDataset.py:121-138)."""
         groups = defaultdict(list)
         waves = {}
         for idx, (f, dname, _) in enumerate(self.filenames):
             wav, sr = self.datasets[dname].get_waveform(f)
-            waves[idx] = torch.as_tensor(wav, dtype=torch.float32)
-            groups[(sr, len(wav))].append(idx)
-        for (sr, _n), idxs in groups.items():
+            waves[idx] = torch.as_tensor(wav, dtype=torch.float32).reshape(-1)
+            groups[sr].append(idx)
+        for sr, idxs in groups.items():
+            idxs = sorted(idxs, key=lambda i: waves[i].numel())
+            hop = hop_for(sr, getattr(self.opt, "frames", 5))
             for s in range(0, len(idxs), self.cqt_batch):
                 part = idxs[s:s + self.cqt_batch]
-                mel = cqt_features(torch.stack([waves[i] for i in part]), sr, self.opt).double().cpu()   # .double(): KeyDataset.py:509
+                lens = [waves[i].numel() for i in part]
+                if min(lens) == max(lens):
+                    mel = cqt_features(torch.stack([waves[i] for i in part]), sr, self.opt)
+                else:
+                    batch = torch.zeros((len(part), max(lens)), dtype=torch.float32)
+                    for j, i in enumerate(part):
+                        batch[j, :lens[j]] = waves[i]
+                    mel = cqt_features(batch, sr, self.opt, lengths=torch.tensor(lens, dtype=torch.int64))
+                mel = mel.double().cpu()                                               # .double(): KeyDataset.py:509
                 for j, i in enumerate(part):
-                    self.mel[str(i)] = mel[j:j + 1].clone()                            # (1, bins, T)
+                    self.mel[str(i)] = mel[j:j + 1, :, :1 + lens[j] // hop].clone()    # (1, bins, T_i)
                     self.mel2[str(i)] = None
         for idx, (f, dname, _) in enumerate(self.filenames):
             ld = self.datasets[dname]

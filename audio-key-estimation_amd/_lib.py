@@ -37,9 +37,11 @@ SYMBOLS = {
     "ake_cqt_plan_create": (_I, [C.POINTER(CqtConfig), C.POINTER(_P)]),
     "ake_cqt_plan_destroy": (None, [_P]),
     "ake_cqt_plan_n_bins": (_I, [_P]),
+    "ake_cqt_plan_hop": (_I, [_P]),
     "ake_cqt_num_frames": (_I64, [_P, _I64]),
     "ake_cqt_workspace_bytes": (_SZ, [_P, _I, _I64]),
     "ake_cqt_logmag_f32": (_I, [_P, _P, _I, _I64, _I64, _P, _I64, _P, _SZ, _P]),
+    "ake_cqt_logmag_ragged_f32": (_I, [_P, _P, _I, _I64, _I64, _P, _P, _I64, _P, _SZ, _P]),
     "ake_pcnet_default_config": (_I, [C.POINTER(PcnetConfig), _I, _I]),
     "ake_pcnet_create": (_I, [C.POINTER(PcnetConfig), C.POINTER(_P)]),
     "ake_pcnet_destroy": (None, [_P]),
@@ -67,6 +69,7 @@ SYMBOLS = {
     "ake_pcnet_tap_copy": (_I, [_P, C.c_char_p, _I, _I, _P, _P, _P]),
     "ake_pipeline_workspace_bytes": (_SZ, [_P, _P, _I, _I64]),
     "ake_pipeline_forward_f32": (_I, [_P, _P, _P, _I, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
+    "ake_pipeline_forward_ragged_f32": (_I, [_P, _P, _P, _I, _I64, _I64, _P, _P, _P, _P, _P, _SZ, _P]),
     "ake_prof_enable": (_I, [C.c_char_p, _I]),
     "ake_prof_collect": (_I, []),
     "ake_prof_reset": (_I, []),

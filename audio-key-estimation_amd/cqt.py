@@ -58,8 +58,12 @@ class CQTPlan:
             self._ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def logmag(self, audio: torch.Tensor, out_frames: int | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
-        """audio (B, n) or (n,) -> log(1+|CQT|) float32 (B, n_bins, out_frames); frames past the clip are zero."""
+    def logmag(self, audio: torch.Tensor, out_frames: int | None = None, out: torch.Tensor | None = None,
+               lengths: torch.Tensor | None = None) -> torch.Tensor:
+        """audio (B, n) or (n,) -> log(1+|CQT|) float32 (B, n_bins, out_frames); frames past the clip are zero.
+
+        ``lengths`` (B,) int64: ragged batch -- row i holds ``lengths[i] <= n`` samples (the rest of the row is ignored); clip i
+        gets ``1 + lengths[i] // hop`` frames and zeros after them, as ``KeyDataset.__getitem__`` pads (KeyDataset.py:245)."""
         squeeze = audio.dim() == 1
         if squeeze:
             audio = audio[None]
@@ -77,8 +81,14 @@ class CQTPlan:
         ws = self._workspace(nbytes)
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
-            _lib.check(L.ake_cqt_logmag_f32(self._h, audio.data_ptr(), B, n, audio.stride(0), out.data_ptr(), out_frames,
-                                            ws.data_ptr(), ws.numel(), stream), "ake_cqt_logmag_f32")
+            if lengths is None:
+                _lib.check(L.ake_cqt_logmag_f32(self._h, audio.data_ptr(), B, n, audio.stride(0), out.data_ptr(), out_frames,
+                                                ws.data_ptr(), ws.numel(), stream), "ake_cqt_logmag_f32")
+            else:
+                lengths = torch.as_tensor(lengths).to(device=self.device, dtype=torch.int64).contiguous()
+                assert lengths.shape == (B,)
+                _lib.check(L.ake_cqt_logmag_ragged_f32(self._h, audio.data_ptr(), B, n, audio.stride(0), lengths.data_ptr(), out.data_ptr(),
+                                                       out_frames, ws.data_ptr(), ws.numel(), stream), "ake_cqt_logmag_ragged_f32")
         return out[0] if squeeze else out
 
 

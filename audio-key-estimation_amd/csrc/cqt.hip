@@ -216,7 +216,8 @@ constexpr int kLagHost[kCascMax + 1] = {0, 16, 24, 24, 24, 24, 24, 24};
 struct CascArgs {
     const float* x;            // [batch][x_stride] audio
     long long x_stride;
-    int n;                     // samples per clip
+    int n;                     // samples per clip (ragged batches: of the longest clip)
+    const long long* n_clip;   // ragged batches: samples of each clip (<= n), or null; the rest of a row reads as zero
     float* y[kCascMax + 1];    // level l = 1..n_stage: sample m at y[l][clip * y_stride[l] + m + pad]
     long long y_stride[kCascMax + 1];
     int y_count[kCascMax + 1]; // floats stored per clip (sample range [-pad, y_count - pad))
@@ -345,7 +346,9 @@ __global__ __launch_bounds__(NT) void cqt_cascade_kernel(CascArgs a) {
     constexpr int G = C / 4 / NT;                                     // float4 groups of the audio chunk per thread
     // Audio through a buffer resource: hardware range checking returns 0 for every dword outside [0, n) -- the zero padding
     // of the transform's definition -- so the prefetch is branch-free and all G loads are in flight together.
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs), 0, a.n * 4, 0x00020000);
+    int n_here = a.n;
+    if (a.n_clip) { const long long nc = a.n_clip[clip]; n_here = nc < 0 ? 0 : (nc < a.n ? static_cast<int>(nc) : a.n); }
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs), 0, n_here * 4, 0x00020000);
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     f4u pre[G];
     auto fetch = [&](int k) {                                          // audio samples [F0(k-1), F0(k))
@@ -609,9 +612,11 @@ __global__ __launch_bounds__(1024) void cqt_bank_bf16_kernel(
 // [clip][frame][bin] scratch -> [clip][bin][out_frames] (the reference layout), zero-filling frames >= T
 // (KeyDataset.py:245 padding).  32x32 LDS tile transpose: coalesced on both sides.
 __global__ __launch_bounds__(256) void cqt_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int T,
-                                                            int n_bins, int out_frames) {
+                                                            int n_bins, int out_frames, const long long* __restrict__ n_clip, int hop) {
     __shared__ float tile[32][33];
     const int clip = blockIdx.z;
+    int Tc = T;                                                        // ragged batches: frames of THIS clip; the rest is zero padding
+    if (n_clip) { const long long nc = n_clip[clip]; const long long tc = nc < 0 ? 0 : 1 + nc / hop; Tc = tc < T ? static_cast<int>(tc) : T; }
     const int k0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
     const float* s = src + static_cast<long long>(clip) * T * n_bins;
@@ -619,7 +624,7 @@ __global__ __launch_bounds__(256) void cqt_transpose_kernel(const float* __restr
 #pragma unroll
     for (int r = 0; r < 32; r += 8) {
         const int t = t0 + ty + r, k = k0 + tx;
-        tile[ty + r][tx] = (t < T && k < n_bins) ? s[static_cast<long long>(t) * n_bins + k] : 0.f;
+        tile[ty + r][tx] = (t < Tc && k < n_bins) ? s[static_cast<long long>(t) * n_bins + k] : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -906,6 +911,8 @@ void ake_cqt_plan_destroy(ake_cqt_plan* p) {
 
 int ake_cqt_plan_n_bins(const ake_cqt_plan* p) { return p ? p->cfg.n_bins : 0; }
 
+int ake_cqt_plan_hop(const ake_cqt_plan* p) { return p ? p->cfg.hop_length : 0; }
+
 int64_t ake_cqt_num_frames(const ake_cqt_plan* p, int64_t n_samples) {
     if (!p || n_samples < 0) return -1;
     return 1 + n_samples / p->cfg.hop_length;
@@ -923,8 +930,34 @@ size_t ake_cqt_workspace_bytes(const ake_cqt_plan* p, int batch, int64_t n_sampl
     return ake::align_up(c.off, 256);
 }
 
+}  // extern "C"
+
+namespace {
+int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_t n, int64_t audio_stride, const int64_t* n_clip,
+                    float* out, int64_t out_frames, void* workspace, size_t ws_bytes, ake_stream_t stream_);
+}
+
+extern "C" {
+
 int ake_cqt_logmag_f32(const ake_cqt_plan* p, const float* audio, int batch, int64_t n, int64_t audio_stride,
                        float* out, int64_t out_frames, void* workspace, size_t ws_bytes, ake_stream_t stream_) {
+    return cqt_logmag_impl(p, audio, batch, n, audio_stride, nullptr, out, out_frames, workspace, ws_bytes, stream_);
+}
+
+int ake_cqt_logmag_ragged_f32(const ake_cqt_plan* p, const float* audio, int batch, int64_t n_max, int64_t audio_stride,
+                              const int64_t* n_samples_dev, float* out, int64_t out_frames, void* workspace, size_t ws_bytes,
+                              ake_stream_t stream_) {
+    AKE_REQUIRE(n_samples_dev, AKE_ERR_INVALID, "ake_cqt_logmag_ragged_f32: null n_samples_dev");
+    AKE_REQUIRE(p && p->engine == 3, AKE_ERR_UNSUPPORTED, "cqt: ragged batches need engine 3 (the default up to 8 octaves)");
+    return cqt_logmag_impl(p, audio, batch, n_max, audio_stride, n_samples_dev, out, out_frames, workspace, ws_bytes, stream_);
+}
+
+}  // extern "C"
+
+namespace {
+
+int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_t n, int64_t audio_stride, const int64_t* n_clip,
+                    float* out, int64_t out_frames, void* workspace, size_t ws_bytes, ake_stream_t stream_) {
     AKE_REQUIRE(p && audio && out, AKE_ERR_INVALID, "ake_cqt_logmag_f32: null argument");
     AKE_REQUIRE(batch > 0 && n > 0 && audio_stride >= n, AKE_ERR_INVALID, "cqt: bad batch/n_samples/stride");
     AKE_REQUIRE(n < (1ll << 30), AKE_ERR_INVALID, "cqt: clip too long (%lld samples)", static_cast<long long>(n));
@@ -939,6 +972,7 @@ int ake_cqt_logmag_f32(const ake_cqt_plan* p, const float* audio, int batch, int
     auto fill_cascade = [&](CascArgs& a, int fused) {
         std::memset(&a, 0, sizeof(a));
         a.x = audio; a.x_stride = audio_stride; a.n = static_cast<int>(n);
+        a.n_clip = reinterpret_cast<const long long*>(n_clip);
         a.pad = pad_of(p); a.hop = p->cfg.hop_length; a.n_stage = fused; a.taps = p->taps;
         for (int l = 1; l <= fused; ++l) a.y_count[l] = len_store(p, l, n);
         a.g0 = -512;
@@ -1032,10 +1066,10 @@ int ake_cqt_logmag_f32(const ake_cqt_plan* p, const float* audio, int batch, int
         dim3 grid((p->cfg.n_bins + 31) / 32, static_cast<unsigned>((out_frames + 31) / 32), batch);
         ake::ProfScope ps("cqt_transpose_kernel", stream);
         hipLaunchKernelGGL(cqt_transpose_kernel, grid, dim3(256), 0, stream, scratch, out, static_cast<int>(T), p->cfg.n_bins,
-                           static_cast<int>(out_frames));
+                           static_cast<int>(out_frames), reinterpret_cast<const long long*>(n_clip), p->cfg.hop_length);
     }
     AKE_HIP_CHECK(hipGetLastError());
     return AKE_OK;
 }
 
-}  // extern "C"
+}  // namespace

@@ -10,6 +10,15 @@ __global__ void fill_i64_kernel(long long* dst, long long v, int n) {
     if (i < n) dst[i] = v;
 }
 
+__global__ void frames_i64_kernel(long long* dst, const long long* __restrict__ n_clip, int hop, long long t_max, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const long long nc = n_clip[i];
+        const long long t = nc < 0 ? 0 : 1 + nc / hop;                 // librosa center=True framing, as ake_cqt_num_frames
+        dst[i] = t < t_max ? t : t_max;
+    }
+}
+
 struct PipeCarve {
     float* mel;
     long long* seq;
@@ -45,9 +54,30 @@ size_t ake_pipeline_workspace_bytes(const ake_cqt_plan* plan, const ake_pcnet* n
     return pc.total;
 }
 
+static int pipeline_impl(const ake_cqt_plan* plan, const ake_pcnet* net, const float* audio_dev, int batch, int64_t n_samples,
+                         int64_t audio_stride, const int64_t* n_clip_dev, int hop, float* key_out_dev, float* tonic_out_dev,
+                         float* genre_out_dev, void* workspace, size_t workspace_bytes, ake_stream_t stream);
+
 int ake_pipeline_forward_f32(const ake_cqt_plan* plan, const ake_pcnet* net, const float* audio_dev, int batch,
                              int64_t n_samples, int64_t audio_stride, float* key_out_dev, float* tonic_out_dev,
                              float* genre_out_dev, void* workspace, size_t workspace_bytes, ake_stream_t stream) {
+    return pipeline_impl(plan, net, audio_dev, batch, n_samples, audio_stride, nullptr, 0, key_out_dev, tonic_out_dev, genre_out_dev, workspace,
+                         workspace_bytes, stream);
+}
+
+int ake_pipeline_forward_ragged_f32(const ake_cqt_plan* plan, const ake_pcnet* net, const float* audio_dev, int batch,
+                                    int64_t n_max, int64_t audio_stride, const int64_t* n_samples_dev, float* key_out_dev,
+                                    float* tonic_out_dev, float* genre_out_dev, void* workspace, size_t workspace_bytes,
+                                    ake_stream_t stream) {
+    AKE_REQUIRE(n_samples_dev, AKE_ERR_INVALID, "ake_pipeline_forward_ragged_f32: null n_samples_dev");
+    AKE_REQUIRE(plan && n_max > 0, AKE_ERR_INVALID, "ake_pipeline_forward_ragged_f32: bad argument");
+    return pipeline_impl(plan, net, audio_dev, batch, n_max, audio_stride, n_samples_dev, ake_cqt_plan_hop(plan), key_out_dev, tonic_out_dev,
+                         genre_out_dev, workspace, workspace_bytes, stream);
+}
+
+static int pipeline_impl(const ake_cqt_plan* plan, const ake_pcnet* net, const float* audio_dev, int batch, int64_t n_samples,
+                         int64_t audio_stride, const int64_t* n_clip_dev, int hop, float* key_out_dev, float* tonic_out_dev,
+                         float* genre_out_dev, void* workspace, size_t workspace_bytes, ake_stream_t stream) {
     AKE_REQUIRE(plan && net && audio_dev, AKE_ERR_INVALID, "ake_pipeline_forward_f32: null argument");
     const int n_bins = ake_cqt_plan_n_bins(plan);
     AKE_REQUIRE(n_bins == ake_pcnet_pitches(net), AKE_ERR_INVALID, "pipeline: CQT has %d bins but the net expects %d pitches",
@@ -58,9 +88,14 @@ int ake_pipeline_forward_f32(const ake_cqt_plan* plan, const ake_pcnet* net, con
     AKE_REQUIRE(workspace && workspace_bytes >= pc.total, AKE_ERR_WORKSPACE, "pipeline: workspace %zu < %zu bytes", workspace_bytes, pc.total);
     const int64_t T = ake_cqt_num_frames(plan, n_samples);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    rc = ake_cqt_logmag_f32(plan, audio_dev, batch, n_samples, audio_stride, pc.mel, T, pc.cqt_ws, pc.cqt_bytes, stream);
+    rc = n_clip_dev ? ake_cqt_logmag_ragged_f32(plan, audio_dev, batch, n_samples, audio_stride, n_clip_dev, pc.mel, T, pc.cqt_ws, pc.cqt_bytes, stream)
+                    : ake_cqt_logmag_f32(plan, audio_dev, batch, n_samples, audio_stride, pc.mel, T, pc.cqt_ws, pc.cqt_bytes, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(fill_i64_kernel, dim3((batch + 255) / 256), dim3(256), 0, s, pc.seq, static_cast<long long>(T), batch);
+    if (n_clip_dev)   // seq_length of every clip = its own frame count (KeyDataset.py:248: mel.shape[2] before padding)
+        hipLaunchKernelGGL(frames_i64_kernel, dim3((batch + 255) / 256), dim3(256), 0, s, pc.seq, reinterpret_cast<const long long*>(n_clip_dev), hop,
+                           static_cast<long long>(T), batch);
+    else
+        hipLaunchKernelGGL(fill_i64_kernel, dim3((batch + 255) / 256), dim3(256), 0, s, pc.seq, static_cast<long long>(T), batch);
     return ake_pcnet_forward_f32(net, pc.mel, batch, static_cast<int>(T), reinterpret_cast<const int64_t*>(pc.seq), key_out_dev,
                                  tonic_out_dev, genre_out_dev, pc.net_ws, pc.net_bytes, stream);
 }

@@ -22,8 +22,11 @@ class KeyEstimator:
         self._ws = None
 
     @torch.no_grad()
-    def __call__(self, audio: torch.Tensor):
-        """audio (B, n) float32 on the GPU -> tuple of (B,12), (B,12)[, (B,11)] float32 tensors."""
+    def __call__(self, audio: torch.Tensor, lengths: torch.Tensor | None = None):
+        """audio (B, n) float32 on the GPU -> tuple of (B,12), (B,12)[, (B,11)] float32 tensors.
+
+        ``lengths`` (B,) int64: ragged batch, row i holds ``lengths[i] <= n`` samples; every clip is pooled over its own frames
+        (``seq_length`` = ``1 + lengths[i] // hop``), as a ``KeyDataset`` batch of unequal clips is (KeyDataset.py:245-256)."""
         net, L = self.net, _lib.lib()
         net._sync_weights(self.device)
         audio = audio.to(device=self.device, dtype=torch.float32)
@@ -37,8 +40,16 @@ class KeyEstimator:
         tonic = torch.empty((B, 12), dtype=torch.float32, device=self.device)
         genre = torch.empty((B, 11), dtype=torch.float32, device=self.device) if net.genre else None
         with torch.cuda.device(self.device):
-            _lib.check(L.ake_pipeline_forward_f32(self.plan.handle, net.handle, audio.data_ptr(), B, n, audio.stride(0),
-                                                  key.data_ptr(), tonic.data_ptr(), genre.data_ptr() if genre is not None else None,
-                                                  self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream),
-                       "ake_pipeline_forward_f32")
+            if lengths is None:
+                _lib.check(L.ake_pipeline_forward_f32(self.plan.handle, net.handle, audio.data_ptr(), B, n, audio.stride(0),
+                                                      key.data_ptr(), tonic.data_ptr(), genre.data_ptr() if genre is not None else None,
+                                                      self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream),
+                           "ake_pipeline_forward_f32")
+            else:
+                lengths = torch.as_tensor(lengths).to(device=self.device, dtype=torch.int64).contiguous()
+                assert lengths.shape == (B,)
+                _lib.check(L.ake_pipeline_forward_ragged_f32(self.plan.handle, net.handle, audio.data_ptr(), B, n, audio.stride(0), lengths.data_ptr(),
+                                                             key.data_ptr(), tonic.data_ptr(), genre.data_ptr() if genre is not None else None,
+                                                             self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream),
+                           "ake_pipeline_forward_ragged_f32")
         return (key, tonic, genre) if net.genre else (key, tonic)

@@ -68,6 +68,7 @@ int ake_cqt_default_config(ake_cqt_config* cfg, int sample_rate, int frames_per_
 int ake_cqt_plan_create(const ake_cqt_config* cfg, ake_cqt_plan** out);
 void ake_cqt_plan_destroy(ake_cqt_plan* plan);
 int ake_cqt_plan_n_bins(const ake_cqt_plan* plan);
+int ake_cqt_plan_hop(const ake_cqt_plan* plan);
 /* 1 + n_samples / hop  (librosa center=True framing). */
 int64_t ake_cqt_num_frames(const ake_cqt_plan* plan, int64_t n_samples);
 size_t ake_cqt_workspace_bytes(const ake_cqt_plan* plan, int batch, int64_t n_samples);
@@ -79,6 +80,14 @@ size_t ake_cqt_workspace_bytes(const ake_cqt_plan* plan, int batch, int64_t n_sa
 int ake_cqt_logmag_f32(const ake_cqt_plan* plan, const float* audio_dev, int batch, int64_t n_samples,
                        int64_t audio_stride, float* out_dev, int64_t out_frames, void* workspace,
                        size_t workspace_bytes, ake_stream_t stream);
+
+/* Ragged batch (clips of different lengths in one call).  Row i holds n_samples_dev[i] <= n_max samples
+ * (device array, int64); whatever follows them in the row is never read (hardware range checking returns 0, the transform's
+ * zero padding).  Clip i gets 1 + n_samples[i] / hop frames; frames beyond them are written as 0, as KeyDataset.__getitem__
+ * pads to the longest clip (KeyDataset.py:245).  Workspace as for (batch, n_max).  Engine 3 (the default up to 8 octaves). */
+int ake_cqt_logmag_ragged_f32(const ake_cqt_plan* plan, const float* audio_dev, int batch, int64_t n_max,
+                              int64_t audio_stride, const int64_t* n_samples_dev, float* out_dev, int64_t out_frames,
+                              void* workspace, size_t workspace_bytes, ake_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * PitchClassNet forward (inference: eval-mode BatchNorm folded into the convolutions).
@@ -209,6 +218,12 @@ size_t ake_pipeline_workspace_bytes(const ake_cqt_plan* plan, const ake_pcnet* n
 int ake_pipeline_forward_f32(const ake_cqt_plan* plan, const ake_pcnet* net, const float* audio_dev, int batch,
                              int64_t n_samples, int64_t audio_stride, float* key_out_dev, float* tonic_out_dev,
                              float* genre_out_dev, void* workspace, size_t workspace_bytes, ake_stream_t stream);
+/* The same for a ragged batch (ake_cqt_logmag_ragged_f32): seq_length of clip i = 1 + n_samples[i] / hop, computed on the
+ * device; workspace as ake_pipeline_workspace_bytes(plan, net, batch, n_max). */
+int ake_pipeline_forward_ragged_f32(const ake_cqt_plan* plan, const ake_pcnet* net, const float* audio_dev, int batch,
+                                    int64_t n_max, int64_t audio_stride, const int64_t* n_samples_dev, float* key_out_dev,
+                                    float* tonic_out_dev, float* genre_out_dev, void* workspace, size_t workspace_bytes,
+                                    ake_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-kernel timing with hipEvents recorded on the launch stream (bench.py roofline leg).

@@ -53,6 +53,33 @@ def test_ragged_lengths_and_padding(plan, n):
     assert rel_err(got[:, :T], O.cqt_logmag(y, SR, HOP)) < TOL
 
 
+def test_ragged_batch_equals_per_clip_transform(plan):
+    """clips of different lengths in ONE call (ake_cqt_logmag_ragged_f32).  Whatever follows a clip in its row is
+    never read (NaN there would poison the result); every clip equals its own single-clip transform and the direct-form oracle;
+    frames past a clip's own length are zero (KeyDataset.py:245)."""
+    lens = [70001, 70000, 4410 * 3 + 7, 50000, 4409, 30000]
+    n_max = max(lens)
+    rows = np.full((len(lens), n_max + 5), np.nan, np.float32)
+    clips = []
+    for i, n in enumerate(lens):
+        y, _ = synthetic.make_clip(10 + i, n)
+        clips.append(y)
+        rows[i, :n] = y
+    audio = torch.from_numpy(rows).to(DEV)[:, :n_max]                         # row stride n_max + 5
+    T_max = O.n_frames(n_max, HOP)
+    got = plan.logmag(audio, out_frames=T_max + 2, lengths=torch.tensor(lens)).cpu().numpy()
+    assert got.shape == (len(lens), 288, T_max + 2) and np.isfinite(got).all()
+    for i, n in enumerate(lens):
+        T = O.n_frames(n, HOP)
+        assert np.all(got[i, :, T:] == 0), i
+        alone = plan.logmag(torch.from_numpy(clips[i]).to(DEV)).cpu().numpy()
+        assert rel_err(got[i, :, :T], alone) < 1e-5, i
+        assert rel_err(got[i, :, :T], O.cqt_logmag(clips[i], SR, HOP)) < TOL, i
+    p1 = ake_amd.CQTPlan(SR, HOP, 288, 36, device=DEV, engine=1)             # the cross-check engines take equal-length batches only
+    with pytest.raises(ake_amd._lib.AkeError, match="engine 3"):
+        p1.logmag(audio, lengths=torch.tensor(lens))
+
+
 def test_other_rates_and_hops():
     for sr, frames, octaves in ((44100, 5, 8), (22050, 10, 8), (22050, 5, 7)):
         hop = ake_amd.hop_for(sr, frames)

@@ -46,6 +46,30 @@ def test_pipeline_equals_cqt_then_forward_and_oracle(net, gold_default):
         assert rel_err(a.cpu(), b) < 1e-3
 
 
+def test_ragged_pipeline_equals_per_clip_pipeline(net):
+    """ake_pipeline_forward_ragged_f32: every clip of a ragged batch is transformed on its own samples and pooled over its own frames
+    (seq_length = 1 + n_i // hop, on the device): the same answer as the KeyDataset route -- per-clip CQT, zero padding to the longest
+    clip, forward with seq_length (KeyDataset.py:242-256).  (Not the same as the clip in a batch of its own: the padded frames take
+    part in the time-circular pitch convolutions, in the reference as here.)"""
+    lens = [synthetic.N_SAMPLES, 22050 * 9 + 123, 22050 * 12, 22050 * 7]
+    est = ake_amd.KeyEstimator(net, 22050, 5)
+    rows = torch.zeros((len(lens), max(lens)))
+    clips = []
+    for i, n in enumerate(lens):
+        y, _ = synthetic.make_clip(40 + i, n)
+        clips.append(torch.from_numpy(y))
+        rows[i, :n] = clips[-1]
+        rows[i, n:] = 7.0                                                     # never read
+    key, tonic, genre = est(rows.to(DEV), lengths=torch.tensor(lens))
+    T = [1 + n // 4410 for n in lens]
+    mel = torch.zeros((len(lens), 1, 288, max(T)), device=DEV)
+    for i, y in enumerate(clips):
+        mel[i, 0, :, :T[i]] = est.plan.logmag(y.to(DEV))
+    k1, t1, g1 = net(mel, torch.tensor(T, device=DEV))
+    assert (key - k1).abs().max() < 1e-5 and rel_err(tonic.cpu(), t1.cpu()) < 2e-5 and rel_err(genre.cpu(), g1.cpu()) < 2e-5
+    assert (t1[1] - t1[0]).abs().max() > 0 and not torch.equal(mel[1], mel[0])  # the clips do differ
+
+
 def test_keydataset_item_contract_and_validate(net):
     opt = default_opt()
     ds = ake_amd.KeyDataset(True, opt)
