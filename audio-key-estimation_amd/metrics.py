@@ -22,6 +22,18 @@ def _build_table() -> torch.Tensor:
 KEY_SIGNATURE_MAP = _build_table()      # (21, 12)
 
 
+_tables = {}
+
+
+def _device_table(dev, dtype):
+    """The table on `dev`, uploaded once (the reference re-uploads it per sample, models.py:1077; a host-to-device copy per call
+    also stalls the launch queue and cannot be captured into a graph)."""
+    key = (str(dev), dtype)
+    if key not in _tables:
+        _tables[key] = KEY_SIGNATURE_MAP.to(device=dev, dtype=dtype)
+    return _tables[key]
+
+
 def mirex_score(key_labels, key_preds, tonic_labels, tonic_preds, key_signature_id):
     """-> (mirex, correct, fifths, relative, parallel, other, accuracy), float32 scalars.
 
@@ -30,7 +42,7 @@ def mirex_score(key_labels, key_preds, tonic_labels, tonic_preds, key_signature_
     24-way label index, and the if-chain gives 'fifths' precedence.
     """
     dev = key_preds.device
-    table = KEY_SIGNATURE_MAP.to(device=dev, dtype=key_preds.dtype)
+    table = _device_table(dev, key_preds.dtype)
     eps = 1e-8
     pn = key_preds.norm(dim=1, keepdim=True).clamp_min(eps)
     tn = table.norm(dim=1, keepdim=True).clamp_min(eps)
