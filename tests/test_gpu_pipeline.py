@@ -8,7 +8,7 @@ import torch
 import ake_amd
 from ake_amd import synthetic
 from ake_amd.lightning_shim import Trainer
-from conftest import golden_state_dict, rel_err
+from conftest import REPO, golden_state_dict, rel_err
 from oracle import cqt_oracle, mirex_oracle, pcnet_oracle
 
 pytestmark = pytest.mark.gpu
@@ -68,6 +68,19 @@ def test_ragged_pipeline_equals_per_clip_pipeline(net):
     k1, t1, g1 = net(mel, torch.tensor(T, device=DEV))
     assert (key - k1).abs().max() < 1e-5 and rel_err(tonic.cpu(), t1.cpu()) < 2e-5 and rel_err(genre.cpu(), g1.cpu()) < 2e-5
     assert (t1[1] - t1[0]).abs().max() > 0 and not torch.equal(mel[1], mel[0])  # the clips do differ
+
+
+def test_config5_sharded_equivariance_two_ranks():
+    """BASELINE configs[4] / SURVEY 8d config 5: the 25 shifted guard-octave inputs dealt to two ranks (both on this GPU, gloo for
+    the gather), roll identity <= 1e-5 and equality with the reference's table asserted by the tool itself."""
+    import json, os, subprocess, sys
+    env = dict(os.environ, AKE_REHEARSE_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(REPO, "tools", "config5_equivariance.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["pass"] and line["n_gpus"] == 2 and line["inputs"] == 25 and line["max_roll_identity_error"] <= 1e-5
 
 
 def test_keydataset_item_contract_and_validate(net):
