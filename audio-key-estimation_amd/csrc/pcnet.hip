@@ -51,6 +51,7 @@ struct PackedConv {          // device-resident folded + packed convolution
     int tb = 0, ku = 0, ntiles = 0, nt = 1;
     size_t f_off = 0;
     long long bf_off = -1;         // 16-byte offset of the bf16x3 fragments in ake_pcnet::bf_frags_dev (8 -> 8 channel 7x7 pitch convs), or -1
+    long long l0_off = -1;         // ... of the layer-0 form (layer0_mfma_kernel: <= 4 channels, 12 x 7), or -1
 };
 
 struct LayerDims {
@@ -1087,6 +1088,13 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
         pc->bf_off = -1;
         if ((pc->kh == 12 || pc->kh == 2) && pc->kw == 7 && pc->cout == 1 && pc->co == 1 && pc->cin == 32) { pc->bf_off = static_cast<long long>(count); count += static_cast<size_t>(pc->kh) * 22 * 2 * 64; }
     }
+    if (!n->pc2pc.empty())                                   // layer 0's pitch-class stack (<= 4 channels): layer0_mfma_kernel
+        for (PackedConv& pc : n->pc2pc[0]) {
+            pc.l0_off = -1;
+            if (n->cfg.num_layers > 1 && pc.kh == 12 && pc.kw == 7 && pc.co == 4 && pc.groups == 1 && pc.cout <= 4 && pc.cin <= 4) {
+                pc.l0_off = static_cast<long long>(count); count += 24 * 64;
+            }
+        }
     for (size_t i = 1; i < n->semi.size(); ++i) {            // semitone convs that follow an 8-channel pitch stack: fused into its last conv
         PackedConv& pc = n->semi[i];
         pc.bf_off = -1;
@@ -1111,6 +1119,10 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
             hipLaunchKernelGGL(pack_pc_bf16_kernel, dim3((pc->kh * 4 * NT * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
                                n->bf_frags_dev + pc->bf_off, pc->cin, pc->cout, pc->co, NT, pc->kh);
         }
+    if (!n->pc2pc.empty())
+        for (const PackedConv& pc : n->pc2pc[0])
+            if (pc.l0_off >= 0)
+                hipLaunchKernelGGL(pack_l0_bf16_kernel, dim3(3), dim3(256), 0, s, n->blob_dev + pc.w_off, n->bf_frags_dev + pc.l0_off, pc.cin, pc.cout);
     for (size_t i = 1; i < n->semi.size(); ++i)
         if (n->semi[i].bf_off >= 0)
             hipLaunchKernelGGL(pack_semi_bf16_kernel, dim3(1), dim3(192), 0, s, n->blob_dev + n->semi[i].w_off, n->bf_frags_dev + n->semi[i].bf_off);
@@ -1361,11 +1373,22 @@ struct Fwd {
         a.H = P; a.T = T0; a.NF = NF; a.n_conv = c.conv_layers;
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(layer0_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return false;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(layer0_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(layer0_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+                return false;
             attr_set = true;
         }
+        // the convolution stack on bf16 MFMA when the fragments exist and the maps fit (AKE_PC_F32=1: the exact-f32 VALU form)
+        bool mfma = !g_pc_f32_only;
+        for (int j = 0; j < c.conv_layers; ++j) {
+            mfma = mfma && n->pc2pc[0][j].l0_off >= 0;
+            if (mfma) a.frag[j] = n->bf_frags_dev + n->pc2pc[0][j].l0_off;
+        }
+        a.RPp = (T0 + 8 + 1) / 2 * 2;
+        const size_t lds_m = (static_cast<size_t>(4) * 12 * a.RP + static_cast<size_t>(2) * 12 * a.RPp * 4 + static_cast<size_t>(P) * T0) * sizeof(float);
         ake::ProfScope ps("layer0_fused_kernel", s);
-        hipLaunchKernelGGL(layer0_fused_kernel, dim3(B), dim3(512), lds, s, a);
+        if (mfma && lds_m <= 150 * 1024) hipLaunchKernelGGL(layer0_mfma_kernel, dim3(B), dim3(512), lds_m, s, a);
+        else hipLaunchKernelGGL(layer0_fused_kernel, dim3(B), dim3(512), lds, s, a);
         return true;
     }
 

@@ -1466,6 +1466,8 @@ struct Layer0Args {
     float* fold0;                // [clip][1][12][T]
     float* psix;                 // [clip][NF][36][T]
     int H, T, RP, NF, n_conv;    // RP: LDS row pitch in floats (T + 6 rounded up to 4)
+    const uint4* frag[4];        // layer0_mfma_kernel: B fragments of the convs [12 dy][hi|lo][64 lanes] x 8 bf16 (pack_l0_bf16_kernel)
+    int RPp;                     // layer0_mfma_kernel: row pitch of the channels-last maps, in positions (even, >= T + 8)
 };
 
 __global__ __launch_bounds__(512) void layer0_fused_kernel(Layer0Args a) {
@@ -1624,6 +1626,160 @@ __global__ void local_pool_kernel(LocalPoolArgs a) {
         if (which == 0) v = 1.f / (1.f + expf(-v));
     }
     a.outs[which][i] = v;
+}
+
+// ---- the same launch with the convolution stack on bf16 MFMA (split operands) ------------------------------------------------
+// The VALU form above spends 2.9 M FMAs per clip at the vector rate (0.07 ms per 256 clips, the kernel is VALU-bound).  Here the
+// maps live in LDS as channels-last split planes [12 rows][T + 8 positions][4 ch] (8 bytes per position and plane, 3 zero positions
+// either side = the convs' zero padding), and a conv is the MFMA form of conv_p2p_bf16_kernel with 4 channels:
+//   m = (pitch class p, frame pair j)     A[m][k = (position q', ci)] = X[(p + dy) mod 12][2j + q'][ci]    (8 positions x 4 channels = 32)
+//   n = (tau, co) = 4 * tau + co < 8      B[k][n] = w[co][ci][dy][q' - tau]                                  (columns 8..15 idle)
+//   k-step = dy: 12 steps x 3 MFMAs per 16 x 16 tile, ~29 tiles per clip.
+// One A fragment = one aligned 16-byte LDS read (2 positions x 4 channels); the 24 weight fragments of a layer sit in registers.
+__global__ void pack_l0_bf16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin, int cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (dy, lane)
+    if (i >= 12 * 64) return;
+    const int dy = i / 64, lane = i - dy * 64;
+    const int n = lane & 15, qq = lane >> 4;
+    const int tau = n >> 2, co = n & 3;
+    unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+    for (int e = 0; e < 8; ++e) {
+        const int pos = 2 * qq + (e >> 2), ci = e & 3;
+        const int dx = pos - tau;
+        float v = 0.f;
+        if (n < 8 && dx >= 0 && dx < 7 && ci < cin && co < cout) v = w[((ci * 12 + dy) * 7 + dx) * 4 + co];
+        const unsigned int hb = bf16_bits(v);
+        const unsigned int lb = bf16_bits(v - __uint_as_float(hb << 16));
+        hi[e >> 1] |= hb << (16 * (e & 1));
+        lo[e >> 1] |= lb << (16 * (e & 1));
+    }
+    out[(2 * dy + 0) * 64 + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    out[(2 * dy + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+__global__ __launch_bounds__(512) void layer0_mfma_kernel(Layer0Args a) {
+    extern __shared__ __attribute__((aligned(16))) float l0[];
+    const int clip = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int T = a.T, RP = a.RP, RPp = a.RPp, NF = a.NF;
+    // LDS: f32 map of the latest conv output [4][12][RP] (for up_sixth) | two channels-last maps, each hi plane + lo plane of
+    // [12][RPp] positions x 4 bf16 | the clip's CQT [H][T] (semitone phase only)
+    float* const fmap = l0;
+    unsigned short* const mapA = reinterpret_cast<unsigned short*>(l0 + 4 * 12 * RP);
+    const int plane = 12 * RPp * 4;                                   // bf16 elements per plane
+    unsigned short* const mapB = mapA + 2 * plane;
+    float* const ml = reinterpret_cast<float*>(mapB + 2 * plane);
+    for (int i = tid; i < 4 * 12 * RP + 2 * plane; i += 512) l0[i] = 0.f;   // (the two maps = 4 planes of bf16 = 2 * plane floats)
+    // ---- semitone conv + BN + LeakyReLU + octave fold -> channel 0 of map A ----
+    {
+        const float4* mel4 = reinterpret_cast<const float4*>(a.mel + static_cast<long long>(clip) * a.H * T);
+        const int n4 = a.H * T / 4;
+        for (int i = tid; i < n4; i += 512) reinterpret_cast<float4*>(ml)[i] = mel4[i];
+        __syncthreads();
+        float w9[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) w9[i] = a.sw[i];
+        const float sb = a.sb[0];
+        const int n_oct = a.H / 36;
+        for (int i = tid; i < 12 * T; i += 512) {
+            const int p = i / T, t = i - p * T;
+            const int tm = t == 0 ? T - 1 : t - 1, tp = t == T - 1 ? 0 : t + 1;
+            float best = -INFINITY;
+            for (int o = 0; o < n_oct; ++o) {
+                const float* r = ml + 3 * (p + 12 * o) * T;
+                float acc = 0.f;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    acc = fmaf(r[dy * T + tm], w9[dy * 3 + 0], acc);
+                    acc = fmaf(r[dy * T + t], w9[dy * 3 + 1], acc);
+                    acc = fmaf(r[dy * T + tp], w9[dy * 3 + 2], acc);
+                }
+                float v = acc + sb;
+                v = v > 0.f ? v : v * kSlope;
+                best = fmaxf(best, v);
+            }
+            const unsigned int hb = bf16_bits(best);
+            mapA[(p * RPp + 3 + t) * 4] = static_cast<unsigned short>(hb);
+            mapA[plane + (p * RPp + 3 + t) * 4] = static_cast<unsigned short>(bf16_bits(best - __uint_as_float(hb << 16)));
+            a.fold0[(static_cast<long long>(clip) * 12 + p) * T + t] = best;
+        }
+    }
+    __syncthreads();
+    // ---- the convolution stack on MFMA ----
+    typedef float f32x4c __attribute__((ext_vector_type(4)));
+    const int J = (T + 1) / 2, M = 12 * J, n_tiles = (M + 15) / 16;
+    const int tau = (r16 >> 2) & 1, co = r16 & 3;
+    const unsigned short* in = mapA;
+    unsigned short* out = mapB;
+    for (int j = 0; j < a.n_conv; ++j) {
+        uint4 breg[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) breg[i] = a.frag[j][i * 64 + lane];
+        const float bias = (r16 < 8 && co < NF) ? a.b[j][co] : 0.f;
+        float* const g = a.dst[j] + clip * a.dst_clip_stride[j];
+        for (int tile = wave; tile < n_tiles; tile += 8) {
+            int m = tile * 16 + r16;
+            m = m < M ? m : M - 1;
+            const int p = m / J, jj = m - p * J;
+            f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 12; ++dy) {
+                int row = p + dy;
+                row -= row >= 12 ? 12 : 0;
+                const int pos = row * RPp + 2 * jj + 2 * q;              // padded position of frame 2j - 3 + 2q
+                const bf16x8c ah = __builtin_bit_cast(bf16x8c, *reinterpret_cast<const uint4*>(in + pos * 4));
+                const bf16x8c al = __builtin_bit_cast(bf16x8c, *reinterpret_cast<const uint4*>(in + plane + pos * 4));
+                const bf16x8c bh = __builtin_bit_cast(bf16x8c, breg[2 * dy]), bl = __builtin_bit_cast(bf16x8c, breg[2 * dy + 1]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+            }
+            if (r16 < 8 && co < NF) {                                    // D[m = 4q + i][n = (tau, co)]
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int mm = tile * 16 + 4 * q + i;
+                    const int pp = mm / J, t = 2 * (mm - pp * J) + tau;
+                    if (mm < M && t < T) {
+                        float v = acc[i] + bias;
+                        v = v > 0.f ? v : v * kSlope;
+                        const unsigned int hb = bf16_bits(v);
+                        out[(pp * RPp + 3 + t) * 4 + co] = static_cast<unsigned short>(hb);
+                        out[plane + (pp * RPp + 3 + t) * 4 + co] = static_cast<unsigned short>(bf16_bits(v - __uint_as_float(hb << 16)));
+                        fmap[(co * 12 + pp) * RP + 3 + t] = v;
+                        g[(static_cast<long long>(co) * 12 + pp) * T + t] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned short* tmp = in;
+        in = out;
+        out = const_cast<unsigned short*>(tmp);
+    }
+    // ---- layer 1's up_sixth + BN + LeakyReLU from the f32 map of the last conv ----
+    if (a.psix) {
+        typedef const float __attribute__((address_space(4))) cfloat;
+        cfloat* uw = (cfloat*)a.uw;
+        cfloat* ub = (cfloat*)a.ub;
+        float* ps = a.psix + static_cast<long long>(clip) * NF * 36 * T;
+        for (int i = tid; i < 12 * T; i += 512) {
+            const int p = i / T, t = i - p * T;
+            float x[4];
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) x[ci] = fmap[(ci * 12 + p) * RP + 3 + t];
+            for (int co2 = 0; co2 < NF; ++co2) {
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    float acc = ub[co2];
+#pragma unroll
+                    for (int ci = 0; ci < 4; ++ci)
+                        if (ci < NF) acc = fmaf(x[ci], uw[(ci * NF + co2) * 3 + jj], acc);
+                    ps[(static_cast<long long>(co2) * 36 + 3 * p + jj) * T + t] = acc > 0.f ? acc : acc * kSlope;
+                }
+            }
+        }
+    }
 }
 
 // ==========================================================================================
