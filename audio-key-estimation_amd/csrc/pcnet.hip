@@ -1599,7 +1599,8 @@ struct Fwd {
                 ha.KH[h] = c1[h]->kh; ha.circular[h] = c1[h]->kh == 12 ? 1 : 0; ha.H_out[h] = ha.circular[h] ? 12 : 12 - c1[h]->kh + 1;
             }
             ha.T_in = T1; ha.T_out = T2; ha.JB = (T2 + 15) / 16; ha.Tp = 16 * (ha.JB - 1) + 22;
-            const size_t lds = static_cast<size_t>(2) * 12 * ha.Tp * 4 * sizeof(uint4) + static_cast<size_t>(8) * kHead1MT * 4 * 64 * sizeof(float);
+            // the patch, and after the multiply loop the partial tiles of the 8 waves in the same bytes (two workgroups per CU fit)
+            const size_t lds = std::max(static_cast<size_t>(2) * 12 * ha.Tp * 4 * sizeof(uint4), static_cast<size_t>(8) * kHead1MT * 4 * 64 * sizeof(float));
             static bool h1_attr = false;
             if (!h1_attr) {
                 AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head1_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));

@@ -1225,7 +1225,7 @@ __global__ __launch_bounds__(512) void conv_head1_bf16_kernel(Head1BfArgs a) {
     const int Tp = a.Tp;
     uint4* const pH = lds4;                                  // [12][Tp][4 groups of 8 channels]
     uint4* const pL = lds4 + 12 * Tp * 4;
-    float* const red = reinterpret_cast<float*>(lds4 + 2 * 12 * Tp * 4);      // [8 waves][kHead1MT][4][64]
+    float* const red = reinterpret_cast<float*>(lds4);       // [8 waves][kHead1MT][4][64]: reuses the patch's bytes after the multiply loop
     {
         const long long cbase = static_cast<long long>(clip) * 12 * a.T_in * 4;
         const uint4* gh = reinterpret_cast<const uint4*>(a.xh[head]) + cbase;
@@ -1260,10 +1260,24 @@ __global__ __launch_bounds__(512) void conv_head1_bf16_kernel(Head1BfArgs a) {
 #pragma unroll
     for (int mt = 0; mt < kHead1MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
     const uint4* __restrict__ bg = a.bfrag[head] + lane;
+    // weight fragments three k-steps ahead (they come from L2: fetched at their use, every k-step paid a full round trip)
+    constexpr int PF = 3;
+    uint4 nbh[PF], nbl[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        const int kn = wave + 8 * i < nks ? wave + 8 * i : wave;
+        nbh[i] = bg[(2 * kn + 0) * 64]; nbl[i] = bg[(2 * kn + 1) * 64];
+    }
     for (int ks = wave; ks < nks; ks += 8) {
         const int dy = ks / 22, dxe = ks - dy * 22;
-        const bf16x8c bh = __builtin_bit_cast(bf16x8c, bg[(2 * ks + 0) * 64]);
-        const bf16x8c bl = __builtin_bit_cast(bf16x8c, bg[(2 * ks + 1) * 64]);
+        const bf16x8c bh = __builtin_bit_cast(bf16x8c, nbh[0]);
+        const bf16x8c bl = __builtin_bit_cast(bf16x8c, nbl[0]);
+#pragma unroll
+        for (int i = 0; i + 1 < PF; ++i) { nbh[i] = nbh[i + 1]; nbl[i] = nbl[i + 1]; }
+        {
+            const int kn = ks + 8 * PF < nks ? ks + 8 * PF : ks;
+            nbh[PF - 1] = bg[(2 * kn + 0) * 64]; nbl[PF - 1] = bg[(2 * kn + 1) * 64];
+        }
 #pragma unroll
         for (int mt = 0; mt < kHead1MT; ++mt) {
             if (mt < mtiles) {
@@ -1278,6 +1292,7 @@ __global__ __launch_bounds__(512) void conv_head1_bf16_kernel(Head1BfArgs a) {
             }
         }
     }
+    __syncthreads();                                         // every wave is done with the patch
 #pragma unroll
     for (int mt = 0; mt < kHead1MT; ++mt)
 #pragma unroll
