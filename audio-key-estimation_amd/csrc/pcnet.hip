@@ -531,6 +531,38 @@ int run_nchw_to_cl16(const float* src, int C, int batch, int T, unsigned short* 
     return AKE_OK;
 }
 
+// does inference run the last layer's pitch-class stack + its time pooling as ONE launch (pc2pc_fused_kernel)?  The stack's
+// intermediate activations then never leave LDS (ake_debug_keep_taps(1) keeps the per-conv launches for bisecting).
+bool pc2pc_fuses(const ake_pcnet* n, int i, int T) {
+    static const bool off = std::getenv("AKE_PC_FUSED") != nullptr && std::atoi(std::getenv("AKE_PC_FUSED")) == 0;
+    const auto& c = n->cfg;
+    if (off || g_keep_taps || i < 1 || i != c.num_layers - 1 || c.time_pool_size != 2 || c.conv_layers < 1 || c.conv_layers > 4) return false;
+    if (!pc2pc_uses_bf16(n, i, T) || T % 4 || 12 * T > 1024) return false;
+    for (const PackedConv& pc : n->pc2pc[i])
+        if (pc.cout != 16 || pc.cin > 16 || pc.kh != 12) return false;
+    return static_cast<size_t>(4) * 12 * (T + 8) * 2 * sizeof(uint4) <= 150 * 1024;
+}
+
+int run_pc2pc_fused(const ake_pcnet* n, int i, const float* src, int cin, int batch, int T, float* pooled, unsigned short* feat_cl, hipStream_t s) {
+    Pc2pcFusedArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.src = src; a.src_clip_stride = static_cast<long long>(cin) * 12 * T; a.cin = cin;
+    a.n_conv = static_cast<int>(n->pc2pc[i].size());
+    for (int j = 0; j < a.n_conv; ++j) { a.bfrag[j] = n->bf_frags_dev + n->pc2pc[i][j].bf_off; a.bias[j] = n->blob_dev + n->pc2pc[i][j].b_off; }
+    a.pooled = pooled;
+    if (feat_cl) { a.fh = feat_cl; a.fl = feat_cl + static_cast<long long>(batch) * 12 * (T / 2) * 16; }
+    a.T = T; a.Tp = T + 8;
+    const size_t lds = static_cast<size_t>(4) * 12 * a.Tp * 2 * sizeof(uint4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc2pc_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    ake::ProfScope ps("pc2pc_fused_kernel", s);
+    hipLaunchKernelGGL(pc2pc_fused_kernel, dim3(batch), dim3(1024), lds, s, a);
+    return AKE_OK;
+}
+
 // pitch-class convolution on bf16 MFMA (conv_pc_bf16_kernel): channels-last planes in; planes (cout == 16) or NCHW f32 out
 int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* planes_in, int batch, int T_in, bool same_time, bool lrelu,
                 float* dst_nchw, unsigned short* planes_out, hipStream_t s, const char* name) {
@@ -1538,8 +1570,14 @@ struct Fwd {
         // the intermediate activations stay in that format (same 64 B per position as 16 f32 channels: the ping-pong buffers are
         // reused), the last convolution writes NCHW f32 for the pooling / heads
         const bool pc_bf = !train && pc2pc_uses_bf16(n, i, Ti);
-        if (pc_bf) run_nchw_to_cl16(psrc, cin, B, Ti, reinterpret_cast<unsigned short*>(b.pcb[i]), s);
-        for (int j = 0; j < c.conv_layers; ++j) {
+        // heads on the bf16 kernels read a channels-last copy of the pooled features (decided here: the fused stack writes it itself)
+        const bool head_bf = !train && !g_pc_f32_only && L > 1 && n->final_ch == 16 && c.head_layers >= 2 && n->head_key[0].bf_off >= 0 &&
+                             n->head_tonic[0].bf_off >= 0 && b.Tf <= kPcBf16MaxFrames;
+        const bool pc_fused = !train && L > 1 && pc2pc_fuses(n, i, Ti);
+        if (pc_fused) {
+            if ((rc = run_pc2pc_fused(n, i, psrc, cin, B, Ti, b.pcf, head_bf ? b.feat_cl : nullptr, s))) return rc;
+        } else if (pc_bf) run_nchw_to_cl16(psrc, cin, B, Ti, reinterpret_cast<unsigned short*>(b.pcb[i]), s);
+        for (int j = 0; j < c.conv_layers && !pc_fused; ++j) {
             pdst = train ? b.pcst[i][j] : ((j & 1) ? b.pcb[i] : b.pca[i]);
             pdst_aff = !train ? nullptr : b.aff_pcst[i][j];
             if (pc_bf) {
@@ -1558,7 +1596,8 @@ struct Fwd {
         }
         const float* feat = pdst;                 // features feeding the heads
         const float* feat_aff = pdst_aff;
-        if (L > 1) {   // models.py:396  (the pitch stream of the last layer feeds nothing: its pool is skipped)
+        if (pc_fused) { feat = b.pcf; feat_aff = nullptr; }
+        else if (L > 1) {   // models.py:396  (the pitch stream of the last layer feeds nothing: its pool is skipped)
             time_pool(pdst, pdst_aff, B, cout, 12, Ti, b.pcf, cout, 0);
             feat = b.pcf; feat_aff = nullptr;
         }
@@ -1571,10 +1610,8 @@ struct Fwd {
         int Tm = Tf;
         // key / tonic heads: the first convolution (16 -> 32 channels, most of a head's work) on the bf16 kernel; both read the same
         // channels-last copy of the features
-        const bool head_bf = !train && !g_pc_f32_only && L > 1 && n->final_ch == 16 && c.head_layers >= 2 && n->head_key[0].bf_off >= 0 &&
-                             n->head_tonic[0].bf_off >= 0 && Tf <= kPcBf16MaxFrames;
         unsigned short* feat_cl = b.feat_cl;
-        if (head_bf) run_nchw_to_cl16(feat, n->final_ch, B, Tf, feat_cl, s);
+        if (head_bf && !pc_fused) run_nchw_to_cl16(feat, n->final_ch, B, Tf, feat_cl, s);
         // two-conv heads: conv0 leaves its 32 channels as channels-last planes and ONE launch of conv_head1_bf16_kernel finishes
         // both the key and the tonic map
         const int T1 = Tf - (c.kernel_size - 1), T2 = T1 - (c.kernel_size - 1);
@@ -1800,6 +1837,10 @@ static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frame
                 const bool to_cat = i == 0 && L > 1;             // layer 0's last conv writes into cat[1]
                 if (to_cat && j == last_j) break;                // strided inside the concat buffer: use "model.1.cat"
                 if (j < last_j - (to_cat ? 2 : 1)) break;
+                if (i == L - 1 && pc2pc_fuses(n, i, Ti)) {
+                    ake::set_error("tap: '%s' stays in LDS (the stack runs as one launch); ake_debug_keep_taps(1) before the forward keeps it", name);
+                    return AKE_ERR_INVALID;
+                }
                 if (j < last_j && i == L - 1 && pc2pc_uses_bf16(n, i, Ti) && channels_last) *channels_last = 1;
                 return set((j & 1) ? b.pcb[i] : b.pca[i], i == 0 ? c.n_filters : d.out_pc, 12, Ti);
             }

@@ -1196,6 +1196,165 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
 }
 
 // ==========================================================================================
+// The last layer's PitchClass2PitchClass stack (cin <= 16 -> 16 -> 16 -> 16 channels on a 12 x T map) + the time pooling that
+// follows it (models.py:393, 396) in ONE launch: one workgroup of 16 waves per clip keeps the maps in LDS as channels-last
+// split planes (two ping-pong maps of 12 x (T + 8) x 16 channels), converts the NCHW f32 input while loading, runs the convs with
+// the MFMA loop of conv_pc_bf16_kernel<1, *> (same arithmetic in the same order), and the last epilogue takes the max over frame
+// pairs in registers and writes the pooled features twice: NCHW f32 (taps, f32 heads) and channels-last planes (bf16 heads).
+// Measured on the per-conv launches (phases switched off one at a time): 13 us of launch + epilogue and 4 us of patch load per
+// 21 us of MFMA loop, three times, plus the conversion and pooling passes.
+// ==========================================================================================
+struct Pc2pcFusedArgs {
+    const float* src;             // NCHW f32 [clip][cin][12][T]
+    long long src_clip_stride;
+    int cin, n_conv;
+    const uint4* bfrag[4];        // per conv: [48 k-steps][hi|lo][64 lanes] x 8 bf16
+    const float* bias[4];         // per conv: [16]
+    float* pooled;                // NCHW f32 [clip][16][12][T / 2]
+    unsigned short* fh;           // channels-last planes of the pooled features [clip][12][T / 2][16], or null
+    unsigned short* fl;
+    int T, Tp;                    // T % 4 == 0, 12 * T <= 1024; Tp = T + 8
+};
+
+__global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+    const int clip = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int T = a.T, Tp = a.Tp;
+    constexpr int MT = 4;
+    const int n16 = 12 * Tp * 2;                              // uint4 per plane
+    uint4* const map0 = lds4;                                 // two maps, each: hi plane, lo plane
+    uint4* const map1 = lds4 + 2 * n16;
+    for (int i = threadIdx.x; i < 4 * n16; i += 1024) lds4[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    {   // input: NCHW f32 -> split channels-last, frame t at patch position t + 3
+        const float* src = a.src + clip * a.src_clip_stride;
+        for (int i = threadIdx.x; i < 12 * T * 2; i += 1024) {
+            const int half = i & 1, pos = i >> 1;
+            const int y = pos / T, t = pos - y * T;
+            unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int c = half * 8 + k;
+                const float v = c < a.cin ? src[(static_cast<long long>(c) * 12 + y) * T + t] : 0.f;
+                const unsigned int hb = bf16_bits(v);
+                hi[k >> 1] |= hb << (16 * (k & 1));
+                lo[k >> 1] |= bf16_bits(v - __uint_as_float(hb << 16)) << (16 * (k & 1));
+            }
+            const int idx = ((y * Tp + t + 3) << 1) + half;
+            map0[idx] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            map0[n16 + idx] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+    }
+    __syncthreads();
+    const int Mtot = 12 * T;
+    const int tile0 = wave * MT;
+    const bool active = tile0 * 16 < Mtot;
+    int ay[MT], at[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = (tile0 + mt) * 16 + r16;
+        if (m >= Mtot) m = Mtot - 1;
+        ay[mt] = m / T;
+        at[mt] = m - ay[mt] * T;
+    }
+    typedef float f32x4c __attribute__((ext_vector_type(4)));
+    const int dxq = q >> 1, half = q & 1;
+    const int Tf = T / 2;
+    float* const pooled_c = a.pooled + static_cast<long long>(clip) * 16 * 12 * Tf;
+    unsigned short* const fh_c = a.fh ? a.fh + static_cast<long long>(clip) * 12 * Tf * 16 : nullptr;
+    unsigned short* const fl_c = a.fh ? a.fl + static_cast<long long>(clip) * 12 * Tf * 16 : nullptr;
+    for (int j = 0; j < a.n_conv; ++j) {
+        const uint4* const pH = (j & 1) ? map1 : map0;
+        const uint4* const pL = pH + n16;
+        unsigned short* const oH = reinterpret_cast<unsigned short*>((j & 1) ? map0 : map1);
+        unsigned short* const oL = oH + n16 * 8;
+        const bool last = j == a.n_conv - 1;
+        // (selected, not indexed: a dynamically indexed member array sends the whole argument struct through scratch memory,
+        //  and every load from it then drains the weight prefetch)
+        const uint4* const bfrag_j = j == 0 ? a.bfrag[0] : (j == 1 ? a.bfrag[1] : (j == 2 ? a.bfrag[2] : a.bfrag[3]));
+        const float* const bias_j = j == 0 ? a.bias[0] : (j == 1 ? a.bias[1] : (j == 2 ? a.bias[2] : a.bias[3]));
+        if (active) {
+            f32x4c acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
+            const uint4* __restrict__ bg = bfrag_j + lane;
+            uint4 nbh = bg[0], nbl = bg[64];
+#pragma unroll 1
+            for (int dy = 0; dy < 12; ++dy) {   // (not unrolled: with all 48 k-steps in one block hipcc serialises every load against its MFMA)
+                int rowoff[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    int row = ay[mt] + dy;
+                    row -= row >= 12 ? 12 : 0;
+                    rowoff[mt] = ((row * Tp + at[mt] + dxq) << 1) + half;
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int ks = dy * 4 + p;
+                    const bf16x8c bh = __builtin_bit_cast(bf16x8c, nbh), bl = __builtin_bit_cast(bf16x8c, nbl);
+                    const int kn = ks + 1 < 48 ? ks + 1 : ks;            // next k-step's weights, in flight during this one's MFMAs
+                    nbh = bg[(kn * 2 + 0) * 64]; nbl = bg[(kn * 2 + 1) * 64];
+                    bf16x8c ah[MT], al[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        ah[mt] = __builtin_bit_cast(bf16x8c, pH[rowoff[mt] + 4 * p]);
+                        al[mt] = __builtin_bit_cast(bf16x8c, pL[rowoff[mt] + 4 * p]);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt], 0, 0, 0);
+                }
+            }
+            // ---- epilogue: D[row m = 4q + i][col = co]; T % 4 == 0: the four positions of a lane share a row, frames t0 .. t0 + 3 ----
+            const int co = r16;
+            const float bias = bias_j[co];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m0 = (tile0 + mt) * 16 + 4 * q;
+                if (m0 < Mtot) {
+                    const int y = m0 / T, t0 = m0 - y * T;
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float x = acc[mt][i] + bias;
+                        v[i] = x > 0.f ? x : x * kSlope;
+                    }
+                    if (!last) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int e = ((((y * Tp + t0 + i + 3) << 1) + (co >> 3)) << 3) + (co & 7);
+                            const unsigned int hb = bf16_bits(v[i]);
+                            oH[e] = static_cast<unsigned short>(hb);
+                            oL[e] = static_cast<unsigned short>(bf16_bits(v[i] - __uint_as_float(hb << 16)));
+                        }
+                    } else {                                             // nn.MaxPool2d((1, 2)), models.py:396
+#pragma unroll
+                        for (int i = 0; i < 4; i += 2) {
+                            const float pv = fmaxf(v[i], v[i + 1]);
+                            const int tq = (t0 + i) >> 1;
+                            pooled_c[(co * 12 + y) * Tf + tq] = pv;      // (uniform clip base + 32-bit offsets: few address registers)
+                            if (a.fh) {
+                                const int e = (y * Tf + tq) * 16 + co;
+                                const unsigned int hb = bf16_bits(pv);
+                                fh_c[e] = static_cast<unsigned short>(hb);
+                                fl_c[e] = static_cast<unsigned short>(bf16_bits(pv - __uint_as_float(hb << 16)));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ==========================================================================================
 // Last convolution of the key / tonic heads: 32 channels -> ONE map, 12 x 7 over circular pitch classes, valid in time
 // (models.py:730-731).  With a single output channel the N dimension of the MFMA is filled with 16 output FRAMES (Toeplitz in
 // time), the K dimension with the 32 input channels of one tap -- channels-last split planes [clip][12][T_in][32] again:
