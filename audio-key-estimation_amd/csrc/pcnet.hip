@@ -1319,7 +1319,7 @@ struct Fwd {
         a.dst = b.semi_raw[layer]; a.dst_coff = 0; a.dst_clip_stride = 0;
         a.n_strips = (Tn + TW - 1) / TW;
         ta.in_affine = in_aff; ta.stats = b.stats + 2 * n->bns[bn].ch_off; ta.stats_stride = 2 * n->bn_channels;
-        const int per_clip = 12 * a.n_strips;
+        const int per_clip = (P / 3) * a.n_strips;            // thread = (semitone row, strip of frames)
         const int threads = per_clip >= 256 ? 256 : (per_clip + 63) / 64 * 64;
         dim3 grid((per_clip + threads - 1) / threads, pc.groups, B), block(threads);
         {
