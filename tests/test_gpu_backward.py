@@ -5,12 +5,12 @@ Tolerances.  The network has ~3M LeakyReLU pre-activations per step; the f32 for
 ~1e-6, so in most random cases ONE OR A FEW pre-activations within ~1e-6 of zero take the other branch ("kink flip").
 The gradient is discontinuous there: one flipped element moves dbeta of its BatchNorm by 0.99*|ga| and, through the
 batch statistics, every gradient upstream of it by 1e-4..5e-2 of its max (measured; float32 PyTorch on the CPU shows
-the same 1e-3 gaps against float64, at other layers).  tools/debug_bwd.py counts the flips of one layer and
-tools/grad_seed_scan.py scans (shape, seed) cases.  So:
+the same 1e-3 gaps against float64, at other layers).  tests/tools/debug_bwd.py counts the flips of one layer and
+tests/tools/grad_seed_scan.py scans (shape, seed) cases.  So:
   * TIGHT cases are (shape, seed) pairs without a flip: every tensor must agree to 2e-5 of its max -- this is what
     proves each kernel of the chain (a systematic error fails every seed);
   * KINKED cases only bound the damage (5e-2) and require the median tensor to stay tight.
-If a change of summation order moves a flip into a tight case, re-pick its seed with tools/grad_seed_scan.py."""
+If a change of summation order moves a flip into a tight case, re-pick its seed with tests/tools/grad_seed_scan.py."""
 import json
 from argparse import Namespace
 

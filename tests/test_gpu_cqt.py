@@ -2,7 +2,7 @@
 
 The CQT oracle is the build's own specification (parity with librosa is UNPINNED, oracle/cqt_oracle.py).
 Tolerance: 1e-3 of the tensor's peak (north_star); the multirate evaluation's own error is ~1.5e-4
-(tools/cqt_multirate_proto.py), so we assert 5e-4.
+(tests/tools/cqt_multirate_proto.py), so we assert 5e-4.
 """
 import numpy as np
 import pytest

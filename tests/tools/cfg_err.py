@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Error of the non-default configurations against the float64 oracle, fused and unfused (debug): python3 tools/cfg_err.py"""
+"""Error of the non-default configurations against the float64 oracle, fused and unfused (debug): python3 tests/tools/cfg_err.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from argparse import Namespace
 import torch
 import ake_amd

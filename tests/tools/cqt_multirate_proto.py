@@ -6,7 +6,7 @@ Not shipped, not imported by the product: a numpy model of the algorithm the HIP
 kernels implement (``csrc/cqt.hip``), used to choose the decimator length / Kaiser
 beta and to size the error budget recorded in DESIGN.md.
 
-    python3 tools/cqt_multirate_proto.py
+    python3 tests/tools/cqt_multirate_proto.py
 """
 from __future__ import annotations
 

@@ -1,10 +1,10 @@
 """Count LeakyReLU kink flips between the device's f32 training forward and the f64 oracle at the last pitch-stream
 BatchNorm of the default net, and list per-parameter gradient errors (see tests/test_gpu_backward.py for why these
-two are linked).  Usage on a GPU box: DBG_B=4 DBG_T=52 DBG_SEED=4 python tools/debug_bwd.py"""
+two are linked).  Usage on a GPU box: DBG_B=4 DBG_T=52 DBG_SEED=4 python tests/tools/debug_bwd.py"""
 import ctypes as C
 import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from argparse import Namespace
 import numpy as np, torch
 import ake_amd

@@ -2,8 +2,8 @@
 through the oracle.  Cases above ~1e-5 are LeakyReLU kink flips (one pre-activation whose sign differs between the f32
 forward and the f64 forward), see tests/test_gpu_backward.py."""
 import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from argparse import Namespace
 import numpy as np, torch
 import ake_amd

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""Which activation first departs from the oracle on a long clip: python3 tools/long_clip_bisect.py T [local]"""
+"""Which activation first departs from the oracle on a long clip: python3 tests/tools/long_clip_bisect.py T [local]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from argparse import Namespace
 import numpy as np, torch
 import ake_amd
 from oracle import pcnet_oracle
 T = int(sys.argv[1]); local = len(sys.argv) > 2
-gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "pcnet_default.npz"))
+gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "golden", "pcnet_default.npz"))
 sd = {k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("sd/")}
 sd64 = pcnet_oracle.to_dtype(sd, torch.float64)
 net = ake_amd.PitchClassNet(288, 12, 2, 7, Namespace(genre=True, local=local)); net.load_state_dict(sd); net = net.cuda().eval()

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Long clips (time-tiled kernels) against the float64 oracle, default and --local nets: python3 tools/long_clip_err.py"""
+"""Long clips (time-tiled kernels) against the float64 oracle, default and --local nets: python3 tests/tools/long_clip_err.py"""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from argparse import Namespace
 import numpy as np, torch
 import ake_amd
 from oracle import pcnet_oracle
-gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "pcnet_default.npz"))
+gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "golden", "pcnet_default.npz"))
 sd = {k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("sd/")}
 sd64 = pcnet_oracle.to_dtype(sd, torch.float64)
 def rel(a, b): return float((a.double().cpu() - b).abs().max() / b.abs().max())
