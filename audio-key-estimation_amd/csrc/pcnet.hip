@@ -565,7 +565,8 @@ int run_pc2pc_fused(const ake_pcnet* n, int i, const float* src, int cin, int ba
 
 // pitch-class convolution on bf16 MFMA (conv_pc_bf16_kernel): channels-last planes in; planes (cout == 16) or NCHW f32 out
 int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* planes_in, int batch, int T_in, bool same_time, bool lrelu,
-                float* dst_nchw, unsigned short* planes_out, hipStream_t s, const char* name) {
+                float* dst_nchw, unsigned short* planes_out, hipStream_t s, const char* name, const PackedConv* pc2 = nullptr,
+                unsigned short* planes_out2 = nullptr) {
     PcBfArgs a;
     std::memset(&a, 0, sizeof(a));
     const long long npos_in = static_cast<long long>(batch) * 12 * T_in;
@@ -580,6 +581,12 @@ int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
     a.dst = dst_nchw; a.dst_clip_stride = static_cast<long long>(pc.cout) * H_out * a.T_out;
     a.cl_stride = pc.cout;
     if (planes_out) { a.oh = planes_out; a.ol = planes_out + static_cast<long long>(batch) * H_out * a.T_out * pc.cout; }
+    if (pc2) {   // a second convolution of the same geometry over the same input, as blockIdx.y == 1 (planes out only)
+        AKE_REQUIRE(planes_out && planes_out2 && pc2->cout == pc.cout && pc2->kh == pc.kh && pc2->kw == pc.kw && pc2->cin == pc.cin && pc2->bf_off >= 0,
+                    AKE_ERR_STATE, "conv %s: the paired convolution differs in shape", name);
+        a.bfrag2 = n->bf_frags_dev + pc2->bf_off; a.bias2 = n->blob_dev + pc2->b_off;
+        a.oh2 = planes_out2; a.ol2 = planes_out2 + static_cast<long long>(batch) * H_out * a.T_out * pc.cout;
+    }
     const size_t lds = static_cast<size_t>(2) * 12 * a.Tp * 2 * sizeof(uint4);
     AKE_REQUIRE(lds <= 150 * 1024, AKE_ERR_UNSUPPORTED, "conv %s: %d frames do not fit the bf16 kernel's LDS patch", name, T_in);
     static bool attr_set = false;
@@ -592,7 +599,7 @@ int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
     }
     const int tiles = (H_out * a.T_out + 15) / 16;
     const int waves = std::min(8, (tiles + 3) / 4);
-    dim3 grid((tiles + waves * 4 - 1) / (waves * 4), 1, batch), block(waves * 64);
+    dim3 grid((tiles + waves * 4 - 1) / (waves * 4), pc2 ? 2 : 1, batch), block(waves * 64);
     ake::ProfScope ps(name, s);
     if (pc.cout == 16 && planes_out) hipLaunchKernelGGL((conv_pc_bf16_kernel<1, true>), grid, block, lds, s, a);
     else if (pc.cout == 16) hipLaunchKernelGGL((conv_pc_bf16_kernel<1, false>), grid, block, lds, s, a);
@@ -1629,7 +1636,11 @@ struct Fwd {
             const int nh = genre_bf ? 3 : 2;
             for (int h = 0; h < nh; ++h) {
                 unsigned short* planes = reinterpret_cast<unsigned short*>(hids[h]);
-                if ((rc = run_pc_bf16(n, *c0[h], feat_cl, B, Tf, false, true, nullptr, planes, s, h == 2 ? "conv_pc_bf16_kernel/genre_head" : "conv_pc_bf16_kernel/head")))
+                // the key and the tonic head read the same features with the same geometry: one launch, blockIdx.y picks the head
+                if (h == 0 && (rc = run_pc_bf16(n, *c0[0], feat_cl, B, Tf, false, true, nullptr, planes, s, "conv_pc_bf16_kernel/head", c0[1],
+                                                reinterpret_cast<unsigned short*>(hids[1]))))
+                    return rc;
+                if (h == 2 && (rc = run_pc_bf16(n, *c0[h], feat_cl, B, Tf, false, true, nullptr, planes, s, "conv_pc_bf16_kernel/genre_head")))
                     return rc;
                 ha.xh[h] = planes; ha.xl[h] = planes + static_cast<long long>(B) * 12 * T1 * 32;
                 ha.bfrag[h] = n->bf_frags_dev + c1[h]->bf_off; ha.bias[h] = n->blob_dev + c1[h]->b_off; ha.dst[h] = maps[h];

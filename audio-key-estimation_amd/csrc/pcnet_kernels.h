@@ -1076,6 +1076,11 @@ struct PcBfArgs {
     unsigned short* ol;
     int T_in, T_out, pad_l, Tp, cout, lrelu, cl_stride;
     int KH, circular;             // kernel rows (12 circular for the pitch-class convs; 1, rows independent, for the genre head's first conv)
+    // blockIdx.y == 1: a second convolution of the same geometry over the same input (the key and the tonic head in one launch)
+    const uint4* bfrag2;
+    const float* bias2;
+    unsigned short* oh2;
+    unsigned short* ol2;
 };
 
 template <int NT, bool OUT_CL>
@@ -1127,7 +1132,8 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4c{0.f, 0.f, 0.f, 0.f};
-    const uint4* __restrict__ bg = a.bfrag + lane;
+    const bool second = blockIdx.y == 1;
+    const uint4* __restrict__ bg = (second ? a.bfrag2 : a.bfrag) + lane;
     uint4 nbh[NT], nbl[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { nbh[nt] = bg[(nt * 2 + 0) * 64]; nbl[nt] = bg[(nt * 2 + 1) * 64]; }
@@ -1170,7 +1176,9 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = nt * 16 + r16;
-        const float bias = co < a.cout ? a.bias[co] : 0.f;
+        const float bias = co < a.cout ? (second ? a.bias2 : a.bias)[co] : 0.f;
+        unsigned short* const oh = second ? a.oh2 : a.oh;
+        unsigned short* const ol = second ? a.ol2 : a.ol;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int m0 = (tile0 + mt) * 16 + 4 * q;
@@ -1183,8 +1191,8 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
                     if (OUT_CL) {
                         const long long idx = ((static_cast<long long>(clip) * H_out + y) * a.T_out + t) * a.cl_stride + co;
                         const unsigned int hb = bf16_bits(v);
-                        a.oh[idx] = static_cast<unsigned short>(hb);
-                        a.ol[idx] = static_cast<unsigned short>(bf16_bits(v - __uint_as_float(hb << 16)));
+                        oh[idx] = static_cast<unsigned short>(hb);
+                        ol[idx] = static_cast<unsigned short>(bf16_bits(v - __uint_as_float(hb << 16)));
                     } else {
                         a.dst[clip * a.dst_clip_stride + (static_cast<long long>(co) * H_out + y) * a.T_out + t] = v;
                     }
