@@ -506,7 +506,8 @@ class PitchClassNet(LightningModule):
     @staticmethod
     def keep_taps(on=True):
         """Debug: keep every activation that `tap` can name in memory (inference otherwise fuses the semitone conv into the last
-        pitch conv of a stack and never writes `model.i.p2p.layer.8`).  Process-wide; returns the previous setting."""
+        pitch conv of a stack and runs the last pitch-class stack as one launch: `model.i.p2p.layer.8` and the last layer's
+        `pc2pc.layer.*` are then never written).  Process-wide; returns the previous setting."""
         return bool(_lib.lib().ake_debug_keep_taps(1 if on else 0))
 
     def tap(self, name):

@@ -203,7 +203,8 @@ int ake_adam_step_f32(float* params_dev, const float* grads_dev, float* exp_avg_
 /* Debug tap: copy an intermediate activation of the LAST forward call out of the workspace.
  * name is the reference module path whose output it is (e.g. "model.1.p2p.layer.8"). */
 int ake_pcnet_tap_info(const ake_pcnet* net, const char* name, int batch, int frames, int64_t shape[4]);
-/* Inference fuses the semitone conv into the last pitch conv of a stack, so "model.i.p2p.layer.8" is never written.
+/* Inference fuses the semitone conv into the last pitch conv of a stack and runs the last layer's pitch-class stack as one
+ * launch, so "model.i.p2p.layer.8" and the last layer's "pc2pc.layer.{2,5,8}" are never written (tap_info says so).
  * ake_debug_keep_taps(1) (process-wide, before the forward) keeps every nameable activation in memory (slower); returns the old value. */
 int ake_debug_keep_taps(int on);
 int ake_pcnet_tap_copy(const ake_pcnet* net, const char* name, int batch, int frames, const void* workspace,

@@ -62,6 +62,9 @@ def test_every_layer_against_reference_taps(gold_default, gold_taps):
     # inference fuses the semitone conv into the stack's last pitch conv: that conv's output is never written ...
     with pytest.raises(ake_amd._lib.AkeError, match="fused with the semitone conv"):
         net.tap("model.1.p2p.layer.8")
+    with pytest.raises(ake_amd._lib.AkeError, match="stays in LDS"):                       # ... nor the inside of the fused pitch-class stack
+        net.tap("model.1.pc2pc.layer.5")
+    assert rel_err(net.tap("model.1.time_pool_pc").cpu().numpy(), gold_taps["tap/model.1.time_pool_pc"]) < TOL
     fused_cat = net.tap("model.1.cat").clone()
     # ... unless the debug switch keeps every nameable activation in memory (the unfused kernels: f32 semitone conv)
     was = net.keep_taps(True)
