@@ -317,7 +317,8 @@ struct ConvGeom {            // explicit geometry for the data-gradient convolut
 // conv (12 x k, rows circular), 2 genre conv (kh in {1,2}, rows valid).
 int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int batch, int H, int T_in, bool same_time,
              bool lrelu, float* dst, int dst_ctot, int dst_coff, hipStream_t s, const char* name,
-             const float* in_affine = nullptr, double* stats = nullptr, const ConvGeom* geom = nullptr, bool accumulate = false) {
+             const float* in_affine = nullptr, double* stats = nullptr, const ConvGeom* geom = nullptr, bool accumulate = false,
+             const float* residual = nullptr) {
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
     AKE_REQUIRE(pc.kw == 7, AKE_ERR_UNSUPPORTED, "conv: kernel width %d not built (only 7)", pc.kw);
@@ -340,6 +341,7 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
     a.dst = dst; a.dst_coff = dst_coff; a.dst_clip_stride = static_cast<long long>(dst_ctot) * a.H_out * a.T_out;
     a.lrelu = lrelu ? 1 : 0;
     a.in_affine = in_affine; a.stats = stats; a.stats_stride = 2 * n->bn_channels; a.accumulate = accumulate ? 1 : 0;
+    a.residual = residual; a.residual_clip_stride = static_cast<long long>(pc.cout) * a.H_out * a.T_out;      // dense [B][cout][H][T]
     Tile t;
     MTile mtile;
     static const int mt_env = std::getenv("AKE_MT") ? std::atoi(std::getenv("AKE_MT")) : 3;
@@ -375,7 +377,7 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
 bool p2p_uses_bf16(const ake_pcnet* n, int i, int T) {
     static const bool f32_only = std::getenv("AKE_P2P_F32") != nullptr;
     const auto& c = n->cfg;
-    if (f32_only || i < 1 || c.conv_layers < 2 || n->dims[i].out_p != 8 || T > 146) return false;
+    if (f32_only || c.resblock || i < 1 || c.conv_layers < 2 || n->dims[i].out_p != 8 || T > 146) return false;
     for (int j = 0; j < c.conv_layers; ++j)
         if (n->p2p[i][j].bf_off < 0) return false;
     return true;
@@ -385,7 +387,7 @@ bool p2p_uses_bf16(const ake_pcnet* n, int i, int T) {
 constexpr int kPcBf16MaxFrames = 120;
 bool pc2pc_uses_bf16(const ake_pcnet* n, int i, int T) {
     static const bool f32_only = std::getenv("AKE_PC_F32") != nullptr;
-    if (f32_only || n->pc2pc[i].empty() || T > kPcBf16MaxFrames) return false;
+    if (f32_only || n->cfg.resblock || n->pc2pc[i].empty() || T > kPcBf16MaxFrames) return false;
     for (const PackedConv& pc : n->pc2pc[i])
         if (pc.bf_off < 0 || pc.cout != 16) return false;
     return true;
@@ -679,11 +681,11 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
             b->cat[i] = cv.take<float>((last || i == 1 ? B : C) * (d.prev_pc + d.out_p) * 12 * Ti);
             b->psix[i] = cv.take<float>((i == 1 ? B : C) * d.prev_pc * 36 * Ti);
             b->pa[i] = cv.take<float>(C * d.out_p * P * Ti);
-            b->pb[i] = cv.take<float>(C * d.out_p * P * Ti);
+            b->pb[i] = cv.take<float>((c.resblock ? 2 : 1) * C * d.out_p * P * Ti);          // --resblock: the blocks' 2C-channel hidden map
             if (!last) b->ppool[i] = cv.take<float>(C * d.out_p * P * (Ti / c.time_pool_size));
         }
         b->pca[i] = cv.take<float>((last || i == 0 ? B : C) * pc_out * 12 * Ti);
-        b->pcb[i] = cv.take<float>((last || i == 0 ? B : C) * pc_out * 12 * Ti);
+        b->pcb[i] = cv.take<float>((c.resblock ? 2 : 1) * (last || i == 0 ? B : C) * pc_out * 12 * Ti);
     }
     b->pcf = cv.take<float>(B * n->final_ch * 12 * b->Tf);
     const size_t hid = B * 2 * n->final_ch * 12 * b->Tf;
@@ -759,9 +761,9 @@ int ake_pcnet_default_config(ake_pcnet_config* cfg, int octaves, int genre) {
 int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
     AKE_REQUIRE(cfg && out, AKE_ERR_INVALID, "ake_pcnet_create: null argument");
     const ake_pcnet_config& c = *cfg;
-    AKE_REQUIRE(!(c.resblock || c.denseblock || c.stay_sixth || c.only_semitones || c.p2pc_conv || c.pc2p_mem),
+    AKE_REQUIRE(!(c.denseblock || c.stay_sixth || c.only_semitones || c.p2pc_conv || c.pc2p_mem),
                 AKE_ERR_UNSUPPORTED,
-                "pcnet: resblock/denseblock/stay_sixth/only_semitones/p2pc_conv/pc2p_mem variants are not built");
+                "pcnet: denseblock/stay_sixth/only_semitones/p2pc_conv/pc2p_mem variants are not built");
     AKE_REQUIRE(c.local >= 0, AKE_ERR_INVALID, "pcnet: local = pooling window of the --local heads (0: off)");
     AKE_REQUIRE(c.pitch_classes == 12, AKE_ERR_UNSUPPORTED, "pcnet: pitch_classes must be 12");
     AKE_REQUIRE(c.pitches > 0 && c.pitches % 36 == 0, AKE_ERR_INVALID, "pcnet: pitches must be a multiple of 36");
@@ -793,7 +795,18 @@ int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
         add_conv_specs(n, m + "pool_semi", cs, cs, 3, 3);                     // models.py:313 / :337
         add_bn_specs(n, m + "pool_semi_b", cs);
         const int pc_in = i == 0 ? 1 : d.out_p + d.prev_pc, pc_out = i == 0 ? nf : d.out_pc;
-        for (int j = 0; j < c.conv_layers; ++j) {                             // models.py:191-197
+        if (c.resblock) {                                                     // models.py:181-187: conv + BN, then conv_layers ResBlockEquivariant
+            add_conv_specs(n, m + "pc2pc.layer.0.conv2d", pc_out, pc_in, 12, k);
+            add_bn_specs(n, m + "pc2pc.layer.1", pc_out);
+            for (int r = 0; r < c.conv_layers; ++r) {                         // models.py:429-441
+                const std::string bp = m + "pc2pc.layer." + std::to_string(3 + r) + ".";
+                add_conv_specs(n, bp + "conv1.conv2d", 2 * pc_out, pc_out, 12, k);
+                add_bn_specs(n, bp + "b1", 2 * pc_out);
+                add_conv_specs(n, bp + "conv2.conv2d", pc_out, 2 * pc_out, 12, k);
+                add_bn_specs(n, bp + "b2", pc_out);
+            }
+        }
+        for (int j = 0; j < c.conv_layers && !c.resblock; ++j) {              // models.py:191-197
             add_conv_specs(n, m + "pc2pc.layer." + std::to_string(3 * j) + ".conv2d", pc_out, j == 0 ? pc_in : pc_out, 12, k);
             add_bn_specs(n, m + "pc2pc.layer." + std::to_string(3 * j + 1), pc_out);
         }
@@ -801,7 +814,18 @@ int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
             add_spec(n, m + "up_sixth.weight", {d.prev_pc, d.prev_pc, 3, 1}); // models.py:325
             add_spec(n, m + "up_sixth.bias", {d.prev_pc});
             add_bn_specs(n, m + "up_sixth_b", d.prev_pc);
-            for (int j = 0; j < c.conv_layers; ++j) {                         // models.py:228-234
+            if (c.resblock) {                                                 // models.py:218-224, 402-414
+                add_conv_specs(n, m + "p2p.layer.0", d.out_p, d.prev_pc + d.prev_p, k, k);
+                add_bn_specs(n, m + "p2p.layer.1", d.out_p);
+                for (int r = 0; r < c.conv_layers; ++r) {
+                    const std::string bp = m + "p2p.layer." + std::to_string(3 + r) + ".";
+                    add_conv_specs(n, bp + "conv1", 2 * d.out_p, d.out_p, k, k);
+                    add_bn_specs(n, bp + "b1", 2 * d.out_p);
+                    add_conv_specs(n, bp + "conv2", d.out_p, 2 * d.out_p, k, k);
+                    add_bn_specs(n, bp + "b2", d.out_p);
+                }
+            }
+            for (int j = 0; j < c.conv_layers && !c.resblock; ++j) {          // models.py:228-234
                 add_conv_specs(n, m + "p2p.layer." + std::to_string(3 * j), d.out_p, j == 0 ? d.prev_pc + d.prev_p : d.out_p, k, k);
                 add_bn_specs(n, m + "p2p.layer." + std::to_string(3 * j + 1), d.out_p);
             }
@@ -921,7 +945,15 @@ static void build_packs(ake_pcnet* n, bool train) {
             u.b_off = n->blob.size();
             for (double v : b) n->blob.push_back(static_cast<float>(v));
             up[i] = u;
-            for (int j = 0; j < c.conv_layers; ++j) {
+            if (c.resblock) {   // [conv0, (conv1, conv2) per block]; inference only: no data-gradient packs
+                p2p[i].push_back(fold_pack(n, m + "p2p.layer.0", bn(m + "p2p.layer.1", d.out_p), d.out_p, d.prev_pc + d.prev_p, k, k));
+                for (int r = 0; r < c.conv_layers; ++r) {
+                    const std::string bp = m + "p2p.layer." + std::to_string(3 + r) + ".";
+                    p2p[i].push_back(fold_pack(n, bp + "conv1", bn(bp + "b1", 2 * d.out_p), 2 * d.out_p, d.out_p, k, k));
+                    p2p[i].push_back(fold_pack(n, bp + "conv2", bn(bp + "b2", d.out_p), d.out_p, 2 * d.out_p, k, k));
+                }
+            }
+            for (int j = 0; j < c.conv_layers && !c.resblock; ++j) {
                 p2p[i].push_back(fold_pack(n, m + "p2p.layer." + std::to_string(3 * j), bn(m + "p2p.layer." + std::to_string(3 * j + 1), d.out_p),
                                            d.out_p, j == 0 ? d.prev_pc + d.prev_p : d.out_p, k, k));
                 if (train) n->p2p_d[i].push_back(dgrad_pack(n, m + "p2p.layer." + std::to_string(3 * j) + ".weight", d.out_p,
@@ -930,7 +962,15 @@ static void build_packs(ake_pcnet* n, bool train) {
         }
         semi[i] = fold_pack(n, m + "pool_semi", bn(m + "pool_semi_b", cs), cs, cs, 3, 3);
         const int pc_in = i == 0 ? 1 : d.out_p + d.prev_pc, pc_out = i == 0 ? c.n_filters : d.out_pc;
-        for (int j = 0; j < c.conv_layers; ++j) {
+        if (c.resblock) {
+            pc2pc[i].push_back(fold_pack(n, m + "pc2pc.layer.0.conv2d", bn(m + "pc2pc.layer.1", pc_out), pc_out, pc_in, 12, k));
+            for (int r = 0; r < c.conv_layers; ++r) {
+                const std::string bp = m + "pc2pc.layer." + std::to_string(3 + r) + ".";
+                pc2pc[i].push_back(fold_pack(n, bp + "conv1.conv2d", bn(bp + "b1", 2 * pc_out), 2 * pc_out, pc_out, 12, k));
+                pc2pc[i].push_back(fold_pack(n, bp + "conv2.conv2d", bn(bp + "b2", pc_out), pc_out, 2 * pc_out, 12, k));
+            }
+        }
+        for (int j = 0; j < c.conv_layers && !c.resblock; ++j) {
             pc2pc[i].push_back(fold_pack(n, m + "pc2pc.layer." + std::to_string(3 * j) + ".conv2d",
                                          bn(m + "pc2pc.layer." + std::to_string(3 * j + 1), pc_out), pc_out, j == 0 ? pc_in : pc_out, 12, k));
             if (train) n->pc2pc_d[i].push_back(dgrad_pack(n, m + "pc2pc.layer." + std::to_string(3 * j) + ".conv2d.weight", pc_out,
@@ -1297,8 +1337,8 @@ struct Fwd {
 
     // conv (+BatchNorm `bn_name` + LeakyReLU unless bn_name is empty).  Returns via *aff_out_used whether dst is raw.
     int conv(const PackedConv& pe, const PackedConv& pt, const std::string& bn_name, int kind, Src src, const float* in_aff,
-             int B, int H, int T_in, bool same, float* dst, int ctot, int coff, float* aff_dst, const char* name) {
-        if (!train) return run_conv(n, pe, kind, src, B, H, T_in, same, !bn_name.empty(), dst, ctot, coff, s, name);
+             int B, int H, int T_in, bool same, float* dst, int ctot, int coff, float* aff_dst, const char* name, const float* residual = nullptr) {
+        if (!train) return run_conv(n, pe, kind, src, B, H, T_in, same, !bn_name.empty(), dst, ctot, coff, s, name, nullptr, nullptr, nullptr, false, residual);
         const bool has_bn = !bn_name.empty();
         const int bn = has_bn ? bn_of(bn_name) : -1;
         int rc = run_conv(n, pt, kind, src, B, H, T_in, same, false, dst, ctot, coff, s, name, in_aff,
@@ -1308,6 +1348,25 @@ struct Fwd {
             const int T_out = same ? T_in : T_in - pt.kw + 1;
             const int H_out = kind == 2 ? H - pt.kh + 1 : H;
             finalize_bn(bn, static_cast<double>(B) * H_out * T_out, aff_dst);
+        }
+        return AKE_OK;
+    }
+
+    // --resblock stack (models.py:181-187 / 218-224, 402-454), inference: st = [conv0, (conv1, conv2) per block].  x lives in X
+    // (C channels, dense), a block's hidden map (2C channels) in Hb; conv2 adds x before its LeakyReLU, in place -- the last block
+    // may write channels [0, C) of a wider buffer instead (final_dst with final_ctot channels).
+    int res_stack(const std::vector<PackedConv>& st, int kind, Src first, int B, int H, int T, float* X, float* Hb, float* final_dst,
+                  int final_ctot, const char* label) {
+        const int C = st[0].cout;
+        int rc = conv(st[0], st[0], "bn", kind, first, nullptr, B, H, T, true, X, C, 0, nullptr, label);
+        if (rc) return rc;
+        const int nb = (static_cast<int>(st.size()) - 1) / 2;
+        for (int r = 0; r < nb; ++r) {
+            if ((rc = conv(st[1 + 2 * r], st[1 + 2 * r], "bn", kind, Src{X, C, nullptr, 0, 0}, nullptr, B, H, T, true, Hb, 2 * C, 0, nullptr, label))) return rc;
+            const bool to_final = r == nb - 1 && final_dst;
+            if ((rc = conv(st[2 + 2 * r], st[2 + 2 * r], "bn", kind, Src{Hb, 2 * C, nullptr, 0, 0}, nullptr, B, H, T, true, to_final ? final_dst : X,
+                           to_final ? final_ctot : C, 0, nullptr, label, X)))
+                return rc;
         }
         return AKE_OK;
     }
@@ -1384,7 +1443,7 @@ struct Fwd {
         static const bool off = std::getenv("AKE_L0_FUSED") != nullptr && std::atoi(std::getenv("AKE_L0_FUSED")) == 0;
         const auto& c = n->cfg;
         const int P = c.pitches, T0 = b.Tl[0], NF = c.n_filters;
-        if (off || NF < 2 || NF > 4 || c.conv_layers < 1 || c.conv_layers > 4 || c.kernel_size != 7 || P % 36 || T0 < 1) return false;
+        if (off || c.resblock || NF < 2 || NF > 4 || c.conv_layers < 1 || c.conv_layers > 4 || c.kernel_size != 7 || P % 36 || T0 < 1) return false;
         const PackedConv& sp = n->semi[0];
         if (sp.cin != 1 || sp.co != 1) return false;
         for (int j = 0; j < c.conv_layers; ++j) {
@@ -1445,7 +1504,10 @@ struct Fwd {
         const float* src_aff = nullptr;
         int cin = 1;
         const std::string m = "model.0.pc2pc.layer.";
-        for (int j = 0; j < c.conv_layers; ++j) {
+        if (c.resblock) {
+            if ((rc = res_stack(n->pc2pc[0], 1, Src{b.fold0, 1, nullptr, 0, 0}, B, 12, T0, b.pca[0], b.pcb[0], b.cat[1], ctot1, "conv_mfma_kernel/pc2pc0"))) return rc;
+        }
+        for (int j = 0; j < c.conv_layers && !c.resblock; ++j) {
             const bool lastj = j == c.conv_layers - 1;           // the last conv writes channels [0, nf) of layer 1's concat buffer
             float* dst = lastj ? b.cat[1] : (train ? b.pcst[0][j] : ((j & 1) ? b.pcb[0] : b.pca[0]));
             float* aff = !train ? nullptr : (lastj ? b.aff_cat[1] : b.aff_pcst[0][j]);
@@ -1495,7 +1557,11 @@ struct Fwd {
             const bool bf = !train && p2p_uses_bf16(n, i, Ti);
             bool fused_semi = false;
             const size_t plane = static_cast<size_t>(B) * P * Ti * 8;                 // bf16 elements per plane
-            for (int j = 0; j < c.conv_layers; ++j) {
+            if (c.resblock) {
+                if ((rc = res_stack(n->p2p[i], 0, sdesc, B, P, Ti, b.pa[i], b.pb[i], nullptr, 0, "conv_mfma_kernel/p2p"))) return rc;
+                out = b.pa[i];
+            }
+            for (int j = 0; j < c.conv_layers && !c.resblock; ++j) {
                 out = train ? b.pst[i][j] : ((j & 1) ? b.pb[i] : b.pa[i]);
                 out_aff = !train ? nullptr : b.aff_pst[i][j];
                 if (bf) {
@@ -1538,7 +1604,11 @@ struct Fwd {
             int cin = ctot;
             float* pdst = nullptr;
             float* pdst_aff = nullptr;
-            for (int j = 0; j < c.conv_layers; ++j) {
+            if (c.resblock) {
+                if ((rc = res_stack(n->pc2pc[i], 1, Src{psrc, cin, nullptr, 0, 0}, B, 12, Ti, b.pca[i], b.pcb[i], nullptr, 0, "conv_mfma_kernel/pc2pc"))) return rc;
+                pdst = b.pca[i];
+            }
+            for (int j = 0; j < c.conv_layers && !c.resblock; ++j) {
                 pdst = train ? b.pcst[i][j] : ((j & 1) ? b.pcb[i] : b.pca[i]);
                 pdst_aff = !train ? nullptr : b.aff_pcst[i][j];
                 if ((rc = conv(n->pc2pc[i][j], train ? n->pc2pc_t[i][j] : n->pc2pc[i][j], m + "pc2pc.layer." + std::to_string(3 * j + 1), 1,
@@ -1584,7 +1654,13 @@ struct Fwd {
         if (pc_fused) {
             if ((rc = run_pc2pc_fused(n, i, psrc, cin, B, Ti, b.pcf, head_bf ? b.feat_cl : nullptr, s))) return rc;
         } else if (pc_bf) run_nchw_to_cl16(psrc, cin, B, Ti, reinterpret_cast<unsigned short*>(b.pcb[i]), s);
-        for (int j = 0; j < c.conv_layers && !pc_fused; ++j) {
+        if (c.resblock) {
+            if ((rc = res_stack(n->pc2pc[i], 1, Src{psrc, cin, nullptr, 0, 0}, B, 12, Ti, b.pca[i], b.pcb[i], nullptr, 0,
+                                L == 1 ? "conv_mfma_kernel/pc2pc0" : "conv_mfma_kernel/pc2pc")))
+                return rc;
+            pdst = b.pca[i];
+        }
+        for (int j = 0; j < c.conv_layers && !pc_fused && !c.resblock; ++j) {
             pdst = train ? b.pcst[i][j] : ((j & 1) ? b.pcb[i] : b.pca[i]);
             pdst_aff = !train ? nullptr : b.aff_pcst[i][j];
             if (pc_bf) {
@@ -1758,6 +1834,7 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
     AKE_REQUIRE(!n->cfg.genre || d_genre, AKE_ERR_INVALID, "pcnet backward: genre head enabled but d_genre is null");
     AKE_REQUIRE(n->cfg.local == 0, AKE_ERR_UNSUPPORTED, "pcnet: training a --local net is not built");
+    AKE_REQUIRE(!n->cfg.resblock, AKE_ERR_UNSUPPORTED, "pcnet: training a --resblock net is not built");
     Buffers b;
     int rc = plan_buffers(n, batch, batch, frames, workspace, &b, true);
     if (rc) return rc;
@@ -1804,6 +1881,7 @@ int ake_pcnet_forward_train_f32(const ake_pcnet* n, const float* mel, int batch,
                                 float* key_out, float* tonic_out, float* genre_out, float* bn_stats_out, void* workspace,
                                 size_t ws_bytes, ake_stream_t stream) {
     AKE_REQUIRE(!n || n->cfg.local == 0, AKE_ERR_UNSUPPORTED, "pcnet: training a --local net (per-frame losses, models.py:861-876) is not built");
+    AKE_REQUIRE(!n || !n->cfg.resblock, AKE_ERR_UNSUPPORTED, "pcnet: training a --resblock net is not built (inference only)");
     return forward_impl(n, true, mel, batch, frames, seq_length, key_out, tonic_out, genre_out, bn_stats_out, workspace, ws_bytes, stream);
 }
 
@@ -1837,6 +1915,10 @@ static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frame
     const std::string nm = name;
     auto set = [&](float* ptr, int64_t C, int64_t H, int64_t Tn) { *p = ptr; shape[0] = batch; shape[1] = C; shape[2] = H; shape[3] = Tn; return AKE_OK; };
     if (nm == "model.0.pool") return set(b.fold0, 1, 12, frames);
+    if (c.resblock && (std::strstr(name, "pc2pc.layer.") || std::strstr(name, "p2p.layer."))) {
+        ake::set_error("tap: '%s': the stacks of a --resblock net are not tapped", name);
+        return AKE_ERR_INVALID;
+    }
     for (int i = 0; i < L; ++i) {
         const std::string m = "model." + std::to_string(i) + ".";
         const LayerDims& d = n->dims[i];

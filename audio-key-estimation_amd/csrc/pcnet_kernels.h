@@ -53,6 +53,8 @@ struct ConvArgs {
     double* stats;            // [kStatSlots][..][2] += (sum, sum of squares) of the raw outputs, or null
     int stats_stride;         // doubles between two slots of `stats` (workgroups spread their atomics over the slots)
     int accumulate;           // 1: dst += result (several data-gradients landing on one tensor)
+    const float* residual;    // --resblock: [B][cout][H_out][T_out] added before the LeakyReLU (may be dst itself), or null
+    long long residual_clip_stride;
 };
 
 // Per-channel batch statistics are accumulated with double atomics; thousands of workgroups hitting the same 16 addresses
@@ -501,6 +503,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
     //      One division per M-tile: positions 4q..4q+3 of a tile are consecutive frame groups (j, j+1, ..) of row r,
     //      carried into the next row when j reaches J. ----
     float* d = a.dst + clip * a.dst_clip_stride + t0;
+    const float* rs = a.residual ? a.residual + clip * a.residual_clip_stride + t0 : nullptr;
     const int row_elems = a.T_out;
     float st1[NT], st2[NT];
 #pragma unroll
@@ -519,6 +522,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
                 const int tl = TB * j + tau;
                 if (ok_m && co < a.cout && tl < tt_here) {
                     float v = acc[mt][nt][reg] + a.bias[co];
+                    if (rs) v += rs[(co * a.H_out + (y0 + r)) * row_elems + tl];
                     if (TRAIN && a.stats) { st1[nt] += v; st2[nt] = fmaf(v, v, st2[nt]); }
                     if (a.lrelu) v = v > 0.f ? v : v * kSlope;
                     float* dp = d + ((a.dst_coff + co) * a.H_out + (y0 + r)) * row_elems + tl;

@@ -22,7 +22,7 @@ from . import _lib
 from .lightning_shim import LightningModule
 from .metrics import mirex_score as _mirex_score
 
-_VARIANT_FLAGS = ("resblock", "denseblock", "stay_sixth", "only_semitones", "p2pc_conv", "pc2p_mem")
+_VARIANT_FLAGS = ("denseblock", "stay_sixth", "only_semitones", "p2pc_conv", "pc2p_mem")
 
 
 class EquivariantPitchClassConvolutionSimple(nn.Module):
@@ -42,14 +42,47 @@ class _ConvStack(nn.Module):
         self.layer = nn.Sequential(*blocks)
 
 
-def _pc2pc(cin, cout, k, n):
+class ResBlock(nn.Module):
+    """Parameter container for models.py:402-427 (x -> act2(x + b2(conv2(act1(b1(conv1(x))))))); creation order as the reference's."""
+
+    def __init__(self, kernel_size, conv_layers, num_filters):
+        super().__init__()
+        k = kernel_size
+        self.conv1 = nn.Conv2d(num_filters, 2 * num_filters, k, padding=(k // 2, k // 2), padding_mode="circular")
+        self.b1 = nn.BatchNorm2d(2 * num_filters)
+        self.act1 = nn.LeakyReLU()
+        self.conv2 = nn.Conv2d(2 * num_filters, num_filters, k, padding=(k // 2, k // 2), padding_mode="circular")
+        self.b2 = nn.BatchNorm2d(num_filters)
+        self.act2 = nn.LeakyReLU()
+
+
+class ResBlockEquivariant(nn.Module):
+    """Parameter container for models.py:429-454."""
+
+    def __init__(self, kernel_size, conv_layers, num_filters):
+        super().__init__()
+        self.conv1 = EquivariantPitchClassConvolutionSimple(12, num_filters, 2 * num_filters, kernel_size, True)
+        self.b1 = nn.BatchNorm2d(2 * num_filters)
+        self.act1 = nn.LeakyReLU()
+        self.conv2 = EquivariantPitchClassConvolutionSimple(12, 2 * num_filters, num_filters, kernel_size, True)
+        self.b2 = nn.BatchNorm2d(num_filters)
+        self.act2 = nn.LeakyReLU()
+
+
+def _pc2pc(cin, cout, k, n, resblock=False):
+    if resblock:                                                      # models.py:181-187
+        blocks = [EquivariantPitchClassConvolutionSimple(12, cin, cout, k, True), nn.BatchNorm2d(cout), nn.LeakyReLU()]
+        return _ConvStack(blocks + [ResBlockEquivariant(k, n, cout) for _ in range(n)])
     blocks = []
     for i in range(n):
         blocks += [EquivariantPitchClassConvolutionSimple(12, cin if i == 0 else cout, cout, k, True), nn.BatchNorm2d(cout), nn.LeakyReLU()]
     return _ConvStack(blocks)
 
 
-def _p2p(cin, cout, k, n):
+def _p2p(cin, cout, k, n, resblock=False):
+    if resblock:                                                      # models.py:218-224
+        blocks = [nn.Conv2d(cin, cout, k, padding=k // 2, padding_mode="circular"), nn.BatchNorm2d(cout), nn.LeakyReLU()]
+        return _ConvStack(blocks + [ResBlock(k, n, cout) for _ in range(n)])
     blocks = []
     for i in range(n):
         blocks += [nn.Conv2d(cin if i == 0 else cout, cout, k, padding=k // 2, padding_mode="circular"), nn.BatchNorm2d(cout), nn.LeakyReLU()]
@@ -60,13 +93,13 @@ class PitchClassNetLayer(nn.Module):
     """Parameter container for one layer (models.py:246-350); creation order matches the reference
     so that the same torch seed gives the same initial weights."""
 
-    def __init__(self, layer_num, nf, k, conv_layers):
+    def __init__(self, layer_num, nf, k, conv_layers, resblock=False):
         super().__init__()
         if layer_num == 0:
             self.pool_semi = nn.Conv2d(1, 1, 3, stride=(3, 1), padding=(0, 1), padding_mode="circular")
             self.pool_semi_b = nn.BatchNorm2d(1)
             self.pool_semi_a = nn.LeakyReLU()
-            self.pc2pc = _pc2pc(1, nf, k, conv_layers)
+            self.pc2pc = _pc2pc(1, nf, k, conv_layers, resblock)
             return
         if layer_num == 1:
             prev_p, prev_pc = 1, nf
@@ -79,11 +112,11 @@ class PitchClassNetLayer(nn.Module):
         self.up_sixth = nn.ConvTranspose2d(prev_pc, prev_pc, kernel_size=(3, 1), stride=(3, 1))
         self.up_sixth_b = nn.BatchNorm2d(prev_pc)
         self.up_sixth_a = nn.LeakyReLU()
-        self.p2p = _p2p(prev_pc + prev_p, out_p, k, conv_layers)
+        self.p2p = _p2p(prev_pc + prev_p, out_p, k, conv_layers, resblock)
         self.pool_semi = nn.Conv2d(out_p, out_p, (3, 3), stride=(3, 1), padding=(0, 1), padding_mode="circular")
         self.pool_semi_b = nn.BatchNorm2d(out_p)
         self.pool_semi_a = nn.LeakyReLU()
-        self.pc2pc = _pc2pc(out_p + prev_pc, out_pc, k, conv_layers)
+        self.pc2pc = _pc2pc(out_p + prev_pc, out_pc, k, conv_layers, resblock)
         self.out_pc = out_pc
 
 
@@ -149,7 +182,9 @@ class PitchClassNet(LightningModule):
                                     - _opt_get(opt, "head_layers", 2) * (kernel_size - 1))
             if self.local_window < 1:
                 raise ValueError("--local: frames * loc_window_size must exceed head_layers * (kernel_size - 1)")
-        self.model = nn.Sequential(*[PitchClassNetLayer(i, nf, k, self.conv_layers) for i in range(num_layers)])
+        # --resblock (models.py:181-187, 218-224, 402-454): the stacks are one conv + conv_layers residual blocks.  Inference only here.
+        self.resblock = bool(_opt_get(opt, "resblock", False))
+        self.model = nn.Sequential(*[PitchClassNetLayer(i, nf, k, self.conv_layers, self.resblock) for i in range(num_layers)])
         final = nf if num_layers == 1 else self.model[num_layers - 1].out_pc          # models.py:694-710
         self.head_layers = _opt_get(opt, "head_layers", 2)
         self.genre = bool(_opt_get(opt, "genre", False))
@@ -195,6 +230,7 @@ class PitchClassNet(LightningModule):
         c.genre = 1 if self.genre else 0
         c.max_pool = 1 if _opt_get(self.opt, "max_pool", False) else 0
         c.local = self.local_window
+        c.resblock = 1 if self.resblock else 0
         return c
 
     def _layout(self):
@@ -367,6 +403,8 @@ class PitchClassNet(LightningModule):
         ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream().cuda_stream
+            if self.training and self.resblock:
+                raise NotImplementedError("training a --resblock net is not built on the HIP path (inference only)")
             if self.training:
                 # BatchNorm with batch statistics; with autograd enabled the call becomes one autograd node whose backward
                 # runs the HIP backward kernels (gradients for every parameter), as loss.backward() does in the reference

@@ -273,6 +273,22 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "pcnet_local_T120.npz"), x=xl.numpy(), window=np.int64(W),
                         key=kl.numpy(), tonic=tl.numpy(), genre=gnl.numpy())
 
+    # ---------------------------------------------------------------- F: --resblock, B=2, T=28
+    print("F: --resblock (ResBlock / ResBlockEquivariant stacks), seeded weights, B=2, T=28")
+    opt_r = default_opt(resblock=True)
+    net_r, sd_r = build_reference_net(opt_r, seed=21)
+    net_r.eval()
+    gr = torch.Generator().manual_seed(654)
+    xr = (torch.rand((2, 1, 288, 28), generator=gr) * 2.5).float()
+    seq_r = torch.tensor([28, 22])
+    kr, tr, gnr = net_r(xr.double(), seq_r)
+    okr, otr, ogr = pcnet_oracle.pcnet_forward(sd_r, xr.double(), seq_r)
+    report["checks"]["F_key"] = check("resblock key", okr, kr, 1e-12)
+    report["checks"]["F_tonic"] = check("resblock tonic", otr, tr, 1e-12)
+    report["checks"]["F_genre"] = check("resblock genre", ogr, gnr, 1e-12)
+    np.savez_compressed(os.path.join(GOLD, "pcnet_resblock_T28.npz"), opt=json.dumps(vars(opt_r)), x=xr.numpy(), seq_length=seq_r.numpy(),
+                        key=kr.numpy(), tonic=tr.numpy(), genre=gnr.numpy(), **sd_to_npz(sd_r))
+
     with open(os.path.join(GOLD, "PROVENANCE.json"), "w") as f:
         json.dump(report, f, indent=1)
     print("wrote", sorted(os.listdir(GOLD)))

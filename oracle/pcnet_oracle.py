@@ -124,8 +124,28 @@ def _count(sd, prefix, suffix):
     return n
 
 
+def _res_blocks(x, sd, prefix, conv, training, taps):
+    """--resblock (models.py:181-187 / :218-224): after the first conv + BN + LeakyReLU the Sequential holds ``conv_layers`` blocks
+    at indices 3, 4, ...; a block is x -> act2(x + b2(conv2(act1(b1(conv1(x)))))) (ResBlock / ResBlockEquivariant, models.py:402-454).
+    ``conv(x, block_prefix + "conv1")`` applies the stack's convolution type."""
+    idx = 3
+    while f"{prefix}layer.{idx}.b1.weight" in sd:
+        bp = f"{prefix}layer.{idx}."
+        h = _lrelu(_bn(conv(x, bp + "conv1"), sd, bp + "b1.", training))
+        x = _lrelu(x + _bn(conv(h, bp + "conv2"), sd, bp + "b2.", training))
+        if taps is not None:
+            taps[f"{prefix}layer.{idx}"] = x
+        idx += 1
+    return x
+
+
 def pc2pc_stack(pc, sd, prefix, training=False, taps=None):
-    """PitchClass2PitchClass default branch, models.py:190-197, 201-203."""
+    """PitchClass2PitchClass default branch, models.py:190-197, 201-203; --resblock branch :181-187."""
+    if f"{prefix}layer.3.b1.weight" in sd:
+        pc = equiv_pc_conv(pc, sd[prefix + "layer.0.conv2d.weight"], sd[prefix + "layer.0.conv2d.bias"], same=True)
+        pc = _lrelu(_bn(pc, sd, prefix + "layer.1.", training))
+        return _res_blocks(pc, sd, prefix, lambda x, q: equiv_pc_conv(x, sd[q + ".conv2d.weight"], sd[q + ".conv2d.bias"], same=True),
+                           training, taps)
     n = _count(sd, prefix + "layer.", ".conv2d.weight")
     for i in range(n):
         pc = equiv_pc_conv(pc, sd[f"{prefix}layer.{3*i}.conv2d.weight"], sd[f"{prefix}layer.{3*i}.conv2d.bias"], same=True)
@@ -136,7 +156,11 @@ def pc2pc_stack(pc, sd, prefix, training=False, taps=None):
 
 
 def p2p_stack(p, sd, prefix, training=False, taps=None):
-    """Pitch2Pitch default branch, models.py:227-234, 239-243: circular on both axes."""
+    """Pitch2Pitch default branch, models.py:227-234, 239-243: circular on both axes; --resblock branch :218-224."""
+    if f"{prefix}layer.3.b1.weight" in sd:
+        circ = lambda x, q: _circular_conv(x, sd[q + ".weight"], sd[q + ".bias"], (1, 1), (sd[q + ".weight"].shape[2] // 2,) * 2)
+        p = _lrelu(_bn(circ(p, prefix + "layer.0"), sd, prefix + "layer.1.", training))
+        return _res_blocks(p, sd, prefix, circ, training, taps)
     n = _count(sd, prefix + "layer.", ".weight")
     for i in range(n):
         w = sd[f"{prefix}layer.{3*i}.weight"]

@@ -51,6 +51,11 @@ def gold_local():
 
 
 @pytest.fixture(scope="session")
+def gold_resblock():
+    return load_golden("pcnet_resblock_T28.npz")
+
+
+@pytest.fixture(scope="session")
 def gold_mirex():
     return load_golden("mirex_loss_cases.npz")
 

@@ -250,6 +250,30 @@ def test_local_heads_against_reference_fixture(gold_default, gold_local):
         net.train()(x, None)
 
 
+def test_resblock_against_reference_fixture(gold_resblock):
+    """--resblock (the first architecture variant; models.py:181-187, 218-224, 402-454), inference: the reference's
+    own outputs for its own seeded weights; a second shape (three layers deep would change the family: two layers, B = 3, T = 52) against
+    the oracle."""
+    net, opt = make_net(gold_resblock)
+    assert net.resblock
+    x = torch.from_numpy(gold_resblock["x"]).to(DEV)
+    seq = torch.from_numpy(gold_resblock["seq_length"]).to(DEV)
+    key, tonic, genre = net(x, seq)
+    assert rel_err(key.cpu(), gold_resblock["key"]) < TOL
+    assert rel_err(tonic.cpu(), gold_resblock["tonic"]) < TOL
+    assert rel_err(genre.cpu(), gold_resblock["genre"]) < TOL
+    g = torch.Generator().manual_seed(8)
+    x2 = torch.rand((3, 1, 288, 52), generator=g) * 2.5
+    seq2 = torch.tensor([52, 40, 31])
+    ref = pcnet_oracle.pcnet_forward(golden_state_dict(gold_resblock, torch.float64), x2.double(), seq2)
+    for a, b in zip(net(x2.to(DEV), seq2.to(DEV)), ref):
+        assert rel_err(a.cpu(), b) < TOL
+    with pytest.raises(NotImplementedError):
+        net.train()(x, seq)
+    with pytest.raises(ake_amd._lib.AkeError, match="not tapped"):
+        net.eval()(x, seq); net.tap("model.1.p2p.layer.5")
+
+
 def test_edge_shapes(gold_default):
     net, _ = make_net(gold_default)
     sd = golden_state_dict(gold_default, torch.float64)

@@ -98,6 +98,17 @@ def test_local_heads_against_reference_fixture(gold_default, gold_local):
     assert np.abs(g.numpy() - gold_local["genre"]).max() <= 1e-12
 
 
+def test_resblock_against_reference_fixture(gold_resblock):
+    """--resblock (models.py:181-187, 218-224, 402-454): every stack = conv + BN + LeakyReLU, then conv_layers residual blocks
+    x -> act(x + b2(conv2(act(b1(conv1(x)))))); fixture from the reference run with opt.resblock."""
+    sd = golden_state_dict(gold_resblock, torch.float64)
+    assert "model.1.p2p.layer.3.conv1.weight" in sd and "model.0.pc2pc.layer.5.conv2.conv2d.weight" in sd
+    k, t, g = pcnet_oracle.pcnet_forward(sd, torch.from_numpy(gold_resblock["x"]).double(), torch.from_numpy(gold_resblock["seq_length"]))
+    assert np.abs(k.numpy() - gold_resblock["key"]).max() <= 1e-12
+    assert np.abs(t.numpy() - gold_resblock["tonic"]).max() <= 1e-12
+    assert np.abs(g.numpy() - gold_resblock["genre"]).max() <= 1e-12
+
+
 def test_max_pool_quirk(gold_default):
     """--max_pool with seq_length: only sample 0 takes the max (models.py:764-785)."""
     sd = golden_state_dict(gold_default, torch.float64)
