@@ -634,7 +634,7 @@ int run_semi(const ake_pcnet* n, const PackedConv& pc, const float* src, int bat
 struct Buffers {           // workspace carve
     // per chunk (pitch stream): everything up to the last layer's semitone fold
     float* fold0 = nullptr;
-    std::vector<float*> cat, psix, pa, pb, pca, pcb, ppool;
+    std::vector<float*> cat, psix, pa, pb, pca, pcb, ppool, pin;
     // whole batch (pitch-class tail): last layer's concat buffer, its pc stack, pooled features, heads
     float *pcf = nullptr, *hid_k = nullptr, *hid_t = nullptr, *hid_g = nullptr;
     float *map_k = nullptr, *map_t = nullptr, *map_g = nullptr;
@@ -669,7 +669,7 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
     b->Tf = L > 1 ? b->Tl[L - 1] / c.time_pool_size : frames;
     AKE_REQUIRE(b->Tf >= 1, AKE_ERR_INVALID, "pcnet: %d frames vanish under the time pooling", frames);
     b->cat.assign(L + 1, nullptr); b->psix.assign(L, nullptr); b->pa.assign(L, nullptr); b->pb.assign(L, nullptr);
-    b->pca.assign(L, nullptr); b->pcb.assign(L, nullptr); b->ppool.assign(L, nullptr);
+    b->pca.assign(L, nullptr); b->pcb.assign(L, nullptr); b->ppool.assign(L, nullptr); b->pin.assign(L, nullptr);
     const size_t C = chunk, B = batch;
     b->fold0 = cv.take<float>(B * 12 * frames);
     for (int i = 0; i < L; ++i) {
@@ -680,6 +680,7 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
         if (i >= 1) {
             b->cat[i] = cv.take<float>((last || i == 1 ? B : C) * (d.prev_pc + d.out_p) * 12 * Ti);
             b->psix[i] = cv.take<float>((i == 1 ? B : C) * d.prev_pc * 36 * Ti);
+            if (c.pc2p_mem) b->pin[i] = cv.take<float>(C * d.prev_p * P * Ti);             // --pc2p_mem: pitch stream + summed up_sixth map
             b->pa[i] = cv.take<float>(C * d.out_p * P * Ti);
             b->pb[i] = cv.take<float>((c.resblock ? 2 : 1) * C * d.out_p * P * Ti);          // --resblock: the blocks' 2C-channel hidden map
             if (!last) b->ppool[i] = cv.take<float>(C * d.out_p * P * (Ti / c.time_pool_size));
@@ -761,9 +762,9 @@ int ake_pcnet_default_config(ake_pcnet_config* cfg, int octaves, int genre) {
 int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
     AKE_REQUIRE(cfg && out, AKE_ERR_INVALID, "ake_pcnet_create: null argument");
     const ake_pcnet_config& c = *cfg;
-    AKE_REQUIRE(!(c.denseblock || c.stay_sixth || c.only_semitones || c.p2pc_conv || c.pc2p_mem),
+    AKE_REQUIRE(!(c.denseblock || c.stay_sixth || c.only_semitones || c.p2pc_conv),
                 AKE_ERR_UNSUPPORTED,
-                "pcnet: denseblock/stay_sixth/only_semitones/p2pc_conv/pc2p_mem variants are not built");
+                "pcnet: denseblock/stay_sixth/only_semitones/p2pc_conv variants are not built");
     AKE_REQUIRE(c.local >= 0, AKE_ERR_INVALID, "pcnet: local = pooling window of the --local heads (0: off)");
     AKE_REQUIRE(c.pitch_classes == 12, AKE_ERR_UNSUPPORTED, "pcnet: pitch_classes must be 12");
     AKE_REQUIRE(c.pitches > 0 && c.pitches % 36 == 0, AKE_ERR_INVALID, "pcnet: pitches must be a multiple of 36");
@@ -815,7 +816,7 @@ int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
             add_spec(n, m + "up_sixth.bias", {d.prev_pc});
             add_bn_specs(n, m + "up_sixth_b", d.prev_pc);
             if (c.resblock) {                                                 // models.py:218-224, 402-414
-                add_conv_specs(n, m + "p2p.layer.0", d.out_p, d.prev_pc + d.prev_p, k, k);
+                add_conv_specs(n, m + "p2p.layer.0", d.out_p, c.pc2p_mem ? d.prev_p : d.prev_pc + d.prev_p, k, k);
                 add_bn_specs(n, m + "p2p.layer.1", d.out_p);
                 for (int r = 0; r < c.conv_layers; ++r) {
                     const std::string bp = m + "p2p.layer." + std::to_string(3 + r) + ".";
@@ -826,7 +827,7 @@ int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
                 }
             }
             for (int j = 0; j < c.conv_layers && !c.resblock; ++j) {          // models.py:228-234
-                add_conv_specs(n, m + "p2p.layer." + std::to_string(3 * j), d.out_p, j == 0 ? d.prev_pc + d.prev_p : d.out_p, k, k);
+                add_conv_specs(n, m + "p2p.layer." + std::to_string(3 * j), d.out_p, j == 0 ? (c.pc2p_mem ? d.prev_p : d.prev_pc + d.prev_p) : d.out_p, k, k);
                 add_bn_specs(n, m + "p2p.layer." + std::to_string(3 * j + 1), d.out_p);
             }
         }
@@ -946,7 +947,7 @@ static void build_packs(ake_pcnet* n, bool train) {
             for (double v : b) n->blob.push_back(static_cast<float>(v));
             up[i] = u;
             if (c.resblock) {   // [conv0, (conv1, conv2) per block]; inference only: no data-gradient packs
-                p2p[i].push_back(fold_pack(n, m + "p2p.layer.0", bn(m + "p2p.layer.1", d.out_p), d.out_p, d.prev_pc + d.prev_p, k, k));
+                p2p[i].push_back(fold_pack(n, m + "p2p.layer.0", bn(m + "p2p.layer.1", d.out_p), d.out_p, c.pc2p_mem ? d.prev_p : d.prev_pc + d.prev_p, k, k));
                 for (int r = 0; r < c.conv_layers; ++r) {
                     const std::string bp = m + "p2p.layer." + std::to_string(3 + r) + ".";
                     p2p[i].push_back(fold_pack(n, bp + "conv1", bn(bp + "b1", 2 * d.out_p), 2 * d.out_p, d.out_p, k, k));
@@ -954,10 +955,10 @@ static void build_packs(ake_pcnet* n, bool train) {
                 }
             }
             for (int j = 0; j < c.conv_layers && !c.resblock; ++j) {
+                const int cin_j = j == 0 ? (c.pc2p_mem ? d.prev_p : d.prev_pc + d.prev_p) : d.out_p;
                 p2p[i].push_back(fold_pack(n, m + "p2p.layer." + std::to_string(3 * j), bn(m + "p2p.layer." + std::to_string(3 * j + 1), d.out_p),
-                                           d.out_p, j == 0 ? d.prev_pc + d.prev_p : d.out_p, k, k));
-                if (train) n->p2p_d[i].push_back(dgrad_pack(n, m + "p2p.layer." + std::to_string(3 * j) + ".weight", d.out_p,
-                                                            j == 0 ? d.prev_pc + d.prev_p : d.out_p, k, k));
+                                           d.out_p, cin_j, k, k));
+                if (train) n->p2p_d[i].push_back(dgrad_pack(n, m + "p2p.layer." + std::to_string(3 * j) + ".weight", d.out_p, cin_j, k, k));
             }
         }
         semi[i] = fold_pack(n, m + "pool_semi", bn(m + "pool_semi_b", cs), cs, cs, 3, 3);
@@ -1548,6 +1549,13 @@ struct Fwd {
             }
             // models.py:378-384  repeat + concat (never materialised) + pitch convs
             Src sdesc{p_cur, cp, psix, d.prev_pc, 36};
+            if (c.pc2p_mem) {   // models.py:376-377: no concat, the summed up_sixth map is added to the pitch stream
+                const long long total = static_cast<long long>(B) * cp * P * Ti;
+                ake::ProfScope ps("pc2p_mem_kernel", s);
+                hipLaunchKernelGGL(pc2p_mem_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, p_cur, psix, b.pin[i], cp,
+                                   d.prev_pc / cp, P, Ti, total);
+                sdesc = Src{b.pin[i], cp, nullptr, 0, 0};
+            }
             const float* in_aff = train ? b.aff_p2pin[i] : nullptr;
             float* out = nullptr;
             float* out_aff = nullptr;
@@ -1834,7 +1842,7 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
     AKE_REQUIRE(!n->cfg.genre || d_genre, AKE_ERR_INVALID, "pcnet backward: genre head enabled but d_genre is null");
     AKE_REQUIRE(n->cfg.local == 0, AKE_ERR_UNSUPPORTED, "pcnet: training a --local net is not built");
-    AKE_REQUIRE(!n->cfg.resblock, AKE_ERR_UNSUPPORTED, "pcnet: training a --resblock net is not built");
+    AKE_REQUIRE(!(n->cfg.resblock || n->cfg.pc2p_mem), AKE_ERR_UNSUPPORTED, "pcnet: training a --resblock / --pc2p_mem net is not built");
     Buffers b;
     int rc = plan_buffers(n, batch, batch, frames, workspace, &b, true);
     if (rc) return rc;
@@ -1881,7 +1889,7 @@ int ake_pcnet_forward_train_f32(const ake_pcnet* n, const float* mel, int batch,
                                 float* key_out, float* tonic_out, float* genre_out, float* bn_stats_out, void* workspace,
                                 size_t ws_bytes, ake_stream_t stream) {
     AKE_REQUIRE(!n || n->cfg.local == 0, AKE_ERR_UNSUPPORTED, "pcnet: training a --local net (per-frame losses, models.py:861-876) is not built");
-    AKE_REQUIRE(!n || !n->cfg.resblock, AKE_ERR_UNSUPPORTED, "pcnet: training a --resblock net is not built (inference only)");
+    AKE_REQUIRE(!n || !(n->cfg.resblock || n->cfg.pc2p_mem), AKE_ERR_UNSUPPORTED, "pcnet: training a --resblock / --pc2p_mem net is not built (inference only)");
     return forward_impl(n, true, mel, batch, frames, seq_length, key_out, tonic_out, genre_out, bn_stats_out, workspace, ws_bytes, stream);
 }
 

@@ -1968,6 +1968,26 @@ __global__ __launch_bounds__(512) void layer0_mfma_kernel(Layer0Args a) {
     }
 }
 
+// --pc2p_mem (PitchClass2Pitch_MemoryVariant, models.py:145-166): the up_sixth map is summed over groups of its channels and ADDED to
+// the pitch stream instead of being concatenated to it.  The reference reshapes the P rows to (36, P / 36): row r takes
+// third-semitone index r / (P / 36) -- eight consecutive rows share one -- kept as it is.
+__global__ void pc2p_mem_kernel(const float* __restrict__ p, const float* __restrict__ psix, float* __restrict__ out, int cp, int ratio, int P, int T,
+                                long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;      // (clip, c, row, t)
+    if (i >= total) return;
+    const int t = static_cast<int>(i % T);
+    long long q = i / T;
+    const int r = static_cast<int>(q % P);
+    q /= P;
+    const int c = static_cast<int>(q % cp);
+    const long long clip = q / cp;
+    const int k = r / (P / 36);
+    const float* s = psix + (((clip * cp + c) * ratio) * 36 + k) * T + t;
+    float acc = p[i];
+    for (int g = 0; g < ratio; ++g) acc += s[static_cast<long long>(g) * 36 * T];
+    out[i] = acc;
+}
+
 // ==========================================================================================
 // Training-mode forward helpers (BatchNorm with batch statistics, nn.BatchNorm2d in train(), models.py:196 etc.)
 // ==========================================================================================

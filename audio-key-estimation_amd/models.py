@@ -22,7 +22,7 @@ from . import _lib
 from .lightning_shim import LightningModule
 from .metrics import mirex_score as _mirex_score
 
-_VARIANT_FLAGS = ("denseblock", "stay_sixth", "only_semitones", "p2pc_conv", "pc2p_mem")
+_VARIANT_FLAGS = ("denseblock", "stay_sixth", "only_semitones", "p2pc_conv")
 
 
 class EquivariantPitchClassConvolutionSimple(nn.Module):
@@ -93,7 +93,7 @@ class PitchClassNetLayer(nn.Module):
     """Parameter container for one layer (models.py:246-350); creation order matches the reference
     so that the same torch seed gives the same initial weights."""
 
-    def __init__(self, layer_num, nf, k, conv_layers, resblock=False):
+    def __init__(self, layer_num, nf, k, conv_layers, resblock=False, pc2p_mem=False):
         super().__init__()
         if layer_num == 0:
             self.pool_semi = nn.Conv2d(1, 1, 3, stride=(3, 1), padding=(0, 1), padding_mode="circular")
@@ -112,7 +112,8 @@ class PitchClassNetLayer(nn.Module):
         self.up_sixth = nn.ConvTranspose2d(prev_pc, prev_pc, kernel_size=(3, 1), stride=(3, 1))
         self.up_sixth_b = nn.BatchNorm2d(prev_pc)
         self.up_sixth_a = nn.LeakyReLU()
-        self.p2p = _p2p(prev_pc + prev_p, out_p, k, conv_layers, resblock)
+        # --pc2p_mem (models.py:145-166, 333): the up_sixth map is added to the pitch stream, not concatenated -> fewer input channels
+        self.p2p = _p2p(prev_p if pc2p_mem else prev_pc + prev_p, out_p, k, conv_layers, resblock)
         self.pool_semi = nn.Conv2d(out_p, out_p, (3, 3), stride=(3, 1), padding=(0, 1), padding_mode="circular")
         self.pool_semi_b = nn.BatchNorm2d(out_p)
         self.pool_semi_a = nn.LeakyReLU()
@@ -184,7 +185,8 @@ class PitchClassNet(LightningModule):
                 raise ValueError("--local: frames * loc_window_size must exceed head_layers * (kernel_size - 1)")
         # --resblock (models.py:181-187, 218-224, 402-454): the stacks are one conv + conv_layers residual blocks.  Inference only here.
         self.resblock = bool(_opt_get(opt, "resblock", False))
-        self.model = nn.Sequential(*[PitchClassNetLayer(i, nf, k, self.conv_layers, self.resblock) for i in range(num_layers)])
+        self.pc2p_mem = bool(_opt_get(opt, "pc2p_mem", False))
+        self.model = nn.Sequential(*[PitchClassNetLayer(i, nf, k, self.conv_layers, self.resblock, self.pc2p_mem) for i in range(num_layers)])
         final = nf if num_layers == 1 else self.model[num_layers - 1].out_pc          # models.py:694-710
         self.head_layers = _opt_get(opt, "head_layers", 2)
         self.genre = bool(_opt_get(opt, "genre", False))
@@ -231,6 +233,7 @@ class PitchClassNet(LightningModule):
         c.max_pool = 1 if _opt_get(self.opt, "max_pool", False) else 0
         c.local = self.local_window
         c.resblock = 1 if self.resblock else 0
+        c.pc2p_mem = 1 if self.pc2p_mem else 0
         return c
 
     def _layout(self):
@@ -403,8 +406,8 @@ class PitchClassNet(LightningModule):
         ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream().cuda_stream
-            if self.training and self.resblock:
-                raise NotImplementedError("training a --resblock net is not built on the HIP path (inference only)")
+            if self.training and (self.resblock or self.pc2p_mem):
+                raise NotImplementedError("training a --resblock / --pc2p_mem net is not built on the HIP path (inference only)")
             if self.training:
                 # BatchNorm with batch statistics; with autograd enabled the call becomes one autograd node whose backward
                 # runs the HIP backward kernels (gradients for every parameter), as loss.backward() does in the reference

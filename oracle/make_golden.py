@@ -289,6 +289,22 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "pcnet_resblock_T28.npz"), opt=json.dumps(vars(opt_r)), x=xr.numpy(), seq_length=seq_r.numpy(),
                         key=kr.numpy(), tonic=tr.numpy(), genre=gnr.numpy(), **sd_to_npz(sd_r))
 
+    # ---------------------------------------------------------------- G: --pc2p_mem, B=2, T=40
+    print("G: --pc2p_mem (PitchClass2Pitch_MemoryVariant: the up_sixth map is summed over its 4 channels and ADDED to the pitch stream), B=2, T=40")
+    opt_m = default_opt(pc2p_mem=True)
+    net_m, sd_m = build_reference_net(opt_m, seed=33)
+    net_m.eval()
+    gm = torch.Generator().manual_seed(987)
+    xm = (torch.rand((2, 1, 288, 40), generator=gm) * 2.5).float()
+    seq_m = torch.tensor([40, 31])
+    km, tm, gnm = net_m(xm.double(), seq_m)
+    okm, otm, ogm = pcnet_oracle.pcnet_forward(sd_m, xm.double(), seq_m)
+    report["checks"]["G_key"] = check("pc2p_mem key", okm, km, 1e-12)
+    report["checks"]["G_tonic"] = check("pc2p_mem tonic", otm, tm, 1e-12)
+    report["checks"]["G_genre"] = check("pc2p_mem genre", ogm, gnm, 1e-12)
+    np.savez_compressed(os.path.join(GOLD, "pcnet_pc2pmem_T40.npz"), opt=json.dumps(vars(opt_m)), x=xm.numpy(), seq_length=seq_m.numpy(),
+                        key=km.numpy(), tonic=tm.numpy(), genre=gnm.numpy(), **sd_to_npz(sd_m))
+
     with open(os.path.join(GOLD, "PROVENANCE.json"), "w") as f:
         json.dump(report, f, indent=1)
     print("wrote", sorted(os.listdir(GOLD)))

@@ -182,8 +182,20 @@ def semitone_pool(p, sd, prefix, training=False):
     return _lrelu(_bn(x, sd, prefix + "pool_semi_b.", training))
 
 
+def pitchclass2pitch_memory(p, p_sixth):
+    """PitchClass2Pitch_MemoryVariant.forward, models.py:145-166 (--pc2p_mem): instead of concatenating the repeated third-semitone
+    map, ADD it to the pitch stream -- after summing groups of its channels down to the stream's channel count.  The reference
+    reshapes the P pitch rows to (36, P / 36), so row r receives third-semitone index r // (P / 36) (eight CONSECUTIVE rows share
+    one), not r % 36 as the repeat of the default path does; kept as it is."""
+    B, C, P, T = p.shape
+    s = p_sixth.reshape(B, C, p_sixth.shape[1] // C, p_sixth.shape[2], T).sum(dim=2)          # (B, C, 36, T)
+    k = s.shape[2]
+    return (p.reshape(B, C, k, P // k, T) + s.reshape(B, C, k, 1, T)).reshape(B, C, P, T)
+
+
 def forward_features(sd, mel, time_pool_size=2, training=False, taps=None):
-    """nn.Sequential of PitchClassNetLayer.forward, models.py:352-399 (default flags)."""
+    """nn.Sequential of PitchClassNetLayer.forward, models.py:352-399 (default flags; --pc2p_mem when the first pitch conv of a
+    layer takes only the pitch stream's channels)."""
     num_layers = 0
     while f"model.{num_layers}.pool_semi.weight" in sd:
         num_layers += 1
@@ -202,8 +214,11 @@ def forward_features(sd, mel, time_pool_size=2, training=False, taps=None):
             p_sixth = _lrelu(_bn(p_sixth, sd, pre + "up_sixth_b.", training))     # :373-374
             if taps is not None:
                 taps[pre + "up_sixth_a"] = p_sixth
-            p2 = pitchclass2pitch(p_sixth, pitches)                 # :378
-            p = torch.cat([p, p2], dim=1)                           # :383
+            if sd[pre + "p2p.layer.0.weight"].shape[1] == p.shape[1]:       # --pc2p_mem: :376-377, no concat (:382)
+                p = pitchclass2pitch_memory(p, p_sixth)
+            else:
+                p2 = pitchclass2pitch(p_sixth, pitches)             # :378
+                p = torch.cat([p, p2], dim=1)                       # :383
             p = p2p_stack(p, sd, pre + "p2p.", training, taps)      # :384
             pc2 = pitch2pitchclass_pool(semitone_pool(p, sd, pre, training))  # :386-389
             if taps is not None:

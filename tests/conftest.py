@@ -56,6 +56,11 @@ def gold_resblock():
 
 
 @pytest.fixture(scope="session")
+def gold_pc2pmem():
+    return load_golden("pcnet_pc2pmem_T40.npz")
+
+
+@pytest.fixture(scope="session")
 def gold_mirex():
     return load_golden("mirex_loss_cases.npz")
 

@@ -274,6 +274,27 @@ def test_resblock_against_reference_fixture(gold_resblock):
         net.eval()(x, seq); net.tap("model.1.p2p.layer.5")
 
 
+def test_pc2p_mem_against_reference_fixture(gold_pc2pmem):
+    """--pc2p_mem (models.py:145-166), inference: the reference's own outputs for its own seeded weights (small batch: per-tile kernels),
+    then the BASELINE shape with a batch large enough for the persistent kernels (B = 20, T = 76) against the oracle."""
+    net, opt = make_net(gold_pc2pmem)
+    assert net.pc2p_mem
+    x = torch.from_numpy(gold_pc2pmem["x"]).to(DEV)
+    seq = torch.from_numpy(gold_pc2pmem["seq_length"]).to(DEV)
+    for got, name in zip(net(x, seq), ("key", "tonic", "genre")):
+        assert rel_err(got.cpu(), gold_pc2pmem[name]) < TOL, name
+    g = torch.Generator().manual_seed(18)
+    x2 = torch.rand((20, 1, 288, 76), generator=g) * 2.5
+    seq2 = torch.randint(30, 77, (20,), generator=g)
+    got = net(x2.to(DEV), seq2.to(DEV))
+    idx = [0, 7, 19]
+    ref = pcnet_oracle.pcnet_forward(golden_state_dict(gold_pc2pmem, torch.float64), x2[idx].double(), seq2[idx])
+    for a, b in zip(got, ref):
+        assert rel_err(a[idx].cpu(), b) < TOL
+    with pytest.raises(NotImplementedError):
+        net.train()(x, seq)
+
+
 def test_edge_shapes(gold_default):
     net, _ = make_net(gold_default)
     sd = golden_state_dict(gold_default, torch.float64)

@@ -109,6 +109,21 @@ def test_resblock_against_reference_fixture(gold_resblock):
     assert np.abs(g.numpy() - gold_resblock["genre"]).max() <= 1e-12
 
 
+def test_pc2p_mem_against_reference_fixture(gold_pc2pmem):
+    """--pc2p_mem (models.py:145-166, 333, 376-377): the up_sixth map is summed over its channels and added to the pitch stream (row r
+    takes third-semitone index r // 8 -- the reference's reshape), the first pitch conv has prev_p input channels."""
+    sd = golden_state_dict(gold_pc2pmem, torch.float64)
+    assert sd["model.1.p2p.layer.0.weight"].shape == (8, 1, 7, 7)
+    k, t, g = pcnet_oracle.pcnet_forward(sd, torch.from_numpy(gold_pc2pmem["x"]).double(), torch.from_numpy(gold_pc2pmem["seq_length"]))
+    assert np.abs(k.numpy() - gold_pc2pmem["key"]).max() <= 1e-12
+    assert np.abs(t.numpy() - gold_pc2pmem["tonic"]).max() <= 1e-12
+    assert np.abs(g.numpy() - gold_pc2pmem["genre"]).max() <= 1e-12
+    p = torch.arange(2 * 288 * 3, dtype=torch.float64).reshape(1, 2, 288, 3)
+    ps = torch.ones(1, 4, 36, 3, dtype=torch.float64) * torch.arange(36, dtype=torch.float64).reshape(1, 1, 36, 1)
+    out = pcnet_oracle.pitchclass2pitch_memory(p, ps)
+    assert float((out - p)[0, 0, 17, 0]) == 2 * (17 // 8) and float((out - p)[0, 1, 287, 2]) == 2 * 35      # groups of 2 channels, row // 8
+
+
 def test_max_pool_quirk(gold_default):
     """--max_pool with seq_length: only sample 0 takes the max (models.py:764-785)."""
     sd = golden_state_dict(gold_default, torch.float64)
