@@ -75,6 +75,7 @@ struct ake_pcnet {
     // packed parameters
     std::vector<float> blob;
     float* blob_dev = nullptr;
+    std::vector<PackedConv> foldc, foldc_t;       // per layer: --p2pc_conv's octave-fold convolution [co][ci][n_oct]
     std::vector<PackedConv> semi;                 // per layer
     std::vector<std::vector<PackedConv>> pc2pc;   // per layer, conv_layers entries
     std::vector<PackedConv> up;                   // per layer (index 0 unused)
@@ -459,7 +460,7 @@ int p2p_ps_rows(int H, int T, bool semi, int* plane_pos, size_t* lds) {
 // Only in the net's last layer: an inner layer's pitch tensor is also the next layer's pitch stream (time_pool_p, models.py:395).
 bool p2p_fuses_semi(const ake_pcnet* n, int i, int P, int T) {
     static const bool off = std::getenv("AKE_P2P_PS") != nullptr && std::atoi(std::getenv("AKE_P2P_PS")) == 0;
-    return !off && !g_keep_taps && i == n->cfg.num_layers - 1 && p2p_uses_bf16(n, i, T) && static_cast<size_t>(i) < n->semi.size() && n->semi[i].bf_off >= 0 &&
+    return !off && !g_keep_taps && !n->cfg.p2pc_conv && i == n->cfg.num_layers - 1 && p2p_uses_bf16(n, i, T) && static_cast<size_t>(i) < n->semi.size() && n->semi[i].bf_off >= 0 &&
            p2p_ps_rows(P, T, true, nullptr, nullptr) > 0;
 }
 
@@ -634,6 +635,7 @@ int run_semi(const ake_pcnet* n, const PackedConv& pc, const float* src, int bat
 struct Buffers {           // workspace carve
     // per chunk (pitch stream): everything up to the last layer's semitone fold
     float* fold0 = nullptr;
+    float* smap = nullptr;     // --p2pc_conv only
     std::vector<float*> cat, psix, pa, pb, pca, pcb, ppool, pin;
     // whole batch (pitch-class tail): last layer's concat buffer, its pc stack, pooled features, heads
     float *pcf = nullptr, *hid_k = nullptr, *hid_t = nullptr, *hid_g = nullptr;
@@ -672,6 +674,11 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
     b->pca.assign(L, nullptr); b->pcb.assign(L, nullptr); b->ppool.assign(L, nullptr); b->pin.assign(L, nullptr);
     const size_t C = chunk, B = batch;
     b->fold0 = cv.take<float>(B * 12 * frames);
+    if (c.p2pc_conv) {   // --p2pc_conv: raw semitone maps between the semitone conv and the octave-fold conv (largest layer)
+        size_t m = B * (P / 3) * frames;
+        for (int i = 1; i < L; ++i) m = std::max(m, C * n->dims[i].out_p * (P / 3) * b->Tl[i]);
+        b->smap = cv.take<float>(m);
+    }
     for (int i = 0; i < L; ++i) {
         const int Ti = b->Tl[i];
         const auto& d = n->dims[i];
@@ -762,9 +769,9 @@ int ake_pcnet_default_config(ake_pcnet_config* cfg, int octaves, int genre) {
 int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
     AKE_REQUIRE(cfg && out, AKE_ERR_INVALID, "ake_pcnet_create: null argument");
     const ake_pcnet_config& c = *cfg;
-    AKE_REQUIRE(!(c.denseblock || c.stay_sixth || c.only_semitones || c.p2pc_conv),
+    AKE_REQUIRE(!(c.denseblock || c.stay_sixth || c.only_semitones),
                 AKE_ERR_UNSUPPORTED,
-                "pcnet: denseblock/stay_sixth/only_semitones/p2pc_conv variants are not built");
+                "pcnet: denseblock/stay_sixth/only_semitones variants are not built");
     AKE_REQUIRE(c.local >= 0, AKE_ERR_INVALID, "pcnet: local = pooling window of the --local heads (0: off)");
     AKE_REQUIRE(c.pitch_classes == 12, AKE_ERR_UNSUPPORTED, "pcnet: pitch_classes must be 12");
     AKE_REQUIRE(c.pitches > 0 && c.pitches % 36 == 0, AKE_ERR_INVALID, "pcnet: pitches must be a multiple of 36");
@@ -795,6 +802,10 @@ int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
         const int cs = i == 0 ? 1 : d.out_p;
         add_conv_specs(n, m + "pool_semi", cs, cs, 3, 3);                     // models.py:313 / :337
         add_bn_specs(n, m + "pool_semi_b", cs);
+        if (c.p2pc_conv) {                                                    // models.py:118-119: Pitch2PitchClassConv
+            add_conv_specs(n, m + "pool.conv", cs, cs, c.pitches / 36, 1);
+            add_bn_specs(n, m + "pool.bn", cs);
+        }
         const int pc_in = i == 0 ? 1 : d.out_p + d.prev_pc, pc_out = i == 0 ? nf : d.out_pc;
         if (c.resblock) {                                                     // models.py:181-187: conv + BN, then conv_layers ResBlockEquivariant
             add_conv_specs(n, m + "pc2pc.layer.0.conv2d", pc_out, pc_in, 12, k);
@@ -913,6 +924,7 @@ static void build_packs(ake_pcnet* n, bool train) {
     auto& pc2pc = train ? n->pc2pc_t : n->pc2pc;
     auto& p2p = train ? n->p2p_t : n->p2p;
     semi.assign(L, PackedConv()); up.assign(L, PackedConv());
+    (train ? n->foldc_t : n->foldc).assign(L, PackedConv());
     pc2pc.assign(L, {}); p2p.assign(L, {});
     if (train) { n->pc2pc_d.assign(L, {}); n->p2p_d.assign(L, {}); n->head_key_d.clear(); n->head_tonic_d.clear(); n->head_genre_d.clear(); }
     auto bn = [&](const std::string& prefix, int C) -> std::string {
@@ -962,6 +974,19 @@ static void build_packs(ake_pcnet* n, bool train) {
             }
         }
         semi[i] = fold_pack(n, m + "pool_semi", bn(m + "pool_semi_b", cs), cs, cs, 3, 3);
+        if (c.p2pc_conv) {   // [co][ci][n_oct], BatchNorm folded (eval); plain layout as up_sixth's
+            std::vector<double> w, bb;
+            fold(n, m + "pool.conv.weight", m + "pool.conv.bias", bn(m + "pool.bn", cs), cs, static_cast<size_t>(cs) * (c.pitches / 36), false, cs, w, bb);
+            PackedConv u;
+            u.cin = u.cout = cs; u.kh = c.pitches / 36; u.kw = 1;
+            n->blob.resize(ake::align_up(n->blob.size(), 64));
+            u.w_off = n->blob.size();
+            for (double v : w) n->blob.push_back(static_cast<float>(v));
+            n->blob.resize(ake::align_up(n->blob.size(), 64));
+            u.b_off = n->blob.size();
+            for (double v : bb) n->blob.push_back(static_cast<float>(v));
+            (train ? n->foldc_t : n->foldc)[i] = u;
+        }
         const int pc_in = i == 0 ? 1 : d.out_p + d.prev_pc, pc_out = i == 0 ? c.n_filters : d.out_pc;
         if (c.resblock) {
             pc2pc[i].push_back(fold_pack(n, m + "pc2pc.layer.0.conv2d", bn(m + "pc2pc.layer.1", pc_out), pc_out, pc_in, 12, k));
@@ -1375,6 +1400,34 @@ struct Fwd {
     // pool_semi (+BN+LReLU) + octave fold of `src` [B][C][P][T] into channels [coff, coff+C) of dst [B][ctot][12][T]
     int semi(int layer, const float* src, const float* in_aff, int B, int P, int Tn, float* dst, int ctot, int coff, float* aff_cat_rows) {
         const char* nm = layer == 0 ? "semi_fold_kernel/L0" : "semi_fold_kernel/L1+";
+        if (!train && n->cfg.p2pc_conv) {   // semitone conv (raw, BatchNorm folded) -> octave-fold convolution (LeakyReLU applied on load)
+            const PackedConv& pc = n->semi[layer];
+            SemiTrainArgs ta;
+            std::memset(&ta, 0, sizeof(ta));
+            SemiArgs& a = ta.s;
+            a.src = src; a.C = pc.cin; a.H = P; a.T = Tn;
+            a.src_clip_stride = static_cast<long long>(pc.cin) * P * Tn;
+            a.w = n->blob_dev + pc.w_off; a.bias = n->blob_dev + pc.b_off;
+            a.dst = b.smap; a.n_strips = (Tn + TW - 1) / TW;
+            const int per_clip = (P / 3) * a.n_strips;
+            const int threads = per_clip >= 256 ? 256 : (per_clip + 63) / 64 * 64;
+            dim3 grid((per_clip + threads - 1) / threads, pc.groups, B), block(threads);
+            {
+                ake::ProfScope ps("semi_conv_stats_kernel", s);
+                switch (pc.co) {
+                    case 8: hipLaunchKernelGGL((semi_conv_stats_kernel<8>), grid, block, 0, s, ta); break;
+                    case 4: hipLaunchKernelGGL((semi_conv_stats_kernel<4>), grid, block, 0, s, ta); break;
+                    case 1: hipLaunchKernelGGL((semi_conv_stats_kernel<1>), grid, block, 0, s, ta); break;
+                    default: ake::set_error("semi: bad CO"); return AKE_ERR_UNSUPPORTED;
+                }
+            }
+            const PackedConv& fc = n->foldc[layer];
+            const long long total = static_cast<long long>(B) * pc.cin * 12 * Tn;
+            ake::ProfScope ps("fold_conv_kernel", s);
+            hipLaunchKernelGGL(fold_conv_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.smap, n->blob_dev + fc.w_off,
+                               n->blob_dev + fc.b_off, dst, pc.cin, P / 36, Tn, 1, static_cast<long long>(ctot) * 12 * Tn, coff, total);
+            return AKE_OK;
+        }
         if (!train) return run_semi(n, n->semi[layer], src, B, P, Tn, dst, ctot, coff, s, nm);
         const PackedConv& pc = n->semi_t[layer];
         const int bn = bn_of("model." + std::to_string(layer) + ".pool_semi_b");
@@ -1444,7 +1497,7 @@ struct Fwd {
         static const bool off = std::getenv("AKE_L0_FUSED") != nullptr && std::atoi(std::getenv("AKE_L0_FUSED")) == 0;
         const auto& c = n->cfg;
         const int P = c.pitches, T0 = b.Tl[0], NF = c.n_filters;
-        if (off || c.resblock || NF < 2 || NF > 4 || c.conv_layers < 1 || c.conv_layers > 4 || c.kernel_size != 7 || P % 36 || T0 < 1) return false;
+        if (off || c.resblock || c.p2pc_conv || NF < 2 || NF > 4 || c.conv_layers < 1 || c.conv_layers > 4 || c.kernel_size != 7 || P % 36 || T0 < 1) return false;
         const PackedConv& sp = n->semi[0];
         if (sp.cin != 1 || sp.co != 1) return false;
         for (int j = 0; j < c.conv_layers; ++j) {
@@ -1842,7 +1895,7 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
     AKE_REQUIRE(!n->cfg.genre || d_genre, AKE_ERR_INVALID, "pcnet backward: genre head enabled but d_genre is null");
     AKE_REQUIRE(n->cfg.local == 0, AKE_ERR_UNSUPPORTED, "pcnet: training a --local net is not built");
-    AKE_REQUIRE(!(n->cfg.resblock || n->cfg.pc2p_mem), AKE_ERR_UNSUPPORTED, "pcnet: training a --resblock / --pc2p_mem net is not built");
+    AKE_REQUIRE(!(n->cfg.resblock || n->cfg.pc2p_mem || n->cfg.p2pc_conv), AKE_ERR_UNSUPPORTED, "pcnet: training a --resblock / --pc2p_mem / --p2pc_conv net is not built");
     Buffers b;
     int rc = plan_buffers(n, batch, batch, frames, workspace, &b, true);
     if (rc) return rc;
@@ -1889,7 +1942,8 @@ int ake_pcnet_forward_train_f32(const ake_pcnet* n, const float* mel, int batch,
                                 float* key_out, float* tonic_out, float* genre_out, float* bn_stats_out, void* workspace,
                                 size_t ws_bytes, ake_stream_t stream) {
     AKE_REQUIRE(!n || n->cfg.local == 0, AKE_ERR_UNSUPPORTED, "pcnet: training a --local net (per-frame losses, models.py:861-876) is not built");
-    AKE_REQUIRE(!n || !(n->cfg.resblock || n->cfg.pc2p_mem), AKE_ERR_UNSUPPORTED, "pcnet: training a --resblock / --pc2p_mem net is not built (inference only)");
+    AKE_REQUIRE(!n || !(n->cfg.resblock || n->cfg.pc2p_mem || n->cfg.p2pc_conv), AKE_ERR_UNSUPPORTED,
+                "pcnet: training a --resblock / --pc2p_mem / --p2pc_conv net is not built (inference only)");
     return forward_impl(n, true, mel, batch, frames, seq_length, key_out, tonic_out, genre_out, bn_stats_out, workspace, ws_bytes, stream);
 }
 

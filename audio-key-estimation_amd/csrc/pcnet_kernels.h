@@ -1988,6 +1988,30 @@ __global__ void pc2p_mem_kernel(const float* __restrict__ p, const float* __rest
     out[i] = acc;
 }
 
+// --p2pc_conv (Pitch2PitchClassConv, models.py:108-133): the octave fold as a learned convolution over the octaves and channels
+// (kernel (n_oct, 1), dilation (12, 1)) + BN (folded) + LeakyReLU, instead of the max.  src: semitone maps [clip][C][12 * n_oct][T],
+// either final activations or the raw pre-activation conv output (in_lrelu = 1 applies the LeakyReLU while loading);
+// w: [co][ci][n_oct], dst: channels [coff, coff + C) of [clip][ctot][12][T].
+__global__ void fold_conv_kernel(const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ dst,
+                                 int C, int n_oct, int T, int in_lrelu, long long dst_clip_stride, int dst_coff, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;      // (clip, co, p, t)
+    if (i >= total) return;
+    const int t = static_cast<int>(i % T);
+    long long r = i / T;
+    const int p = static_cast<int>(r % 12); r /= 12;
+    const int co = static_cast<int>(r % C);
+    const long long clip = r / C;
+    const float* s = src + (clip * C * 12 * n_oct + p) * T + t;
+    float acc = bias[co];
+    for (int ci = 0; ci < C; ++ci)
+        for (int o = 0; o < n_oct; ++o) {
+            float x = s[(static_cast<long long>(ci) * 12 * n_oct + 12 * o) * T];
+            if (in_lrelu) x = x > 0.f ? x : x * kSlope;
+            acc = fmaf(x, w[(co * C + ci) * n_oct + o], acc);
+        }
+    dst[clip * dst_clip_stride + (static_cast<long long>(dst_coff + co) * 12 + p) * T + t] = acc > 0.f ? acc : acc * kSlope;
+}
+
 // ==========================================================================================
 // Training-mode forward helpers (BatchNorm with batch statistics, nn.BatchNorm2d in train(), models.py:196 etc.)
 // ==========================================================================================
@@ -2075,7 +2099,7 @@ __global__ void semi_conv_stats_kernel(SemiTrainArgs ta) {
             const float v = acc[co][j] + b;
             if (okc && live && t0 + j < a.T) { drow[t0 + j] = v; s1 += v; s2 = fmaf(v, v, s2); }
         }
-        if (okc) stats_commit(ta.stats, ta.stats_stride, c, s1, s2);
+        if (okc && ta.stats) stats_commit(ta.stats, ta.stats_stride, c, s1, s2);      // (null: inference use by --p2pc_conv, no statistics)
     }
 }
 

@@ -22,7 +22,7 @@ from . import _lib
 from .lightning_shim import LightningModule
 from .metrics import mirex_score as _mirex_score
 
-_VARIANT_FLAGS = ("denseblock", "stay_sixth", "only_semitones", "p2pc_conv")
+_VARIANT_FLAGS = ("denseblock", "stay_sixth", "only_semitones")
 
 
 class EquivariantPitchClassConvolutionSimple(nn.Module):
@@ -89,16 +89,29 @@ def _p2p(cin, cout, k, n, resblock=False):
     return _ConvStack(blocks)
 
 
+class Pitch2PitchClassConv(nn.Module):
+    """Parameter container for models.py:108-121 (--p2pc_conv): the octave fold as Conv2d(C, C, (n_oct, 1), dilation (12, 1)) + BN + act."""
+
+    def __init__(self, pitches_in, in_channels):
+        super().__init__()
+        k = -(-pitches_in // 12)
+        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=(k, 1), dilation=(12, 1))
+        self.bn = nn.BatchNorm2d(in_channels)
+        self.act = nn.LeakyReLU()
+
+
 class PitchClassNetLayer(nn.Module):
     """Parameter container for one layer (models.py:246-350); creation order matches the reference
     so that the same torch seed gives the same initial weights."""
 
-    def __init__(self, layer_num, nf, k, conv_layers, resblock=False, pc2p_mem=False):
+    def __init__(self, layer_num, nf, k, conv_layers, resblock=False, pc2p_mem=False, p2pc_conv=False, pitches=288):
         super().__init__()
         if layer_num == 0:
             self.pool_semi = nn.Conv2d(1, 1, 3, stride=(3, 1), padding=(0, 1), padding_mode="circular")
             self.pool_semi_b = nn.BatchNorm2d(1)
             self.pool_semi_a = nn.LeakyReLU()
+            if p2pc_conv:
+                self.pool = Pitch2PitchClassConv(pitches // 3, 1)                # models.py:316-317
             self.pc2pc = _pc2pc(1, nf, k, conv_layers, resblock)
             return
         if layer_num == 1:
@@ -117,6 +130,8 @@ class PitchClassNetLayer(nn.Module):
         self.pool_semi = nn.Conv2d(out_p, out_p, (3, 3), stride=(3, 1), padding=(0, 1), padding_mode="circular")
         self.pool_semi_b = nn.BatchNorm2d(out_p)
         self.pool_semi_a = nn.LeakyReLU()
+        if p2pc_conv:
+            self.pool = Pitch2PitchClassConv(pitches // 3, out_p)                # models.py:340-341
         self.pc2pc = _pc2pc(out_p + prev_pc, out_pc, k, conv_layers, resblock)
         self.out_pc = out_pc
 
@@ -186,7 +201,9 @@ class PitchClassNet(LightningModule):
         # --resblock (models.py:181-187, 218-224, 402-454): the stacks are one conv + conv_layers residual blocks.  Inference only here.
         self.resblock = bool(_opt_get(opt, "resblock", False))
         self.pc2p_mem = bool(_opt_get(opt, "pc2p_mem", False))
-        self.model = nn.Sequential(*[PitchClassNetLayer(i, nf, k, self.conv_layers, self.resblock, self.pc2p_mem) for i in range(num_layers)])
+        self.p2pc_conv = bool(_opt_get(opt, "p2pc_conv", False))
+        self.model = nn.Sequential(*[PitchClassNetLayer(i, nf, k, self.conv_layers, self.resblock, self.pc2p_mem, self.p2pc_conv, pitches)
+                                     for i in range(num_layers)])
         final = nf if num_layers == 1 else self.model[num_layers - 1].out_pc          # models.py:694-710
         self.head_layers = _opt_get(opt, "head_layers", 2)
         self.genre = bool(_opt_get(opt, "genre", False))
@@ -234,6 +251,7 @@ class PitchClassNet(LightningModule):
         c.local = self.local_window
         c.resblock = 1 if self.resblock else 0
         c.pc2p_mem = 1 if self.pc2p_mem else 0
+        c.p2pc_conv = 1 if self.p2pc_conv else 0
         return c
 
     def _layout(self):
@@ -406,8 +424,8 @@ class PitchClassNet(LightningModule):
         ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream().cuda_stream
-            if self.training and (self.resblock or self.pc2p_mem):
-                raise NotImplementedError("training a --resblock / --pc2p_mem net is not built on the HIP path (inference only)")
+            if self.training and (self.resblock or self.pc2p_mem or self.p2pc_conv):
+                raise NotImplementedError("training a --resblock / --pc2p_mem / --p2pc_conv net is not built on the HIP path (inference only)")
             if self.training:
                 # BatchNorm with batch statistics; with autograd enabled the call becomes one autograd node whose backward
                 # runs the HIP backward kernels (gradients for every parameter), as loss.backward() does in the reference

@@ -305,6 +305,22 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "pcnet_pc2pmem_T40.npz"), opt=json.dumps(vars(opt_m)), x=xm.numpy(), seq_length=seq_m.numpy(),
                         key=km.numpy(), tonic=tm.numpy(), genre=gnm.numpy(), **sd_to_npz(sd_m))
 
+    # ---------------------------------------------------------------- H: --p2pc_conv, B=2, T=40
+    print("H: --p2pc_conv (Pitch2PitchClassConv: the octave fold as a dilated conv + BN + LeakyReLU), B=2, T=40")
+    opt_c = default_opt(p2pc_conv=True)
+    net_c, sd_c = build_reference_net(opt_c, seed=44)
+    net_c.eval()
+    gc = torch.Generator().manual_seed(246)
+    xc = (torch.rand((2, 1, 288, 40), generator=gc) * 2.5).float()
+    seq_c = torch.tensor([40, 33])
+    kc, tc, gnc = net_c(xc.double(), seq_c)
+    okc, otc, ogc = pcnet_oracle.pcnet_forward(sd_c, xc.double(), seq_c)
+    report["checks"]["H_key"] = check("p2pc_conv key", okc, kc, 1e-12)
+    report["checks"]["H_tonic"] = check("p2pc_conv tonic", otc, tc, 1e-12)
+    report["checks"]["H_genre"] = check("p2pc_conv genre", ogc, gnc, 1e-12)
+    np.savez_compressed(os.path.join(GOLD, "pcnet_p2pcconv_T40.npz"), opt=json.dumps(vars(opt_c)), x=xc.numpy(), seq_length=seq_c.numpy(),
+                        key=kc.numpy(), tonic=tc.numpy(), genre=gnc.numpy(), **sd_to_npz(sd_c))
+
     with open(os.path.join(GOLD, "PROVENANCE.json"), "w") as f:
         json.dump(report, f, indent=1)
     print("wrote", sorted(os.listdir(GOLD)))

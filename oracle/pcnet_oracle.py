@@ -103,6 +103,17 @@ def pitch2pitchclass_pool(x, pitch_classes: int = 12):
     return F.max_pool2d(x, (ks, 1), (1, 1), dilation=(pitch_classes, 1))
 
 
+def pitch2pitchclass_conv(x, sd, prefix, training=False):
+    """Pitch2PitchClassConv.forward, models.py:108-133 (--p2pc_conv): the octave fold as a learned convolution -- kernel
+    (ceil(pitches_in / 12), 1) with dilation (12, 1) over the channels, then BatchNorm + LeakyReLU -- instead of the max."""
+    w = sd[prefix + "conv.weight"]
+    pad = w.shape[2] * 12 - x.shape[2]                       # rows of padding_value appended (:130-131); 0 for whole octaves
+    if pad:
+        x = torch.cat([x, torch.full((x.shape[0], x.shape[1], pad, x.shape[3]), float("-inf"), dtype=x.dtype)], dim=2)
+    y = F.conv2d(x, w, sd[prefix + "conv.bias"], dilation=(12, 1))
+    return _lrelu(_bn(y, sd, prefix + "bn.", training))
+
+
 def pitchclass2pitch(x, target_rows: int):
     """PitchClass2Pitch.forward, models.py:140-143: tile rows, crop."""
     reps = math.ceil(target_rows / x.shape[2])
@@ -205,7 +216,8 @@ def forward_features(sd, mel, time_pool_size=2, training=False, taps=None):
         pre = f"model.{i}."
         if i == 0:
             p_semi = semitone_pool(p, sd, pre, training)            # :361-363
-            pc = pitch2pitchclass_pool(p_semi)                      # :368 (p stays raw, :366-367)
+            pc = (pitch2pitchclass_conv(p_semi, sd, pre + "pool.", training) if pre + "pool.conv.weight" in sd
+                  else pitch2pitchclass_pool(p_semi))               # :368 (p stays raw, :366-367)
             if taps is not None:
                 taps[pre + "pool"] = pc
             pc = pc2pc_stack(pc, sd, pre + "pc2pc.", training, taps)  # :369
@@ -220,7 +232,9 @@ def forward_features(sd, mel, time_pool_size=2, training=False, taps=None):
                 p2 = pitchclass2pitch(p_sixth, pitches)             # :378
                 p = torch.cat([p, p2], dim=1)                       # :383
             p = p2p_stack(p, sd, pre + "p2p.", training, taps)      # :384
-            pc2 = pitch2pitchclass_pool(semitone_pool(p, sd, pre, training))  # :386-389
+            pc2 = semitone_pool(p, sd, pre, training)               # :386-388
+            pc2 = (pitch2pitchclass_conv(pc2, sd, pre + "pool.", training) if pre + "pool.conv.weight" in sd
+                   else pitch2pitchclass_pool(pc2))                 # :389
             if taps is not None:
                 taps[pre + "pool"] = pc2
             pc = torch.cat([pc, pc2], dim=1)                        # :392

@@ -61,6 +61,11 @@ def gold_pc2pmem():
 
 
 @pytest.fixture(scope="session")
+def gold_p2pcconv():
+    return load_golden("pcnet_p2pcconv_T40.npz")
+
+
+@pytest.fixture(scope="session")
 def gold_mirex():
     return load_golden("mirex_loss_cases.npz")
 

@@ -295,6 +295,25 @@ def test_pc2p_mem_against_reference_fixture(gold_pc2pmem):
         net.train()(x, seq)
 
 
+def test_p2pc_conv_against_reference_fixture(gold_p2pcconv):
+    """--p2pc_conv (models.py:108-133), inference: the reference's own outputs for its own seeded weights, and a second shape
+    (B = 5, T = 76) against the oracle."""
+    net, opt = make_net(gold_p2pcconv)
+    assert net.p2pc_conv
+    x = torch.from_numpy(gold_p2pcconv["x"]).to(DEV)
+    seq = torch.from_numpy(gold_p2pcconv["seq_length"]).to(DEV)
+    for got, name in zip(net(x, seq), ("key", "tonic", "genre")):
+        assert rel_err(got.cpu(), gold_p2pcconv[name]) < TOL, name
+    g = torch.Generator().manual_seed(28)
+    x2 = torch.rand((5, 1, 288, 76), generator=g) * 2.5
+    seq2 = torch.randint(30, 77, (5,), generator=g)
+    ref = pcnet_oracle.pcnet_forward(golden_state_dict(gold_p2pcconv, torch.float64), x2.double(), seq2)
+    for a, b in zip(net(x2.to(DEV), seq2.to(DEV)), ref):
+        assert rel_err(a.cpu(), b) < TOL
+    with pytest.raises(NotImplementedError):
+        net.train()(x, seq)
+
+
 def test_edge_shapes(gold_default):
     net, _ = make_net(gold_default)
     sd = golden_state_dict(gold_default, torch.float64)

@@ -124,6 +124,16 @@ def test_pc2p_mem_against_reference_fixture(gold_pc2pmem):
     assert float((out - p)[0, 0, 17, 0]) == 2 * (17 // 8) and float((out - p)[0, 1, 287, 2]) == 2 * 35      # groups of 2 channels, row // 8
 
 
+def test_p2pc_conv_against_reference_fixture(gold_p2pcconv):
+    """--p2pc_conv (models.py:108-133, 316-317, 340-341): the octave fold as a dilated convolution + BN + LeakyReLU."""
+    sd = golden_state_dict(gold_p2pcconv, torch.float64)
+    assert sd["model.1.pool.conv.weight"].shape == (8, 8, 8, 1)
+    k, t, g = pcnet_oracle.pcnet_forward(sd, torch.from_numpy(gold_p2pcconv["x"]).double(), torch.from_numpy(gold_p2pcconv["seq_length"]))
+    assert np.abs(k.numpy() - gold_p2pcconv["key"]).max() <= 1e-12
+    assert np.abs(t.numpy() - gold_p2pcconv["tonic"]).max() <= 1e-12
+    assert np.abs(g.numpy() - gold_p2pcconv["genre"]).max() <= 1e-12
+
+
 def test_max_pool_quirk(gold_default):
     """--max_pool with seq_length: only sample 0 takes the max (models.py:764-785)."""
     sd = golden_state_dict(gold_default, torch.float64)
