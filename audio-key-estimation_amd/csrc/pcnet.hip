@@ -460,7 +460,7 @@ int p2p_ps_rows(int H, int T, bool semi, int* plane_pos, size_t* lds) {
 // Only in the net's last layer: an inner layer's pitch tensor is also the next layer's pitch stream (time_pool_p, models.py:395).
 bool p2p_fuses_semi(const ake_pcnet* n, int i, int P, int T) {
     static const bool off = std::getenv("AKE_P2P_PS") != nullptr && std::atoi(std::getenv("AKE_P2P_PS")) == 0;
-    return !off && !g_keep_taps && !n->cfg.p2pc_conv && i == n->cfg.num_layers - 1 && p2p_uses_bf16(n, i, T) && static_cast<size_t>(i) < n->semi.size() && n->semi[i].bf_off >= 0 &&
+    return !off && !g_keep_taps && !n->cfg.p2pc_conv && !n->cfg.stay_sixth && i == n->cfg.num_layers - 1 && p2p_uses_bf16(n, i, T) && static_cast<size_t>(i) < n->semi.size() && n->semi[i].bf_off >= 0 &&
            p2p_ps_rows(P, T, true, nullptr, nullptr) > 0;
 }
 
@@ -636,6 +636,8 @@ struct Buffers {           // workspace carve
     // per chunk (pitch stream): everything up to the last layer's semitone fold
     float* fold0 = nullptr;
     float* smap = nullptr;     // --p2pc_conv only
+    float* p0 = nullptr;       // --stay_sixth only
+    std::vector<float*> pcd;   // --stay_sixth only
     std::vector<float*> cat, psix, pa, pb, pca, pcb, ppool, pin;
     // whole batch (pitch-class tail): last layer's concat buffer, its pc stack, pooled features, heads
     float *pcf = nullptr, *hid_k = nullptr, *hid_t = nullptr, *hid_g = nullptr;
@@ -674,6 +676,11 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
     b->pca.assign(L, nullptr); b->pcb.assign(L, nullptr); b->ppool.assign(L, nullptr); b->pin.assign(L, nullptr);
     const size_t C = chunk, B = batch;
     b->fold0 = cv.take<float>(B * 12 * frames);
+    if (c.stay_sixth) {  // --stay_sixth: layer 0's activated semitone map is the pitch stream; dense copies of the pitch-class stream for the repeat
+        b->p0 = cv.take<float>(B * (P / 3) * frames);
+        b->pcd.assign(L, nullptr);
+        for (int i = 1; i < L; ++i) b->pcd[i] = cv.take<float>(C * n->dims[i].prev_pc * 12 * b->Tl[i]);
+    }
     if (c.p2pc_conv) {   // --p2pc_conv: raw semitone maps between the semitone conv and the octave-fold conv (largest layer)
         size_t m = B * (P / 3) * frames;
         for (int i = 1; i < L; ++i) m = std::max(m, C * n->dims[i].out_p * (P / 3) * b->Tl[i]);
@@ -769,9 +776,8 @@ int ake_pcnet_default_config(ake_pcnet_config* cfg, int octaves, int genre) {
 int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
     AKE_REQUIRE(cfg && out, AKE_ERR_INVALID, "ake_pcnet_create: null argument");
     const ake_pcnet_config& c = *cfg;
-    AKE_REQUIRE(!(c.denseblock || c.stay_sixth || c.only_semitones),
-                AKE_ERR_UNSUPPORTED,
-                "pcnet: denseblock/stay_sixth/only_semitones variants are not built");
+    AKE_REQUIRE(!(c.denseblock || c.only_semitones), AKE_ERR_UNSUPPORTED, "pcnet: denseblock/only_semitones variants are not built");
+    AKE_REQUIRE(!(c.stay_sixth && c.pc2p_mem), AKE_ERR_UNSUPPORTED, "pcnet: stay_sixth together with pc2p_mem is not built");
     AKE_REQUIRE(c.local >= 0, AKE_ERR_INVALID, "pcnet: local = pooling window of the --local heads (0: off)");
     AKE_REQUIRE(c.pitch_classes == 12, AKE_ERR_UNSUPPORTED, "pcnet: pitch_classes must be 12");
     AKE_REQUIRE(c.pitches > 0 && c.pitches % 36 == 0, AKE_ERR_INVALID, "pcnet: pitches must be a multiple of 36");
@@ -800,8 +806,10 @@ int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
         const std::string m = "model." + std::to_string(i) + ".";
         const LayerDims& d = n->dims[i];
         const int cs = i == 0 ? 1 : d.out_p;
-        add_conv_specs(n, m + "pool_semi", cs, cs, 3, 3);                     // models.py:313 / :337
-        add_bn_specs(n, m + "pool_semi_b", cs);
+        if (i == 0 || !c.stay_sixth) {                                        // --stay_sixth: no semitone conv after layer 0 (models.py:336)
+            add_conv_specs(n, m + "pool_semi", cs, cs, 3, 3);                 // models.py:313 / :337
+            add_bn_specs(n, m + "pool_semi_b", cs);
+        }
         if (c.p2pc_conv) {                                                    // models.py:118-119: Pitch2PitchClassConv
             add_conv_specs(n, m + "pool.conv", cs, cs, c.pitches / 36, 1);
             add_bn_specs(n, m + "pool.bn", cs);
@@ -823,9 +831,11 @@ int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
             add_bn_specs(n, m + "pc2pc.layer." + std::to_string(3 * j + 1), pc_out);
         }
         if (i >= 1) {
-            add_spec(n, m + "up_sixth.weight", {d.prev_pc, d.prev_pc, 3, 1}); // models.py:325
-            add_spec(n, m + "up_sixth.bias", {d.prev_pc});
-            add_bn_specs(n, m + "up_sixth_b", d.prev_pc);
+            if (!c.stay_sixth) {                                              // --stay_sixth: plain repeat of the pitch classes (models.py:322-323)
+                add_spec(n, m + "up_sixth.weight", {d.prev_pc, d.prev_pc, 3, 1}); // models.py:325
+                add_spec(n, m + "up_sixth.bias", {d.prev_pc});
+                add_bn_specs(n, m + "up_sixth_b", d.prev_pc);
+            }
             if (c.resblock) {                                                 // models.py:218-224, 402-414
                 add_conv_specs(n, m + "p2p.layer.0", d.out_p, c.pc2p_mem ? d.prev_p : d.prev_pc + d.prev_p, k, k);
                 add_bn_specs(n, m + "p2p.layer.1", d.out_p);
@@ -946,6 +956,7 @@ static void build_packs(ake_pcnet* n, bool train) {
         const LayerDims& d = n->dims[i];
         const int cs = i == 0 ? 1 : d.out_p;
         if (i >= 1) {   // creation order mirrors the forward order: up_sixth, p2p, pool_semi, pc2pc
+            if (!c.stay_sixth) {
             std::vector<double> w, b;
             fold(n, m + "up_sixth.weight", m + "up_sixth.bias", bn(m + "up_sixth_b", d.prev_pc), d.prev_pc,
                  static_cast<size_t>(d.prev_pc) * 3, true, d.prev_pc, w, b);
@@ -958,6 +969,7 @@ static void build_packs(ake_pcnet* n, bool train) {
             u.b_off = n->blob.size();
             for (double v : b) n->blob.push_back(static_cast<float>(v));
             up[i] = u;
+            }
             if (c.resblock) {   // [conv0, (conv1, conv2) per block]; inference only: no data-gradient packs
                 p2p[i].push_back(fold_pack(n, m + "p2p.layer.0", bn(m + "p2p.layer.1", d.out_p), d.out_p, c.pc2p_mem ? d.prev_p : d.prev_pc + d.prev_p, k, k));
                 for (int r = 0; r < c.conv_layers; ++r) {
@@ -973,7 +985,7 @@ static void build_packs(ake_pcnet* n, bool train) {
                 if (train) n->p2p_d[i].push_back(dgrad_pack(n, m + "p2p.layer." + std::to_string(3 * j) + ".weight", d.out_p, cin_j, k, k));
             }
         }
-        semi[i] = fold_pack(n, m + "pool_semi", bn(m + "pool_semi_b", cs), cs, cs, 3, 3);
+        if (i == 0 || !c.stay_sixth) semi[i] = fold_pack(n, m + "pool_semi", bn(m + "pool_semi_b", cs), cs, cs, 3, 3);
         if (c.p2pc_conv) {   // [co][ci][n_oct], BatchNorm folded (eval); plain layout as up_sixth's
             std::vector<double> w, bb;
             fold(n, m + "pool.conv.weight", m + "pool.conv.bias", bn(m + "pool.bn", cs), cs, static_cast<size_t>(cs) * (c.pitches / 36), false, cs, w, bb);
@@ -1492,12 +1504,47 @@ struct Fwd {
                                coff, total);
     }
 
+    // inference: semitone conv + BN + LeakyReLU of `src` [B][C][P][T] as a map of its own [B][C][P / 3][T] (raw = before the LeakyReLU)
+    int semi_map(int layer, const float* src, int B, int P, int Tn, float* dst, bool raw) {
+        const PackedConv& pc = n->semi[layer];
+        SemiTrainArgs ta;
+        std::memset(&ta, 0, sizeof(ta));
+        SemiArgs& a = ta.s;
+        a.src = src; a.C = pc.cin; a.H = P; a.T = Tn;
+        a.src_clip_stride = static_cast<long long>(pc.cin) * P * Tn;
+        a.w = n->blob_dev + pc.w_off; a.bias = n->blob_dev + pc.b_off;
+        a.dst = dst; a.n_strips = (Tn + TW - 1) / TW;
+        ta.out_lrelu = raw ? 0 : 1;
+        const int per_clip = (P / 3) * a.n_strips;
+        const int threads = per_clip >= 256 ? 256 : (per_clip + 63) / 64 * 64;
+        dim3 grid((per_clip + threads - 1) / threads, pc.groups, B), block(threads);
+        ake::ProfScope ps("semi_conv_stats_kernel", s);
+        switch (pc.co) {
+            case 8: hipLaunchKernelGGL((semi_conv_stats_kernel<8>), grid, block, 0, s, ta); break;
+            case 4: hipLaunchKernelGGL((semi_conv_stats_kernel<4>), grid, block, 0, s, ta); break;
+            case 1: hipLaunchKernelGGL((semi_conv_stats_kernel<1>), grid, block, 0, s, ta); break;
+            default: ake::set_error("semi: bad CO"); return AKE_ERR_UNSUPPORTED;
+        }
+        return AKE_OK;
+    }
+
+    // the octave fold of ready maps [B][C][S][T] into channels [coff, coff + C) of dst: max (models.py:95-106) or --p2pc_conv's convolution
+    int fold_maps(int layer, const float* maps, int C, int S, int B, int Tn, float* dst, int ctot, int coff) {
+        if (!n->cfg.p2pc_conv) return run_fold_max(maps, C, S, B, Tn, dst, ctot, coff, s);
+        const PackedConv& fc = n->foldc[layer];
+        const long long total = static_cast<long long>(B) * C * 12 * Tn;
+        ake::ProfScope ps("fold_conv_kernel", s);
+        hipLaunchKernelGGL(fold_conv_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, maps, n->blob_dev + fc.w_off,
+                           n->blob_dev + fc.b_off, dst, C, S / 12, Tn, 0, static_cast<long long>(ctot) * 12 * Tn, coff, total);
+        return AKE_OK;
+    }
+
     // inference, default family: the whole of phase A as one launch, one workgroup per clip (layer0_fused_kernel)
     bool layer0_fused(const float* mel, int B) {
         static const bool off = std::getenv("AKE_L0_FUSED") != nullptr && std::atoi(std::getenv("AKE_L0_FUSED")) == 0;
         const auto& c = n->cfg;
         const int P = c.pitches, T0 = b.Tl[0], NF = c.n_filters;
-        if (off || c.resblock || c.p2pc_conv || NF < 2 || NF > 4 || c.conv_layers < 1 || c.conv_layers > 4 || c.kernel_size != 7 || P % 36 || T0 < 1) return false;
+        if (off || c.resblock || c.p2pc_conv || c.stay_sixth || NF < 2 || NF > 4 || c.conv_layers < 1 || c.conv_layers > 4 || c.kernel_size != 7 || P % 36 || T0 < 1) return false;
         const PackedConv& sp = n->semi[0];
         if (sp.cin != 1 || sp.co != 1) return false;
         for (int j = 0; j < c.conv_layers; ++j) {
@@ -1550,7 +1597,10 @@ struct Fwd {
         const int L = c.num_layers, P = c.pitches, T0 = b.Tl[0];
         int rc;
         if (!train && L > 1 && layer0_fused(mel, B)) return AKE_OK;
-        if ((rc = semi(0, mel, nullptr, B, P, T0, b.fold0, 1, 0, nullptr))) return rc;
+        if (c.stay_sixth && L > 1) {   // models.py:366-367: the activated semitone map is the pitch stream from here on; its fold feeds pc2pc
+            if ((rc = semi_map(0, mel, B, P, T0, b.p0, false))) return rc;
+            if ((rc = fold_maps(0, b.p0, 1, P / 3, B, T0, b.fold0, 1, 0))) return rc;
+        } else if ((rc = semi(0, mel, nullptr, B, P, T0, b.fold0, 1, 0, nullptr))) return rc;
         if (L == 1) return AKE_OK;                               // its pc2pc runs in the tail
         const LayerDims& d1 = n->dims[1];
         const int ctot1 = d1.prev_pc + d1.out_p;
@@ -1571,6 +1621,7 @@ struct Fwd {
                 return rc;
             src = dst; src_aff = aff; cin = c.n_filters;
         }
+        if (c.stay_sixth) return AKE_OK;                         // no up_sixth: the pitch classes are repeated as they are
         // psix's BatchNorm lands in rows [prev_p, ..) of the pitch-conv input table (row 0.. = the pitch stream itself)
         if (train) identity(b.aff_p2pin[1], d1.prev_p);
         up_sixth(1, b.cat[1], static_cast<long long>(ctot1) * 12 * T0, train ? b.aff_cat[1] : nullptr, B, d1.prev_pc, T0, b.psix[1],
@@ -1582,9 +1633,10 @@ struct Fwd {
     // the next up_sixth for the inner layers of deeper nets).
     int pitch_chunk(const float* mel, int c0, int B) {
         const auto& c = n->cfg;
-        const int L = c.num_layers, P = c.pitches, tp = c.time_pool_size;
+        const int L = c.num_layers, tp = c.time_pool_size;
+        const int P = c.stay_sixth ? c.pitches / 3 : c.pitches;  // rows of the pitch stream (--stay_sixth: semitones)
         int rc;
-        const float* p_cur = mel;     // pitch stream [B][cp][P][T], always a final activation
+        const float* p_cur = c.stay_sixth ? b.p0 + static_cast<size_t>(c0) * P * b.Tl[0] : mel;     // pitch stream [B][cp][P][T], always a final activation
         int cp = 1;
         const float* pc_cur = nullptr;
         for (int i = 1; i < L; ++i) {
@@ -1595,13 +1647,24 @@ struct Fwd {
             const std::string m = "model." + std::to_string(i) + ".";
             float* cat = b.cat[i] + (last || i == 1 ? static_cast<size_t>(c0) * ctot * 12 * Ti : 0);
             float* psix = b.psix[i] + (i == 1 ? static_cast<size_t>(c0) * d.prev_pc * 36 * Ti : 0);
-            if (i > 1) {   // layer 1's up_sixth ran batch-wide in entry(); pc_cur = pooled (final) features here
+            if (i > 1 && !c.stay_sixth) {   // layer 1's up_sixth ran batch-wide in entry(); pc_cur = pooled (final) features here
                 if (train) identity(b.aff_p2pin[i], d.prev_p);
                 up_sixth(i, pc_cur, static_cast<long long>(ctot) * 12 * Ti, nullptr, B, d.prev_pc, Ti, psix,
                          train ? b.aff_p2pin[i] + 3 * d.prev_p : nullptr);
             }
             // models.py:378-384  repeat + concat (never materialised) + pitch convs
             Src sdesc{p_cur, cp, psix, d.prev_pc, 36};
+            if (c.stay_sixth) {   // models.py:322-323, 379-383: the pitch classes themselves, repeated over the octaves (a dense copy: they live
+                                  // in channels [0, prev_pc) of a concat buffer)
+                const float* pcs = i == 1 ? b.cat[1] + static_cast<size_t>(c0) * ctot * 12 * Ti : pc_cur;
+                const long long per_clip = static_cast<long long>(d.prev_pc) * 12 * Ti, total = per_clip * B;
+                {
+                    ake::ProfScope ps("slice_channels_kernel", s);
+                    hipLaunchKernelGGL(slice_channels_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, pcs,
+                                       static_cast<long long>(ctot) * 12 * Ti, b.pcd[i], per_clip, total);
+                }
+                sdesc = Src{p_cur, cp, b.pcd[i], d.prev_pc, 12};
+            }
             if (c.pc2p_mem) {   // models.py:376-377: no concat, the summed up_sixth map is added to the pitch stream
                 const long long total = static_cast<long long>(B) * cp * P * Ti;
                 ake::ProfScope ps("pc2p_mem_kernel", s);
@@ -1657,6 +1720,8 @@ struct Fwd {
             // models.py:386-392  pool_semi -> fold, written next to pc in the concat buffer
             if (fused_semi) {
                 if ((rc = run_fold_max(out, d.out_p, P / 3, B, Ti, cat, ctot, d.prev_pc, s))) return rc;
+            } else if (c.stay_sixth) {   // models.py:391: the stack's output is folded as it is (no semitone conv)
+                if ((rc = fold_maps(i, out, d.out_p, P, B, Ti, cat, ctot, d.prev_pc))) return rc;
             } else if ((rc = semi(i, out, out_aff, B, P, Ti, cat, ctot, d.prev_pc, train ? b.aff_cat[i] + 3 * d.prev_pc : nullptr))) return rc;
             if (last) return AKE_OK;                             // pc2pc + pooling + heads run batch-wide
             // inner layers of deeper nets: pc2pc, then both time pools (models.py:393-396)
@@ -1895,7 +1960,8 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
     AKE_REQUIRE(!n->cfg.genre || d_genre, AKE_ERR_INVALID, "pcnet backward: genre head enabled but d_genre is null");
     AKE_REQUIRE(n->cfg.local == 0, AKE_ERR_UNSUPPORTED, "pcnet: training a --local net is not built");
-    AKE_REQUIRE(!(n->cfg.resblock || n->cfg.pc2p_mem || n->cfg.p2pc_conv), AKE_ERR_UNSUPPORTED, "pcnet: training a --resblock / --pc2p_mem / --p2pc_conv net is not built");
+    AKE_REQUIRE(!(n->cfg.resblock || n->cfg.pc2p_mem || n->cfg.p2pc_conv || n->cfg.stay_sixth), AKE_ERR_UNSUPPORTED,
+                "pcnet: training a --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth net is not built");
     Buffers b;
     int rc = plan_buffers(n, batch, batch, frames, workspace, &b, true);
     if (rc) return rc;
@@ -1942,8 +2008,8 @@ int ake_pcnet_forward_train_f32(const ake_pcnet* n, const float* mel, int batch,
                                 float* key_out, float* tonic_out, float* genre_out, float* bn_stats_out, void* workspace,
                                 size_t ws_bytes, ake_stream_t stream) {
     AKE_REQUIRE(!n || n->cfg.local == 0, AKE_ERR_UNSUPPORTED, "pcnet: training a --local net (per-frame losses, models.py:861-876) is not built");
-    AKE_REQUIRE(!n || !(n->cfg.resblock || n->cfg.pc2p_mem || n->cfg.p2pc_conv), AKE_ERR_UNSUPPORTED,
-                "pcnet: training a --resblock / --pc2p_mem / --p2pc_conv net is not built (inference only)");
+    AKE_REQUIRE(!n || !(n->cfg.resblock || n->cfg.pc2p_mem || n->cfg.p2pc_conv || n->cfg.stay_sixth), AKE_ERR_UNSUPPORTED,
+                "pcnet: training a --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth net is not built (inference only)");
     return forward_impl(n, true, mel, batch, frames, seq_length, key_out, tonic_out, genre_out, bn_stats_out, workspace, ws_bytes, stream);
 }
 

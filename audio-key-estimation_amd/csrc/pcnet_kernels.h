@@ -2012,6 +2012,14 @@ __global__ void fold_conv_kernel(const float* __restrict__ src, const float* __r
     dst[clip * dst_clip_stride + (static_cast<long long>(dst_coff + co) * 12 + p) * T + t] = acc > 0.f ? acc : acc * kSlope;
 }
 
+// channels [0, C) of a wider buffer [clip][ctot][HT] -> dense [clip][C][HT]
+__global__ void slice_channels_kernel(const float* __restrict__ src, long long src_clip_stride, float* __restrict__ dst, long long per_clip, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long clip = i / per_clip;
+    dst[i] = src[clip * src_clip_stride + (i - clip * per_clip)];
+}
+
 // ==========================================================================================
 // Training-mode forward helpers (BatchNorm with batch statistics, nn.BatchNorm2d in train(), models.py:196 etc.)
 // ==========================================================================================
@@ -2040,6 +2048,7 @@ struct SemiTrainArgs {
     const float* in_affine;   // [C][3] or null
     double* stats;            // [kStatSlots][..][2]
     int stats_stride;
+    int out_lrelu;            // 1: store the activated map (inference uses: --stay_sixth's pitch stream)
 };
 
 template <int CO>
@@ -2097,7 +2106,7 @@ __global__ void semi_conv_stats_kernel(SemiTrainArgs ta) {
 #pragma unroll
         for (int j = 0; j < TW; ++j) {
             const float v = acc[co][j] + b;
-            if (okc && live && t0 + j < a.T) { drow[t0 + j] = v; s1 += v; s2 = fmaf(v, v, s2); }
+            if (okc && live && t0 + j < a.T) { drow[t0 + j] = (ta.out_lrelu && v < 0.f) ? v * kSlope : v; s1 += v; s2 = fmaf(v, v, s2); }
         }
         if (okc && ta.stats) stats_commit(ta.stats, ta.stats_stride, c, s1, s2);      // (null: inference use by --p2pc_conv, no statistics)
     }

@@ -22,7 +22,7 @@ from . import _lib
 from .lightning_shim import LightningModule
 from .metrics import mirex_score as _mirex_score
 
-_VARIANT_FLAGS = ("denseblock", "stay_sixth", "only_semitones")
+_VARIANT_FLAGS = ("denseblock", "only_semitones")
 
 
 class EquivariantPitchClassConvolutionSimple(nn.Module):
@@ -104,7 +104,7 @@ class PitchClassNetLayer(nn.Module):
     """Parameter container for one layer (models.py:246-350); creation order matches the reference
     so that the same torch seed gives the same initial weights."""
 
-    def __init__(self, layer_num, nf, k, conv_layers, resblock=False, pc2p_mem=False, p2pc_conv=False, pitches=288):
+    def __init__(self, layer_num, nf, k, conv_layers, resblock=False, pc2p_mem=False, p2pc_conv=False, pitches=288, stay_sixth=False):
         super().__init__()
         if layer_num == 0:
             self.pool_semi = nn.Conv2d(1, 1, 3, stride=(3, 1), padding=(0, 1), padding_mode="circular")
@@ -122,14 +122,16 @@ class PitchClassNetLayer(nn.Module):
             prev_p = 2 * nf if layer_num == 2 else 2 * nf * 4 ** (layer_num - 2)
             prev_pc = 2 * prev_p
             out_p, out_pc = 4 * prev_p, 4 * prev_pc
-        self.up_sixth = nn.ConvTranspose2d(prev_pc, prev_pc, kernel_size=(3, 1), stride=(3, 1))
-        self.up_sixth_b = nn.BatchNorm2d(prev_pc)
-        self.up_sixth_a = nn.LeakyReLU()
+        if not stay_sixth:                                                        # models.py:322-327
+            self.up_sixth = nn.ConvTranspose2d(prev_pc, prev_pc, kernel_size=(3, 1), stride=(3, 1))
+            self.up_sixth_b = nn.BatchNorm2d(prev_pc)
+            self.up_sixth_a = nn.LeakyReLU()
         # --pc2p_mem (models.py:145-166, 333): the up_sixth map is added to the pitch stream, not concatenated -> fewer input channels
         self.p2p = _p2p(prev_p if pc2p_mem else prev_pc + prev_p, out_p, k, conv_layers, resblock)
-        self.pool_semi = nn.Conv2d(out_p, out_p, (3, 3), stride=(3, 1), padding=(0, 1), padding_mode="circular")
-        self.pool_semi_b = nn.BatchNorm2d(out_p)
-        self.pool_semi_a = nn.LeakyReLU()
+        if not stay_sixth:                                                        # models.py:336-339
+            self.pool_semi = nn.Conv2d(out_p, out_p, (3, 3), stride=(3, 1), padding=(0, 1), padding_mode="circular")
+            self.pool_semi_b = nn.BatchNorm2d(out_p)
+            self.pool_semi_a = nn.LeakyReLU()
         if p2pc_conv:
             self.pool = Pitch2PitchClassConv(pitches // 3, out_p)                # models.py:340-341
         self.pc2pc = _pc2pc(out_p + prev_pc, out_pc, k, conv_layers, resblock)
@@ -202,8 +204,11 @@ class PitchClassNet(LightningModule):
         self.resblock = bool(_opt_get(opt, "resblock", False))
         self.pc2p_mem = bool(_opt_get(opt, "pc2p_mem", False))
         self.p2pc_conv = bool(_opt_get(opt, "p2pc_conv", False))
-        self.model = nn.Sequential(*[PitchClassNetLayer(i, nf, k, self.conv_layers, self.resblock, self.pc2p_mem, self.p2pc_conv, pitches)
-                                     for i in range(num_layers)])
+        self.stay_sixth = bool(_opt_get(opt, "stay_sixth", False))
+        if self.stay_sixth and self.pc2p_mem:
+            raise NotImplementedError("--stay_sixth together with --pc2p_mem is not built")
+        self.model = nn.Sequential(*[PitchClassNetLayer(i, nf, k, self.conv_layers, self.resblock, self.pc2p_mem, self.p2pc_conv, pitches,
+                                                        self.stay_sixth) for i in range(num_layers)])
         final = nf if num_layers == 1 else self.model[num_layers - 1].out_pc          # models.py:694-710
         self.head_layers = _opt_get(opt, "head_layers", 2)
         self.genre = bool(_opt_get(opt, "genre", False))
@@ -252,6 +257,7 @@ class PitchClassNet(LightningModule):
         c.resblock = 1 if self.resblock else 0
         c.pc2p_mem = 1 if self.pc2p_mem else 0
         c.p2pc_conv = 1 if self.p2pc_conv else 0
+        c.stay_sixth = 1 if self.stay_sixth else 0
         return c
 
     def _layout(self):
@@ -424,8 +430,9 @@ class PitchClassNet(LightningModule):
         ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream().cuda_stream
-            if self.training and (self.resblock or self.pc2p_mem or self.p2pc_conv):
-                raise NotImplementedError("training a --resblock / --pc2p_mem / --p2pc_conv net is not built on the HIP path (inference only)")
+            if self.training and (self.resblock or self.pc2p_mem or self.p2pc_conv or self.stay_sixth):
+                raise NotImplementedError("training a --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth net is not built on the HIP path "
+                                          "(inference only)")
             if self.training:
                 # BatchNorm with batch statistics; with autograd enabled the call becomes one autograd node whose backward
                 # runs the HIP backward kernels (gradients for every parameter), as loss.backward() does in the reference

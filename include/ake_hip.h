@@ -107,10 +107,12 @@ typedef struct ake_pcnet_config {
     int time_pool_size; /* opt.time_pool_size, default 2 */
     int genre;          /* opt.genre: 1 adds the 11-way genre head */
     int max_pool;       /* opt.max_pool (models.py:766-797, sample-0 quirk kept) */
-    /* Non-default architecture variants (models.py:108-133,145-166,456-648): must be 0 (resblock, p2pc_conv and pc2p_mem excepted),
+    /* Non-default architecture variants (models.py:108-133,145-166,456-648): must be 0 (resblock, stay_sixth, p2pc_conv and pc2p_mem excepted),
      * ake_pcnet_create returns AKE_ERR_UNSUPPORTED otherwise. */
     int resblock;       /* opt.resblock (models.py:181-187, 218-224, 402-454): 1 builds the residual-block stacks; inference only */
-    int denseblock, stay_sixth, only_semitones;
+    int denseblock;
+    int stay_sixth;     /* opt.stay_sixth (models.py:322-323, 336, 366-367): 1 keeps the pitch stream at semitone resolution after layer 0; inference only */
+    int only_semitones;
     int p2pc_conv;      /* opt.p2pc_conv (models.py:108-133): 1 folds the octaves with a learned dilated conv + BN + LeakyReLU instead of the max; inference only */
     int pc2p_mem;       /* opt.pc2p_mem (models.py:145-166): 1 adds the summed up_sixth map to the pitch stream instead of concatenating; inference only */
     /* opt.local (sliding-window key tracking, models.py:720-722): 0 = off, else the heads' pooling window

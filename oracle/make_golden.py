@@ -321,6 +321,22 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "pcnet_p2pcconv_T40.npz"), opt=json.dumps(vars(opt_c)), x=xc.numpy(), seq_length=seq_c.numpy(),
                         key=kc.numpy(), tonic=tc.numpy(), genre=gnc.numpy(), **sd_to_npz(sd_c))
 
+    # ---------------------------------------------------------------- I: --stay_sixth, three layers, B=2, T=64
+    print("I: --stay_sixth (the pitch stream stays at semitone resolution: 96 rows, no up_sixth / pool_semi after layer 0), num_layers=2, B=2, T=40")
+    opt_s = default_opt(stay_sixth=True)
+    net_s, sd_s = build_reference_net(opt_s, seed=55)
+    net_s.eval()
+    gs = torch.Generator().manual_seed(135)
+    xs = (torch.rand((2, 1, 288, 40), generator=gs) * 2.5).float()
+    seq_s = torch.tensor([40, 29])
+    ks_, ts_, gns_ = net_s(xs.double(), seq_s)
+    oks, ots, ogs = pcnet_oracle.pcnet_forward(sd_s, xs.double(), seq_s)
+    report["checks"]["I_key"] = check("stay_sixth key", oks, ks_, 1e-12)
+    report["checks"]["I_tonic"] = check("stay_sixth tonic", ots, ts_, 1e-12)
+    report["checks"]["I_genre"] = check("stay_sixth genre", ogs, gns_, 1e-12)
+    np.savez_compressed(os.path.join(GOLD, "pcnet_staysixth_T40.npz"), opt=json.dumps(vars(opt_s)), x=xs.numpy(), seq_length=seq_s.numpy(),
+                        key=ks_.numpy(), tonic=ts_.numpy(), genre=gns_.numpy(), **sd_to_npz(sd_s))
+
     with open(os.path.join(GOLD, "PROVENANCE.json"), "w") as f:
         json.dump(report, f, indent=1)
     print("wrote", sorted(os.listdir(GOLD)))

@@ -208,19 +208,37 @@ def forward_features(sd, mel, time_pool_size=2, training=False, taps=None):
     """nn.Sequential of PitchClassNetLayer.forward, models.py:352-399 (default flags; --pc2p_mem when the first pitch conv of a
     layer takes only the pitch stream's channels)."""
     num_layers = 0
-    while f"model.{num_layers}.pool_semi.weight" in sd:
+    while f"model.{num_layers}.pc2pc.layer.0.conv2d.weight" in sd:       # (pool_semi is absent from --stay_sixth layers >= 1)
         num_layers += 1
     p, pc = mel, None
     pitches = mel.shape[2]
+    # --stay_sixth (models.py:322-323, 336, 366-367, 371, 385): the pitch stream continues at semitone resolution -- layer 0's semitone
+    # map replaces the CQT as the stream, later layers have neither up_sixth nor pool_semi and repeat the 12 pitch-class rows directly
+    stay = num_layers > 1 and "model.1.up_sixth.weight" not in sd
     for i in range(num_layers):
         pre = f"model.{i}."
         if i == 0:
             p_semi = semitone_pool(p, sd, pre, training)            # :361-363
+            if stay:
+                p = p_semi                                          # :366-367
             pc = (pitch2pitchclass_conv(p_semi, sd, pre + "pool.", training) if pre + "pool.conv.weight" in sd
                   else pitch2pitchclass_pool(p_semi))               # :368 (p stays raw, :366-367)
             if taps is not None:
                 taps[pre + "pool"] = pc
             pc = pc2pc_stack(pc, sd, pre + "pc2pc.", training, taps)  # :369
+        elif stay:
+            p = torch.cat([p, pitchclass2pitch(pc, p.shape[2])], dim=1)   # :379-383 with up = PitchClass2Pitch(pitches // 3)
+            p = p2p_stack(p, sd, pre + "p2p.", training, taps)      # :384
+            pc2 = (pitch2pitchclass_conv(p, sd, pre + "pool.", training) if pre + "pool.conv.weight" in sd
+                   else pitch2pitchclass_pool(p))                   # :391
+            if taps is not None:
+                taps[pre + "pool"] = pc2
+            pc = torch.cat([pc, pc2], dim=1)                        # :392
+            pc = pc2pc_stack(pc, sd, pre + "pc2pc.", training, taps)  # :393
+            p = F.max_pool2d(p, (1, time_pool_size))                # :395
+            pc = F.max_pool2d(pc, (1, time_pool_size))              # :396
+            if taps is not None:
+                taps[pre + "time_pool_pc"] = pc
         else:
             p_sixth = F.conv_transpose2d(pc, sd[pre + "up_sixth.weight"], sd[pre + "up_sixth.bias"], stride=(3, 1))  # :372
             p_sixth = _lrelu(_bn(p_sixth, sd, pre + "up_sixth_b.", training))     # :373-374

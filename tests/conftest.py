@@ -66,6 +66,11 @@ def gold_p2pcconv():
 
 
 @pytest.fixture(scope="session")
+def gold_staysixth():
+    return load_golden("pcnet_staysixth_T40.npz")
+
+
+@pytest.fixture(scope="session")
 def gold_mirex():
     return load_golden("mirex_loss_cases.npz")
 

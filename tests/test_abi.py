@@ -87,19 +87,19 @@ def test_set_tensor_validation_and_strict_finalize(gold_default):
     lib.ake_pcnet_destroy(h)
 
 
-@pytest.mark.parametrize("flag", ["denseblock", "stay_sixth", "only_semitones"])
+@pytest.mark.parametrize("flag", ["denseblock", "only_semitones"])
 def test_variant_flags_are_refused(flag):
     rc, h = _create({flag: 1})
     assert rc == -5 and b"not built" in _lib.lib().ake_last_error()
 
 
-@pytest.mark.parametrize("flag", ["resblock", "pc2p_mem", "p2pc_conv"])
-def test_variant_tensor_registry_equals_reference_state_dict(flag, gold_resblock, gold_pc2pmem, gold_p2pcconv):
+@pytest.mark.parametrize("flag", ["resblock", "pc2p_mem", "p2pc_conv", "stay_sixth"])
+def test_variant_tensor_registry_equals_reference_state_dict(flag, gold_resblock, gold_pc2pmem, gold_p2pcconv, gold_staysixth):
     """cfg.resblock / cfg.pc2p_mem = 1: the handle expects exactly the float entries of the reference's state_dict for that flag."""
     lib = _lib.lib()
     rc, h = _create({flag: 1})
     assert rc == 0
-    gold = {"resblock": gold_resblock, "pc2p_mem": gold_pc2pmem, "p2pc_conv": gold_p2pcconv}[flag]
+    gold = {"resblock": gold_resblock, "pc2p_mem": gold_pc2pmem, "p2pc_conv": gold_p2pcconv, "stay_sixth": gold_staysixth}[flag]
     want = {k[3:]: tuple(gold[k].shape) for k in gold.files if k.startswith("sd/") and gold[k].dtype.kind == "f"}
     got = {}
     for i in range(lib.ake_pcnet_num_tensors(h)):

@@ -314,6 +314,27 @@ def test_p2pc_conv_against_reference_fixture(gold_p2pcconv):
         net.train()(x, seq)
 
 
+def test_stay_sixth_against_reference_fixture(gold_staysixth):
+    """--stay_sixth (models.py:322-323, 336, 366-367), inference: the reference's own outputs for its own seeded weights (per-tile
+    kernels on the 96-row pitch stream), then B = 24, T = 76 (persistent kernels) against the oracle."""
+    net, opt = make_net(gold_staysixth)
+    assert net.stay_sixth
+    x = torch.from_numpy(gold_staysixth["x"]).to(DEV)
+    seq = torch.from_numpy(gold_staysixth["seq_length"]).to(DEV)
+    for got, name in zip(net(x, seq), ("key", "tonic", "genre")):
+        assert rel_err(got.cpu(), gold_staysixth[name]) < TOL, name
+    g = torch.Generator().manual_seed(38)
+    x2 = torch.rand((64, 1, 288, 76), generator=g) * 2.5
+    seq2 = torch.randint(30, 77, (64,), generator=g)
+    got = net(x2.to(DEV), seq2.to(DEV))
+    idx = [0, 31, 63]
+    ref = pcnet_oracle.pcnet_forward(golden_state_dict(gold_staysixth, torch.float64), x2[idx].double(), seq2[idx])
+    for a, b in zip(got, ref):
+        assert rel_err(a[idx].cpu(), b) < TOL
+    with pytest.raises(NotImplementedError):
+        net.train()(x, seq)
+
+
 def test_edge_shapes(gold_default):
     net, _ = make_net(gold_default)
     sd = golden_state_dict(gold_default, torch.float64)

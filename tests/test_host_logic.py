@@ -62,17 +62,17 @@ def test_forward_fails_loudly_without_a_gpu_tensor():
         net.train()(torch.zeros(1, 1, 288, 76), None)            # the train-mode forward is HIP-only as well
 
 
-@pytest.mark.parametrize("flag", ["denseblock", "stay_sixth", "only_semitones"])
+@pytest.mark.parametrize("flag", ["denseblock", "only_semitones"])
 def test_variant_flags_raise(flag):
     with pytest.raises(NotImplementedError):
         ake_amd.PitchClassNet(288, 12, 2, 7, Namespace(**{flag: True}))
 
 
-@pytest.mark.parametrize("flag", ["resblock", "pc2p_mem", "p2pc_conv"])
-def test_variant_state_dict_equals_reference(flag, gold_resblock, gold_pc2pmem, gold_p2pcconv):
+@pytest.mark.parametrize("flag", ["resblock", "pc2p_mem", "p2pc_conv", "stay_sixth"])
+def test_variant_state_dict_equals_reference(flag, gold_resblock, gold_pc2pmem, gold_p2pcconv, gold_staysixth):
     """--resblock / --pc2p_mem: keys, order and shapes of the state_dict equal the reference's (strict load of a reference checkpoint)."""
     net = ake_amd.PitchClassNet(288, 12, 2, 7, Namespace(genre=True, **{flag: True}))
-    gold = {"resblock": gold_resblock, "pc2p_mem": gold_pc2pmem, "p2pc_conv": gold_p2pcconv}[flag]
+    gold = {"resblock": gold_resblock, "pc2p_mem": gold_pc2pmem, "p2pc_conv": gold_p2pcconv, "stay_sixth": gold_staysixth}[flag]
     ref = {k[3:]: gold[k] for k in gold.files if k.startswith("sd/")}
     sd = net.state_dict()
     assert list(sd.keys()) == list(ref.keys())

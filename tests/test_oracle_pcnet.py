@@ -134,6 +134,17 @@ def test_p2pc_conv_against_reference_fixture(gold_p2pcconv):
     assert np.abs(g.numpy() - gold_p2pcconv["genre"]).max() <= 1e-12
 
 
+def test_stay_sixth_against_reference_fixture(gold_staysixth):
+    """--stay_sixth (models.py:322-323, 336, 366-367, 371, 385): layer 0's semitone map becomes the pitch stream (96 rows); the later
+    layers have no up_sixth / pool_semi and repeat the pitch classes directly."""
+    sd = golden_state_dict(gold_staysixth, torch.float64)
+    assert "model.1.up_sixth.weight" not in sd and "model.1.pool_semi.weight" not in sd and "model.0.pool_semi.weight" in sd
+    k, t, g = pcnet_oracle.pcnet_forward(sd, torch.from_numpy(gold_staysixth["x"]).double(), torch.from_numpy(gold_staysixth["seq_length"]))
+    assert np.abs(k.numpy() - gold_staysixth["key"]).max() <= 1e-12
+    assert np.abs(t.numpy() - gold_staysixth["tonic"]).max() <= 1e-12
+    assert np.abs(g.numpy() - gold_staysixth["genre"]).max() <= 1e-12
+
+
 def test_max_pool_quirk(gold_default):
     """--max_pool with seq_length: only sample 0 takes the max (models.py:764-785)."""
     sd = golden_state_dict(gold_default, torch.float64)
