@@ -1444,6 +1444,7 @@ struct Fwd {
         const PackedConv& pc = n->semi_t[layer];
         const int bn = bn_of("model." + std::to_string(layer) + ".pool_semi_b");
         SemiTrainArgs ta;
+        std::memset(&ta, 0, sizeof(ta));
         SemiArgs& a = ta.s;
         a.src = src; a.C = pc.cin; a.H = P; a.T = Tn;
         a.src_clip_stride = static_cast<long long>(pc.cin) * P * Tn;
