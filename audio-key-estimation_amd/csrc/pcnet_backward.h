@@ -164,7 +164,6 @@ struct Bwd {
         const auto& c = n->cfg;
         const int L = c.num_layers, P = c.pitches, tp = c.time_pool_size;
         AKE_REQUIRE(L <= 2, AKE_ERR_UNSUPPORTED, "backward: num_layers > 2 is not built yet");
-        AKE_REQUIRE(!c.max_pool, AKE_ERR_UNSUPPORTED, "backward: --max_pool is not built");
         int rc;
         const int Tf = b.Tf;
         const int Tm = Tf - (c.kernel_size - 1) * c.head_layers;
@@ -182,6 +181,7 @@ struct Bwd {
         pa.rows[0] = 12; pa.rows[1] = 12; pa.rows[2] = 11;
         pa.Tm = Tm; pa.seq = reinterpret_cast<const long long*>(seq);
         pa.n_pool_layers = L - 1; pa.tp = tp; pa.shrink = (c.kernel_size - 1) * c.head_layers; pa.batch = B;
+        pa.maps[0] = b.map_k; pa.maps[1] = b.map_t; pa.maps[2] = c.genre ? b.map_g : nullptr; pa.max_pool = c.max_pool;
         {
             ake::ProfScope ps("head_pool_bwd_kernel", s);
             hipLaunchKernelGGL(head_pool_bwd_kernel, dim3((B * 12 + 63) / 64, 3), dim3(64), 0, s, pa);

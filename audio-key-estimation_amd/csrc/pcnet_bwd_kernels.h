@@ -42,6 +42,8 @@ struct PoolHeadBwdArgs {
     int Tm;
     const long long* seq;
     int n_pool_layers, tp, shrink, batch;
+    const float* maps[3];     // --max_pool: the forward's maps [B][rows (12 stored)][Tm]: the gradient goes to the (first) maximum
+    int max_pool;
 };
 
 __global__ void head_pool_bwd_kernel(PoolHeadBwdArgs a) {
@@ -66,6 +68,14 @@ __global__ void head_pool_bwd_kernel(PoolHeadBwdArgs a) {
     if (which == 0) {
         const float y = a.key_out[clip * 12 + row];
         g *= y * (1.f - y);
+    }
+    // models.py:764-797: torch.max over the frames for every clip without seq_length, for clip 0 only with it (the quirk kept)
+    if (a.max_pool && (!a.seq || clip == 0)) {
+        const float* m = a.maps[which] + (static_cast<long long>(clip) * a.rows[which] + row) * a.Tm;
+        int best = 0;
+        for (int t = 1; t < L; ++t) best = m[t] > m[best] ? t : best;
+        for (int t = 0; t < a.Tm; ++t) dm[t] = (t == best && L > 0) ? g : 0.f;
+        return;
     }
     const float gl = L > 0 ? g / static_cast<float>(L) : 0.f;
     for (int t = 0; t < a.Tm; ++t) dm[t] = t < L ? gl : 0.f;

@@ -133,3 +133,34 @@ def test_single_layer_and_no_genre():
     check_grads(net, ref, 5e-2)
     rows = grad_errors(net, ref)
     assert rows[len(rows) // 2][0] < 1e-4, rows[:5]
+
+
+@pytest.mark.parametrize("with_seq", [True, False])
+def test_max_pool_gradients(gold_default, with_seq):
+    """--max_pool (models.py:764-797): torch.max over the frames -- for every clip without seq_length, for clip 0 only with it (the
+    reference's quirk) -- routes the gradient to the maximal frame.  The head maps' gradients change completely under this flag, so
+    the last head convolutions are held tight; the rest is bounded as in the kinked cases."""
+    opt = Namespace(**json.loads(str(gold_default["opt"])))
+    opt.max_pool = True
+    net = ake_amd.PitchClassNet(288, 12, 2, 7, opt)
+    sd32 = golden_state_dict(gold_default)
+    net.load_state_dict(sd32, strict=True)
+    net = net.to(DEV).train()
+    x, seq, labels = make_case(4, 52, 0)
+    if not with_seq:
+        seq = None
+    sd = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.double() if v.is_floating_point() else v)
+          for k, v in sd32.items()}
+    out = pcnet_oracle.pcnet_forward(sd, x.double(), seq, training=True, max_pool=True)
+    lref = loss_fn(out[0], out[1], out[2], *labels)
+    lref.backward()
+    ref = {k: v.grad for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad}
+    o = net(x.to(DEV), seq.to(DEV) if with_seq else None)
+    loss = loss_fn(o[0], o[1], o[2], *(t.to(DEV) for t in labels))
+    assert abs(float(loss.detach()) - float(lref.detach())) < 2e-5 * max(1.0, abs(float(lref.detach())))
+    loss.backward()
+    rows = grad_errors(net, ref)
+    by_name = {n: e for e, n, _ in rows}
+    for name in ("key_classifier.3.conv2d.weight", "tonic_classifier.3.conv2d.weight", "genre_classifier.3.weight"):
+        assert by_name[name] < 1e-4, (name, by_name[name])
+    assert rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 1e-4, rows[:5]
