@@ -529,9 +529,13 @@ typedef float f32x4b __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(1024) void cqt_bank_bf16_kernel(
     BankCall2 call, const OctDesc2* __restrict__ octs, const uint4* __restrict__ table,
-    int batch, int hop, int hop_twos, float* __restrict__ out, long long out_clip_stride, int n_bins_total) {
+    int batch, int hop, int hop_twos, float* __restrict__ out, long long out_clip_stride, int n_bins_total, int n_frames) {
     extern __shared__ __attribute__((aligned(16))) uint4 ldsW[];
-    const int t = blockIdx.x;
+    // gridDim.x is a multiple of 8, so blockIdx.x % 8 is the XCD: consecutive frames go to ONE XCD, whose L2 then serves the parts of
+    // their tap windows that overlap (the windows of octaves 5..7 overlap 2-8 fold)
+    const int per_xcd = gridDim.x >> 3;
+    const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (t >= n_frames) return;
     const int o = blockIdx.y;
     const OctDesc2 g = octs[o];
     const int lane = threadIdx.x & 63;
@@ -1011,10 +1015,10 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
         }
         launch_cascade(a);
         scratch = c.take<float>(static_cast<size_t>(batch) * T * p->cfg.n_bins);
-        dim3 grid(static_cast<unsigned>(T), p->n_oct, (batch + 255) / 256);
+        dim3 grid(static_cast<unsigned>((T + 7) / 8 * 8), p->n_oct, (batch + 255) / 256);
         ake::ProfScope ps("cqt_bank_bf16_kernel", stream);
         hipLaunchKernelGGL(cqt_bank_bf16_kernel, grid, dim3(1024), p->bank2_lds, stream, call2, p->octs2_dev, p->table2_dev, batch,
-                           p->cfg.hop_length, p->hop_twos, scratch, static_cast<long long>(T) * p->cfg.n_bins, p->cfg.n_bins);
+                           p->cfg.hop_length, p->hop_twos, scratch, static_cast<long long>(T) * p->cfg.n_bins, p->cfg.n_bins, static_cast<int>(T));
     } else {
         BankCall call;
         std::memset(&call, 0, sizeof(call));
