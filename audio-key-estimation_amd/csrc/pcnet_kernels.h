@@ -853,12 +853,15 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+            typedef float f32x2w __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2w __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int c = 0; c < NV; ++c) {
-                const float v = c < ctot ? vin[k][c] : 0.f;
-                const unsigned int hb = bf16_bits(v);
-                hi[c >> 1] |= hb << (16 * (c & 1));
-                lo[c >> 1] |= bf16_bits(v - __uint_as_float(hb << 16)) << (16 * (c & 1));
+            for (int c = 0; c < NV; c += 2) {   // hardware conversion (v_cvt_pk_bf16_f32, round to nearest even as bf16_bits), two channels at a time
+                const f32x2w v = {c < ctot ? vin[k][c] : 0.f, (c + 1 < NV && c + 1 < ctot) ? vin[k][c + 1 < NV ? c + 1 : c] : 0.f};
+                const bf16x2w h = __builtin_convertvector(v, bf16x2w);
+                const bf16x2w l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2w), bf16x2w);
+                hi[c >> 1] = __builtin_bit_cast(unsigned int, h);
+                lo[c >> 1] = __builtin_bit_cast(unsigned int, l);
             }
             const int i = threadIdx.x + 512 * k;
             if (i < npos) {
