@@ -58,6 +58,13 @@ struct LayerDims {
     int prev_p = 0, prev_pc = 0, out_p = 0, out_pc = 0;
 };
 
+// --denseblock: one _DenseLayer / _DenseLayerEquivariant (models.py:456-582).  Both convolutions keep their raw weights; the BatchNorm +
+// activation in FRONT of each is a row table (scale, shift, negative slope) in ake_pcnet::dense_aff_dev that the kernel applies on load.
+struct DensePack {
+    PackedConv c1, c2;       // 1-wide bottleneck (stored as 7 taps, centre one non-zero), k-wide convolution
+    size_t aff1 = 0, aff2 = 0;   // float offsets of the two tables
+};
+
 int pick_co(int cout) { return cout >= 8 ? 8 : (cout >= 2 ? 4 : 1); }
 
 }  // namespace
@@ -108,6 +115,12 @@ struct ake_pcnet {
     int32_t* run_off_dev = nullptr;    // per training BatchNorm channel (BnLayer::ch_off order): flat offsets of running_mean, running_var
     float* folded_dev = nullptr;
     bool tracing = false;
+    std::vector<std::vector<DensePack>> dense_pc, dense_p;   // --denseblock: per layer, conv_layers entries
+    struct AffRec { std::string bn; int C; float slope; size_t off; };
+    std::vector<AffRec> aff_recs;      // BatchNorm layers behind dense_aff_dev, in table order
+    size_t dense_aff_floats = 0;
+    float* dense_aff_dev = nullptr;
+    int32_t* dense_aff_idx_dev = nullptr;
     uint4* bf_frags_dev = nullptr;     // split-bf16 weight fragments of conv_p2p_bf16_kernel, rebuilt from the eval packs on the device
     size_t bf_frags_count = 0;         // uint4 entries
 };
@@ -234,6 +247,19 @@ PackedConv fold_pack(ake_pcnet* n, const std::string& conv_prefix, const std::st
     return pack_conv(n, w, b, cout, cin, kh, kw);
 }
 
+// --denseblock: a convolution with its raw weights (no BatchNorm behind it); a 1-wide kernel is stored as 7 taps with only the centre
+// one non-zero, so that the 7-tap Toeplitz kernels run it (bkey empty: bias=False)
+PackedConv dense_conv_pack(ake_pcnet* n, const std::string& wkey, const std::string& bkey, int cout, int cin, int kh, int kw_src) {
+    const auto& w32 = T(n, wkey);
+    std::vector<double> w(static_cast<size_t>(cout) * cin * kh * 7, 0.0), b(cout, 0.0);
+    for (size_t r = 0; r < static_cast<size_t>(cout) * cin * kh; ++r) {
+        if (kw_src == 7) for (int dx = 0; dx < 7; ++dx) w[r * 7 + dx] = w32[r * 7 + dx];
+        else w[r * 7 + 3] = w32[r];
+    }
+    if (!bkey.empty()) { const auto& b32 = T(n, bkey); for (int co = 0; co < cout; ++co) b[co] = b32[co]; }
+    return pack_conv(n, w, b, cout, cin, kh, 7);
+}
+
 // ---- launch helpers ---------------------------------------------------------------------
 
 struct Tile {
@@ -308,6 +334,7 @@ int launch_mfma(const PackedConv& pc, const MfmaArgs& a, int MT, dim3 grid, dim3
 
 struct Src {
     const float* p0; int c0; const float* p1; int c1; int h1;
+    int ctot0 = 0;           // channels of the buffer p0 points into when only its first c0 are read (0: c0)
 };
 
 struct ConvGeom {            // explicit geometry for the data-gradient convolutions
@@ -319,14 +346,15 @@ struct ConvGeom {            // explicit geometry for the data-gradient convolut
 int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int batch, int H, int T_in, bool same_time,
              bool lrelu, float* dst, int dst_ctot, int dst_coff, hipStream_t s, const char* name,
              const float* in_affine = nullptr, double* stats = nullptr, const ConvGeom* geom = nullptr, bool accumulate = false,
-             const float* residual = nullptr) {
+             const float* residual = nullptr, bool rows_zero = false) {
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
     AKE_REQUIRE(pc.kw == 7, AKE_ERR_UNSUPPORTED, "conv: kernel width %d not built (only 7)", pc.kw);
     AKE_REQUIRE(src.c0 + src.c1 == pc.cin, AKE_ERR_STATE, "conv %s: cin mismatch", name);
     a.src0 = src.p0; a.c0 = src.c0; a.src1 = src.p1; a.c1 = src.c1; a.h1 = src.h1 > 0 ? src.h1 : 1;
     a.H = H; a.T_in = T_in;
-    a.src0_clip_stride = static_cast<long long>(src.c0) * H * T_in;
+    a.src0_clip_stride = static_cast<long long>(src.ctot0 > 0 ? src.ctot0 : src.c0) * H * T_in;
+    a.rows_zero = rows_zero ? 1 : 0;
     a.src1_clip_stride = static_cast<long long>(src.c1) * a.h1 * T_in;
     const bool fullrows = kind != 0;
     if (kind == 0) { a.py = pc.kh / 2; a.pad_l = pc.kw / 2; a.time_circ = 1; a.T_out = T_in; a.H_out = H; }
@@ -675,7 +703,8 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
     b->cat.assign(L + 1, nullptr); b->psix.assign(L, nullptr); b->pa.assign(L, nullptr); b->pb.assign(L, nullptr);
     b->pca.assign(L, nullptr); b->pcb.assign(L, nullptr); b->ppool.assign(L, nullptr); b->pin.assign(L, nullptr);
     const size_t C = chunk, B = batch;
-    b->fold0 = cv.take<float>(B * 12 * frames);
+    const size_t dg = c.denseblock ? static_cast<size_t>(c.n_filters) * c.conv_layers : 0;   // channels a dense block appends in place
+    b->fold0 = cv.take<float>(B * (L == 1 ? 1 + dg : 1) * 12 * frames);
     if (c.stay_sixth) {  // --stay_sixth: layer 0's activated semitone map is the pitch stream; dense copies of the pitch-class stream for the repeat
         b->p0 = cv.take<float>(B * (P / 3) * frames);
         b->pcd.assign(L, nullptr);
@@ -692,14 +721,15 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
         const bool last = i == L - 1;
         const int pc_out = i == 0 ? c.n_filters : d.out_pc;
         if (i >= 1) {
-            b->cat[i] = cv.take<float>((last || i == 1 ? B : C) * (d.prev_pc + d.out_p) * 12 * Ti);
+            b->cat[i] = cv.take<float>((last || i == 1 ? B : C) * (d.prev_pc + d.out_p + dg) * 12 * Ti);
             b->psix[i] = cv.take<float>((i == 1 ? B : C) * d.prev_pc * 36 * Ti);
             if (c.pc2p_mem) b->pin[i] = cv.take<float>(C * d.prev_p * P * Ti);             // --pc2p_mem: pitch stream + summed up_sixth map
             b->pa[i] = cv.take<float>(C * d.out_p * P * Ti);
-            b->pb[i] = cv.take<float>((c.resblock ? 2 : 1) * C * d.out_p * P * Ti);          // --resblock: the blocks' 2C-channel hidden map
+            b->pb[i] = cv.take<float>((c.resblock ? 2 : 1) * C * (c.denseblock ? static_cast<size_t>((d.prev_pc + d.prev_p) / 2) * c.n_filters : d.out_p) * P * Ti);   // --resblock: the blocks' 2C-channel hidden map; --denseblock: the bottleneck map
             if (!last) b->ppool[i] = cv.take<float>(C * d.out_p * P * (Ti / c.time_pool_size));
         }
-        b->pca[i] = cv.take<float>((last || i == 0 ? B : C) * pc_out * 12 * Ti);
+        const size_t pca_ch = (c.denseblock && i >= 1) ? static_cast<size_t>((d.out_p + d.prev_pc) / 2) * c.n_filters : pc_out;   // --denseblock: bottleneck
+        b->pca[i] = cv.take<float>((last || i == 0 ? B : C) * pca_ch * 12 * Ti);
         b->pcb[i] = cv.take<float>((c.resblock ? 2 : 1) * (last || i == 0 ? B : C) * pc_out * 12 * Ti);
     }
     b->pcf = cv.take<float>(B * n->final_ch * 12 * b->Tf);
@@ -776,7 +806,9 @@ int ake_pcnet_default_config(ake_pcnet_config* cfg, int octaves, int genre) {
 int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
     AKE_REQUIRE(cfg && out, AKE_ERR_INVALID, "ake_pcnet_create: null argument");
     const ake_pcnet_config& c = *cfg;
-    AKE_REQUIRE(!(c.denseblock || c.only_semitones), AKE_ERR_UNSUPPORTED, "pcnet: denseblock/only_semitones variants are not built");
+    AKE_REQUIRE(!c.only_semitones, AKE_ERR_UNSUPPORTED, "pcnet: the only_semitones variant is not built");
+    AKE_REQUIRE(!(c.denseblock && (c.resblock || c.pc2p_mem || c.p2pc_conv || c.stay_sixth || c.local)), AKE_ERR_UNSUPPORTED,
+                "pcnet: denseblock together with resblock / pc2p_mem / p2pc_conv / stay_sixth / local is not built");
     AKE_REQUIRE(!(c.stay_sixth && c.pc2p_mem), AKE_ERR_UNSUPPORTED, "pcnet: stay_sixth together with pc2p_mem is not built");
     AKE_REQUIRE(c.local >= 0, AKE_ERR_INVALID, "pcnet: local = pooling window of the --local heads (0: off)");
     AKE_REQUIRE(c.pitch_classes == 12, AKE_ERR_UNSUPPORTED, "pcnet: pitch_classes must be 12");
@@ -801,6 +833,33 @@ int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
         n->dims[i] = d;
     }
     n->final_ch = L == 1 ? nf : n->dims[L - 1].out_pc;   // models.py:694-710
+    const int growth_all = nf * c.conv_layers;           // channels one dense block appends
+    if (c.denseblock) {                                  // models.py:267-278 (layers), :678-689 (heads)
+        int pp = 1, ppc = 1 + growth_all;
+        for (int i = 1; i < L; ++i) {
+            LayerDims d;
+            d.prev_p = pp; d.prev_pc = ppc;
+            d.out_p = pp + growth_all + ppc;             // block input (pitch stream | repeated up_sixth map) + its growth
+            d.out_pc = ppc + d.out_p + growth_all;       // block input (pitch classes | folded semitone maps) + its growth
+            n->dims[i] = d;
+            pp = d.out_p; ppc = d.out_pc;
+        }
+        n->final_ch = L == 1 ? 1 + growth_all : n->dims[L - 1].out_pc;
+    }
+    // one dense block: layer j reads cin + j * nf channels; bn_size = cin / 2 (1 for a single input channel), models.py:189, 226
+    auto add_dense_specs = [&](const std::string& base, int cin, bool equiv) {
+        const int bott = (cin > 1 ? cin / 2 : 1) * nf;
+        for (int j = 0; j < c.conv_layers; ++j) {
+            const std::string lp = base + "denselayer" + std::to_string(j + 1) + ".";
+            const int cj = cin + j * nf;
+            add_bn_specs(n, lp + "norm1", cj);
+            if (equiv) add_conv_specs(n, lp + "conv1.conv2d", bott, cj, 12, 1);
+            else add_spec(n, lp + "conv1.weight", {bott, cj, 1, 1});                  // bias=False, models.py:464
+            add_bn_specs(n, lp + "norm2", bott);
+            if (equiv) add_conv_specs(n, lp + "conv2.conv2d", nf, bott, 12, k);
+            else add_spec(n, lp + "conv2.weight", {nf, bott, k, k});
+        }
+    };
     // ---- expected state_dict entries ----
     for (int i = 0; i < L; ++i) {
         const std::string m = "model." + std::to_string(i) + ".";
@@ -815,6 +874,16 @@ int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
             add_bn_specs(n, m + "pool.bn", cs);
         }
         const int pc_in = i == 0 ? 1 : d.out_p + d.prev_pc, pc_out = i == 0 ? nf : d.out_pc;
+        if (c.denseblock) {                                                   // models.py:188-189, 225-226
+            add_dense_specs(m + "pc2pc.layer.0.", pc_in, true);
+            if (i >= 1) {
+                add_spec(n, m + "up_sixth.weight", {d.prev_pc, d.prev_pc, 3, 1});
+                add_spec(n, m + "up_sixth.bias", {d.prev_pc});
+                add_bn_specs(n, m + "up_sixth_b", d.prev_pc);
+                add_dense_specs(m + "p2p.layer.0.", d.prev_pc + d.prev_p, false);
+            }
+            continue;
+        }
         if (c.resblock) {                                                     // models.py:181-187: conv + BN, then conv_layers ResBlockEquivariant
             add_conv_specs(n, m + "pc2pc.layer.0.conv2d", pc_out, pc_in, 12, k);
             add_bn_specs(n, m + "pc2pc.layer.1", pc_out);
@@ -887,7 +956,8 @@ void ake_pcnet_destroy(ake_pcnet* n) {
     if (!n) return;
     if (n->blob_dev) (void)hipFree(n->blob_dev);
     for (void* p : {static_cast<void*>(n->map_dev), static_cast<void*>(n->fold_ch_dev), static_cast<void*>(n->fold_bn_dev),
-                    static_cast<void*>(n->run_off_dev), static_cast<void*>(n->folded_dev), static_cast<void*>(n->bf_frags_dev)})
+                    static_cast<void*>(n->run_off_dev), static_cast<void*>(n->folded_dev), static_cast<void*>(n->bf_frags_dev),
+                    static_cast<void*>(n->dense_aff_dev), static_cast<void*>(n->dense_aff_idx_dev)})
         if (p) (void)hipFree(p);
     delete n;
 }
@@ -936,6 +1006,29 @@ static void build_packs(ake_pcnet* n, bool train) {
     semi.assign(L, PackedConv()); up.assign(L, PackedConv());
     (train ? n->foldc_t : n->foldc).assign(L, PackedConv());
     pc2pc.assign(L, {}); p2p.assign(L, {});
+    if (!train) { n->dense_pc.assign(L, {}); n->dense_p.assign(L, {}); }
+    // --denseblock (eval packs only): layer j of a block reads cin + j * nf channels
+    auto dense_block = [&](const std::string& base, int cin, bool equiv, std::vector<DensePack>& out) {
+        const int nf = c.n_filters, bott = (cin > 1 ? cin / 2 : 1) * nf;
+        auto table = [&](const std::string& bnp, int C, float slope) {
+            const size_t off = n->dense_aff_floats;
+            n->aff_recs.push_back({bnp, C, slope, off});
+            n->dense_aff_floats += static_cast<size_t>(3) * C;
+            return off;
+        };
+        for (int j = 0; j < c.conv_layers; ++j) {
+            const std::string lp = base + "denselayer" + std::to_string(j + 1) + ".";
+            const int cj = cin + j * nf;
+            DensePack dp;
+            dp.aff1 = table(lp + "norm1", cj, 0.01f);                                  // relu1 = nn.LeakyReLU, models.py:463 / :526
+            dp.c1 = equiv ? dense_conv_pack(n, lp + "conv1.conv2d.weight", lp + "conv1.conv2d.bias", bott, cj, 12, 1)
+                          : dense_conv_pack(n, lp + "conv1.weight", "", bott, cj, 1, 1);
+            dp.aff2 = table(lp + "norm2", bott, 0.f);                                  // relu2 = nn.ReLU, models.py:467 / :530
+            dp.c2 = equiv ? dense_conv_pack(n, lp + "conv2.conv2d.weight", lp + "conv2.conv2d.bias", nf, bott, 12, k)
+                          : dense_conv_pack(n, lp + "conv2.weight", "", nf, bott, k, k);
+            out.push_back(dp);
+        }
+    };
     if (train) { n->pc2pc_d.assign(L, {}); n->p2p_d.assign(L, {}); n->head_key_d.clear(); n->head_tonic_d.clear(); n->head_genre_d.clear(); }
     auto bn = [&](const std::string& prefix, int C) -> std::string {
         if (!train) return prefix;
@@ -978,7 +1071,8 @@ static void build_packs(ake_pcnet* n, bool train) {
                     p2p[i].push_back(fold_pack(n, bp + "conv2", bn(bp + "b2", d.out_p), d.out_p, 2 * d.out_p, k, k));
                 }
             }
-            for (int j = 0; j < c.conv_layers && !c.resblock; ++j) {
+            if (c.denseblock && !train) dense_block(m + "p2p.layer.0.", d.prev_pc + d.prev_p, false, n->dense_p[i]);
+            for (int j = 0; j < c.conv_layers && !c.resblock && !c.denseblock; ++j) {
                 const int cin_j = j == 0 ? (c.pc2p_mem ? d.prev_p : d.prev_pc + d.prev_p) : d.out_p;
                 p2p[i].push_back(fold_pack(n, m + "p2p.layer." + std::to_string(3 * j), bn(m + "p2p.layer." + std::to_string(3 * j + 1), d.out_p),
                                            d.out_p, cin_j, k, k));
@@ -1008,7 +1102,8 @@ static void build_packs(ake_pcnet* n, bool train) {
                 pc2pc[i].push_back(fold_pack(n, bp + "conv2.conv2d", bn(bp + "b2", pc_out), pc_out, 2 * pc_out, 12, k));
             }
         }
-        for (int j = 0; j < c.conv_layers && !c.resblock; ++j) {
+        if (c.denseblock && !train) dense_block(m + "pc2pc.layer.0.", pc_in, true, n->dense_pc[i]);
+        for (int j = 0; j < c.conv_layers && !c.resblock && !c.denseblock; ++j) {
             pc2pc[i].push_back(fold_pack(n, m + "pc2pc.layer." + std::to_string(3 * j) + ".conv2d",
                                          bn(m + "pc2pc.layer." + std::to_string(3 * j + 1), pc_out), pc_out, j == 0 ? pc_in : pc_out, 12, k));
             if (train) n->pc2pc_d[i].push_back(dgrad_pack(n, m + "pc2pc.layer." + std::to_string(3 * j) + ".conv2d.weight", pc_out,
@@ -1090,7 +1185,9 @@ __global__ void running_stats_kernel(const float* __restrict__ bstats, const int
 void reset_packs(ake_pcnet* n) {
     n->blob.clear();
     n->bns.clear(); n->bn_index.clear(); n->bn_channels = 0;
+    n->aff_recs.clear(); n->dense_aff_floats = 0;
 }
+
 
 // The blob layout is a pure function of the configuration: build it once with index-coded values to learn, for every
 // blob float, which flat parameter it comes from.  (Indices + 1 < 2^24 are exact in f32; the eval fold is neutralised by
@@ -1138,6 +1235,31 @@ int upload_i32(const std::vector<int32_t>& v, int32_t** dev) {
     if (*dev) { (void)hipFree(*dev); *dev = nullptr; }
     AKE_HIP_CHECK(hipMalloc(dev, std::max<size_t>(v.size(), 1) * sizeof(int32_t)));
     AKE_HIP_CHECK(hipMemcpy(*dev, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return AKE_OK;
+}
+
+// --denseblock: (re)compute the BatchNorm-on-load tables from the flat parameter buffer on the device
+int rebuild_dense_affine(ake_pcnet* n, const float* params_dev, hipStream_t s) {
+    if (n->aff_recs.empty()) return AKE_OK;
+    const int rows = static_cast<int>(n->dense_aff_floats / 3);
+    if (!n->dense_aff_dev) {
+        std::vector<int32_t> idx;
+        idx.reserve(static_cast<size_t>(rows) * 5);
+        auto off = [&](const std::string& key) { return static_cast<int32_t>(n->grad_off[n->spec_index.at(key)]); };
+        for (const auto& r : n->aff_recs)
+            for (int ch = 0; ch < r.C; ++ch) {
+                int32_t bits;
+                std::memcpy(&bits, &r.slope, sizeof(bits));
+                for (const char* f : {".weight", ".bias", ".running_mean", ".running_var"}) idx.push_back(off(r.bn + f) + ch);
+                idx.push_back(bits);
+            }
+        int rc = upload_i32(idx, &n->dense_aff_idx_dev);
+        if (rc) return rc;
+        AKE_HIP_CHECK(hipMalloc(&n->dense_aff_dev, n->dense_aff_floats * sizeof(float)));
+    }
+    ake::ProfScope ps("dense_affine_kernel", s);
+    hipLaunchKernelGGL(dense_affine_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, params_dev, n->dense_aff_idx_dev, n->dense_aff_dev, rows);
+    AKE_HIP_CHECK(hipGetLastError());
     return AKE_OK;
 }
 
@@ -1270,6 +1392,17 @@ int ake_pcnet_finalize(ake_pcnet* n) {
     if (!n->blob_dev) AKE_HIP_CHECK(hipMalloc(&n->blob_dev, n->blob.size() * sizeof(float)));
     AKE_HIP_CHECK(hipMemcpy(n->blob_dev, n->blob.data(), n->blob.size() * sizeof(float), hipMemcpyHostToDevice));
     if ((rc = rebuild_bf16_frags(n, nullptr))) return rc;
+    if (!n->aff_recs.empty()) {   // --denseblock: the tables come from the same kernel as in ake_pcnet_load_from_device_f32, fed a staged copy
+        std::vector<float> flat(n->grad_floats);
+        for (size_t i = 0; i < n->specs.size(); ++i) std::copy(n->host[i].data.begin(), n->host[i].data.end(), flat.begin() + n->grad_off[i]);
+        float* tmp = nullptr;
+        AKE_HIP_CHECK(hipMalloc(&tmp, flat.size() * sizeof(float)));
+        AKE_HIP_CHECK(hipMemcpy(tmp, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice));
+        rc = rebuild_dense_affine(n, tmp, nullptr);
+        AKE_HIP_CHECK(hipStreamSynchronize(nullptr));
+        (void)hipFree(tmp);
+        if (rc) return rc;
+    }
     AKE_HIP_CHECK(hipStreamSynchronize(nullptr));
     n->finalized = true;
     return AKE_OK;
@@ -1302,7 +1435,8 @@ int ake_pcnet_load_from_device_f32(ake_pcnet* n, const float* params_dev, ake_st
     }
     AKE_HIP_CHECK(hipGetLastError());
     {
-        const int rc2 = rebuild_bf16_frags(n, s);
+        int rc2 = rebuild_bf16_frags(n, s);
+        if (!rc2) rc2 = rebuild_dense_affine(n, params_dev, s);
         if (rc2) return rc2;
     }
     n->finalized = true;
@@ -1386,6 +1520,30 @@ struct Fwd {
             const int T_out = same ? T_in : T_in - pt.kw + 1;
             const int H_out = kind == 2 ? H - pt.kh + 1 : H;
             finalize_bn(bn, static_cast<double>(B) * H_out * T_out, aff_dst);
+        }
+        return AKE_OK;
+    }
+
+    // --denseblock (models.py:584-648), inference: one block IN PLACE on feat [B][ctot][H][T] whose channels [0, cin) are filled; layer j
+    // reads channels [0, cin + j*nf) through its norm1 table, writes the bottleneck map to `bott`, and its k-wide convolution (input
+    // through the norm2 table, ReLU) appends nf channels at cin + j*nf.  kind 0: plain Conv2d -- 1 x 1, then k x k ZERO-padded on both
+    // axes; kind 1: equivariant 12 x 1 and 12 x k (rows circular, frames zero-padded).
+    int dense_stack(const std::vector<DensePack>& packs, int kind, float* feat, int ctot, int cin, int B, int H, int T, float* bott, const char* label) {
+        const int nf = n->cfg.n_filters, k = n->cfg.kernel_size;
+        int rc;
+        for (size_t j = 0; j < packs.size(); ++j) {
+            const DensePack& dp = packs[j];
+            const int cj = cin + static_cast<int>(j) * nf;
+            AKE_REQUIRE(dp.c1.cin == cj && cj + nf <= ctot, AKE_ERR_STATE, "dense %s: channel bookkeeping", label);
+            Src s1{feat, cj, nullptr, 0, 0, ctot};
+            const ConvGeom g1{0, 3, T, H, 0};                  // the single tap sits at offset 3 of the 7 stored
+            if ((rc = run_conv(n, dp.c1, kind, s1, B, H, T, true, false, bott, dp.c1.cout, 0, s, label, n->dense_aff_dev + dp.aff1, nullptr,
+                               kind == 0 ? &g1 : nullptr)))
+                return rc;
+            const ConvGeom g2{k / 2, k / 2, T, H, 0};
+            if ((rc = run_conv(n, dp.c2, kind, Src{bott, dp.c1.cout, nullptr, 0, 0}, B, H, T, true, false, feat, ctot, cj, s, label,
+                               n->dense_aff_dev + dp.aff2, nullptr, kind == 0 ? &g2 : nullptr, false, nullptr, kind == 0)))
+                return rc;
         }
         return AKE_OK;
     }
@@ -1545,7 +1703,7 @@ struct Fwd {
         static const bool off = std::getenv("AKE_L0_FUSED") != nullptr && std::atoi(std::getenv("AKE_L0_FUSED")) == 0;
         const auto& c = n->cfg;
         const int P = c.pitches, T0 = b.Tl[0], NF = c.n_filters;
-        if (off || c.resblock || c.p2pc_conv || c.stay_sixth || NF < 2 || NF > 4 || c.conv_layers < 1 || c.conv_layers > 4 || c.kernel_size != 7 || P % 36 || T0 < 1) return false;
+        if (off || c.resblock || c.denseblock || c.p2pc_conv || c.stay_sixth || NF < 2 || NF > 4 || c.conv_layers < 1 || c.conv_layers > 4 || c.kernel_size != 7 || P % 36 || T0 < 1) return false;
         const PackedConv& sp = n->semi[0];
         if (sp.cin != 1 || sp.co != 1) return false;
         for (int j = 0; j < c.conv_layers; ++j) {
@@ -1601,6 +1759,15 @@ struct Fwd {
         if (c.stay_sixth && L > 1) {   // models.py:366-367: the activated semitone map is the pitch stream from here on; its fold feeds pc2pc
             if ((rc = semi_map(0, mel, B, P, T0, b.p0, false))) return rc;
             if ((rc = fold_maps(0, b.p0, 1, P / 3, B, T0, b.fold0, 1, 0))) return rc;
+        } else if (c.denseblock) {   // the fold is channel 0 of the block's feature buffer (L == 1: fold0 itself, else layer 1's concat buffer)
+            const int g = c.n_filters * c.conv_layers;
+            const int ctot1 = L == 1 ? 1 + g : n->dims[1].prev_pc + n->dims[1].out_p + g;
+            float* feat = L == 1 ? b.fold0 : b.cat[1];
+            if ((rc = semi(0, mel, nullptr, B, P, T0, feat, ctot1, 0, nullptr))) return rc;
+            if (L == 1) return AKE_OK;                           // its block runs in the tail
+            if ((rc = dense_stack(n->dense_pc[0], 1, feat, ctot1, 1, B, 12, T0, b.pca[0], "conv_mfma_kernel/pc2pc0"))) return rc;
+            up_sixth(1, feat, static_cast<long long>(ctot1) * 12 * T0, nullptr, B, n->dims[1].prev_pc, T0, b.psix[1], nullptr);
+            return AKE_OK;
         } else if ((rc = semi(0, mel, nullptr, B, P, T0, b.fold0, 1, 0, nullptr))) return rc;
         if (L == 1) return AKE_OK;                               // its pc2pc runs in the tail
         const LayerDims& d1 = n->dims[1];
@@ -1644,6 +1811,32 @@ struct Fwd {
             const int Ti = b.Tl[i];
             const LayerDims& d = n->dims[i];
             const bool last = i == L - 1;
+            if (c.denseblock) {   // models.py:370-396 with dense stacks: both blocks grow their concat buffers in place
+                const int g = c.n_filters * c.conv_layers;
+                const int ctd = d.prev_pc + d.out_p + g;                             // = d.out_pc
+                float* catd = b.cat[i] + (last || i == 1 ? static_cast<size_t>(c0) * ctd * 12 * Ti : 0);
+                float* psixd = b.psix[i] + (i == 1 ? static_cast<size_t>(c0) * d.prev_pc * 36 * Ti : 0);
+                if (i > 1) up_sixth(i, pc_cur, static_cast<long long>(ctd) * 12 * Ti, nullptr, B, d.prev_pc, Ti, psixd, nullptr);
+                float* fp = b.pa[i];                                                  // [B][out_p][P][Ti]
+                {
+                    const long long total = static_cast<long long>(B) * (cp + d.prev_pc) * P * Ti;
+                    ake::ProfScope ps("concat_repeat_kernel", s);
+                    hipLaunchKernelGGL(concat_repeat_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, p_cur, cp, psixd, d.prev_pc, 36,
+                                       fp, d.out_p, P, Ti, total);
+                }
+                if ((rc = dense_stack(n->dense_p[i], 0, fp, d.out_p, cp + d.prev_pc, B, P, Ti, b.pb[i], "conv_mfma_kernel/p2p"))) return rc;
+                if ((rc = semi(i, fp, nullptr, B, P, Ti, catd, ctd, d.prev_pc, nullptr))) return rc;
+                if (last) return AKE_OK;                                              // its pitch-class block + pooling + heads run batch-wide
+                if ((rc = dense_stack(n->dense_pc[i], 1, catd, ctd, d.prev_pc + d.out_p, B, 12, Ti, b.pca[i], "conv_mfma_kernel/pc2pc"))) return rc;
+                const LayerDims& dn = n->dims[i + 1];
+                const int ctn = dn.prev_pc + dn.out_p + g;
+                const int Tn = Ti / tp;
+                float* catn = b.cat[i + 1] + (i + 1 == L - 1 ? static_cast<size_t>(c0) * ctn * 12 * Tn : 0);
+                time_pool(catd, nullptr, B, ctd, 12, Ti, catn, ctn, 0);
+                time_pool(fp, nullptr, B, d.out_p, P, Ti, b.ppool[i], d.out_p, 0);
+                pc_cur = catn; p_cur = b.ppool[i]; cp = d.out_p;
+                continue;
+            }
             const int ctot = d.prev_pc + d.out_p;
             const std::string m = "model." + std::to_string(i) + ".";
             float* cat = b.cat[i] + (last || i == 1 ? static_cast<size_t>(c0) * ctot * 12 * Ti : 0);
@@ -1766,7 +1959,8 @@ struct Fwd {
         const float* psrc = L == 1 ? b.fold0 : b.cat[i];
         const float* psrc_aff = (train && L > 1) ? b.aff_cat[i] : nullptr;
         int cin = L == 1 ? 1 : d.prev_pc + d.out_p;
-        const int cout = L == 1 ? c.n_filters : d.out_pc;
+        const int cout_default = L == 1 ? c.n_filters : d.out_pc;
+        const int cout = cout_default;
         const std::string m = "model." + std::to_string(i) + ".pc2pc.layer.";
         float* pdst = nullptr;
         float* pdst_aff = nullptr;
@@ -1777,7 +1971,7 @@ struct Fwd {
         // heads on the bf16 kernels read a channels-last copy of the pooled features (decided here: the fused stack writes it itself)
         const bool head_bf = !train && !g_pc_f32_only && L > 1 && n->final_ch == 16 && c.head_layers >= 2 && n->head_key[0].bf_off >= 0 &&
                              n->head_tonic[0].bf_off >= 0 && b.Tf <= kPcBf16MaxFrames;
-        const bool pc_fused = !train && L > 1 && pc2pc_fuses(n, i, Ti);
+        const bool pc_fused = !train && L > 1 && !c.denseblock && pc2pc_fuses(n, i, Ti);
         if (pc_fused) {
             if ((rc = run_pc2pc_fused(n, i, psrc, cin, B, Ti, b.pcf, head_bf ? b.feat_cl : nullptr, s))) return rc;
         } else if (pc_bf) run_nchw_to_cl16(psrc, cin, B, Ti, reinterpret_cast<unsigned short*>(b.pcb[i]), s);
@@ -1787,7 +1981,14 @@ struct Fwd {
                 return rc;
             pdst = b.pca[i];
         }
-        for (int j = 0; j < c.conv_layers && !pc_fused && !c.resblock; ++j) {
+        if (c.denseblock) {   // the last layer's pitch-class block, in place on its concat buffer: the features are the buffer itself
+            float* feat_buf = L == 1 ? b.fold0 : b.cat[i];
+            if ((rc = dense_stack(n->dense_pc[i], 1, feat_buf, n->final_ch, cin, B, 12, Ti, b.pca[i],
+                                  L == 1 ? "conv_mfma_kernel/pc2pc0" : "conv_mfma_kernel/pc2pc")))
+                return rc;
+            pdst = feat_buf;
+        }
+        for (int j = 0; j < c.conv_layers && !pc_fused && !c.resblock && !c.denseblock; ++j) {
             pdst = train ? b.pcst[i][j] : ((j & 1) ? b.pcb[i] : b.pca[i]);
             pdst_aff = !train ? nullptr : b.aff_pcst[i][j];
             if (pc_bf) {
@@ -1808,6 +2009,7 @@ struct Fwd {
         const float* feat_aff = pdst_aff;
         if (pc_fused) { feat = b.pcf; feat_aff = nullptr; }
         else if (L > 1) {   // models.py:396  (the pitch stream of the last layer feeds nothing: its pool is skipped)
+            const int cout = c.denseblock ? n->final_ch : cout_default;
             time_pool(pdst, pdst_aff, B, cout, 12, Ti, b.pcf, cout, 0);
             feat = b.pcf; feat_aff = nullptr;
         }
@@ -1961,7 +2163,7 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
     AKE_REQUIRE(!n->cfg.genre || d_genre, AKE_ERR_INVALID, "pcnet backward: genre head enabled but d_genre is null");
     AKE_REQUIRE(n->cfg.local == 0, AKE_ERR_UNSUPPORTED, "pcnet: training a --local net is not built");
-    AKE_REQUIRE(!(n->cfg.resblock || n->cfg.pc2p_mem || n->cfg.p2pc_conv || n->cfg.stay_sixth), AKE_ERR_UNSUPPORTED,
+    AKE_REQUIRE(!(n->cfg.resblock || n->cfg.pc2p_mem || n->cfg.p2pc_conv || n->cfg.stay_sixth || n->cfg.denseblock), AKE_ERR_UNSUPPORTED,
                 "pcnet: training a --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth net is not built");
     Buffers b;
     int rc = plan_buffers(n, batch, batch, frames, workspace, &b, true);
@@ -2009,7 +2211,7 @@ int ake_pcnet_forward_train_f32(const ake_pcnet* n, const float* mel, int batch,
                                 float* key_out, float* tonic_out, float* genre_out, float* bn_stats_out, void* workspace,
                                 size_t ws_bytes, ake_stream_t stream) {
     AKE_REQUIRE(!n || n->cfg.local == 0, AKE_ERR_UNSUPPORTED, "pcnet: training a --local net (per-frame losses, models.py:861-876) is not built");
-    AKE_REQUIRE(!n || !(n->cfg.resblock || n->cfg.pc2p_mem || n->cfg.p2pc_conv || n->cfg.stay_sixth), AKE_ERR_UNSUPPORTED,
+    AKE_REQUIRE(!n || !(n->cfg.resblock || n->cfg.pc2p_mem || n->cfg.p2pc_conv || n->cfg.stay_sixth || n->cfg.denseblock), AKE_ERR_UNSUPPORTED,
                 "pcnet: training a --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth net is not built (inference only)");
     return forward_impl(n, true, mel, batch, frames, seq_length, key_out, tonic_out, genre_out, bn_stats_out, workspace, ws_bytes, stream);
 }

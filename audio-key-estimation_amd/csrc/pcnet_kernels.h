@@ -55,6 +55,7 @@ struct ConvArgs {
     int accumulate;           // 1: dst += result (several data-gradients landing on one tensor)
     const float* residual;    // --resblock: [B][cout][H_out][T_out] added before the LeakyReLU (may be dst itself), or null
     long long residual_clip_stride;
+    int rows_zero;            // 1: rows outside [0, H) read as zero instead of wrapping (--denseblock's zero-padded pitch convs; TRAIN form only)
 };
 
 // Per-channel batch statistics are accumulated with double atomics; thousands of workgroups hitting the same 16 addresses
@@ -248,6 +249,34 @@ __global__ void head_pool_kernel(PoolHeadArgs a) {
 }
 
 
+// --denseblock: the pitch stack's input (pitch stream | up_sixth map repeated over the octaves, models.py:378-383) materialised as
+// channels [0, c0 + c1) of the block's feature buffer [B][ctot][H][T] -- every later dense layer re-reads it with its own BatchNorm
+__global__ void concat_repeat_kernel(const float* __restrict__ src0, int c0, const float* __restrict__ src1, int c1, int h1, float* __restrict__ dst,
+                                     int ctot, int H, int T, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int t = static_cast<int>(i % T);
+    long long r = i / T;
+    const int y = static_cast<int>(r % H); r /= H;
+    const int c = static_cast<int>(r % (c0 + c1));
+    const long long clip = r / (c0 + c1);
+    const float v = c < c0 ? src0[((clip * c0 + c) * H + y) * T + t] : src1[((clip * c1 + (c - c0)) * h1 + y % h1) * T + t];
+    dst[((clip * ctot + c) * H + y) * T + t] = v;
+}
+
+// --denseblock: eval-mode BatchNorm in front of a convolution cannot be folded into weights shared by several consumers; it becomes a
+// per-channel (scale, shift, negative slope) row that the convolution applies while loading.  idx = [n][5]: flat-parameter offsets of
+// gamma, beta, running_mean, running_var, and the slope's bits (LeakyReLU 0.01 / ReLU 0)
+__global__ void dense_affine_kernel(const float* __restrict__ params, const int* __restrict__ idx, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int* o = idx + 5 * i;
+    const double sc = static_cast<double>(params[o[0]]) / sqrt(static_cast<double>(params[o[3]]) + 1e-5);
+    out[3 * i] = static_cast<float>(sc);
+    out[3 * i + 1] = static_cast<float>(static_cast<double>(params[o[1]]) - static_cast<double>(params[o[2]]) * sc);
+    out[3 * i + 2] = __int_as_float(o[4]);
+}
+
 // ==========================================================================================
 // f32-MFMA implicit-GEMM form of the same "rows circular, time local" convolution.
 //
@@ -384,6 +413,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
                     while (rj_it >= R_in) { rj_it -= R_in; ++cl_it; }
                     const int cs = c_lo + cl;
                     int row = y0 - a.py + rj;                            // in (-H, 2H): one conditional wrap each way
+                    const bool row_ok = !(TRAIN && a.rows_zero) || (row >= 0 && row < a.H);   // zero padding: the row contributes nothing
                     row += row < 0 ? a.H : 0;
                     row -= row >= a.H ? a.H : 0;
                     float asc = 1.f, ash = 0.f, ang = 1.f;                // BatchNorm + LeakyReLU of the producer, applied on load
@@ -407,7 +437,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
                             } else {
                                 ok = ti >= 0 && ti < a.T_in;
                             }
-                            if (ok) {
+                            if (ok && row_ok) {
                                 if (TRAIN) {
                                     const float x = fmaf(srow[ti], asc, ash);
                                     v[u][h] = x > 0.f ? x : x * ang;      // zero padding stays zero: it pads the activation

@@ -22,7 +22,7 @@ from . import _lib
 from .lightning_shim import LightningModule
 from .metrics import mirex_score as _mirex_score
 
-_VARIANT_FLAGS = ("denseblock", "only_semitones")
+_VARIANT_FLAGS = ("only_semitones",)
 
 
 class EquivariantPitchClassConvolutionSimple(nn.Module):
@@ -69,6 +69,41 @@ class ResBlockEquivariant(nn.Module):
         self.act2 = nn.LeakyReLU()
 
 
+class _DenseLayer(nn.Module):
+    """Parameter container for models.py:456-471 / :519-534 (--denseblock): norm1 -> LeakyReLU -> 1-wide bottleneck conv -> norm2 -> ReLU
+    -> k-wide conv.  ``equivariant``: both convolutions are EquivariantPitchClassConvolutionSimple (12 x 1, 12 x k; with bias), else plain
+    Conv2d without bias (1 x 1, k x k zero-padded)."""
+
+    def __init__(self, cin, growth, bn_size, k, equivariant):
+        super().__init__()
+        self.norm1 = nn.BatchNorm2d(cin)
+        self.relu1 = nn.LeakyReLU(inplace=True)
+        if equivariant:
+            self.conv1 = EquivariantPitchClassConvolutionSimple(12, cin, bn_size * growth, 1)
+        else:
+            self.conv1 = nn.Conv2d(cin, bn_size * growth, kernel_size=1, stride=1, bias=False)
+        self.norm2 = nn.BatchNorm2d(bn_size * growth)
+        self.relu2 = nn.ReLU(inplace=True)
+        if equivariant:
+            self.conv2 = EquivariantPitchClassConvolutionSimple(12, bn_size * growth, growth, k, True)
+        else:
+            self.conv2 = nn.Conv2d(bn_size * growth, growth, kernel_size=k, stride=1, padding=k // 2, bias=False)
+
+
+class DenseBlock(nn.ModuleDict):
+    """Parameter container for DenseBlock / DenseBlockEquivariant, models.py:584-648: ``denselayer1..n``, layer i reading cin + i*growth channels."""
+
+    def __init__(self, num_layers, cin, bn_size, growth, k, equivariant):
+        super().__init__()
+        for i in range(num_layers):
+            self.add_module("denselayer%d" % (i + 1), _DenseLayer(cin + i * growth, growth, bn_size, k, equivariant))
+
+
+def _dense_stack(cin, growth, k, n, equivariant):
+    """models.py:188-189 / :225-226: bn_size = cin // 2 (1 for a single input channel), multi_path off (:264)."""
+    return _ConvStack([DenseBlock(n, cin, cin // 2 if cin > 1 else 1, growth, k, equivariant)])
+
+
 def _pc2pc(cin, cout, k, n, resblock=False):
     if resblock:                                                      # models.py:181-187
         blocks = [EquivariantPitchClassConvolutionSimple(12, cin, cout, k, True), nn.BatchNorm2d(cout), nn.LeakyReLU()]
@@ -104,8 +139,33 @@ class PitchClassNetLayer(nn.Module):
     """Parameter container for one layer (models.py:246-350); creation order matches the reference
     so that the same torch seed gives the same initial weights."""
 
-    def __init__(self, layer_num, nf, k, conv_layers, resblock=False, pc2p_mem=False, p2pc_conv=False, pitches=288, stay_sixth=False):
+    def __init__(self, layer_num, nf, k, conv_layers, resblock=False, pc2p_mem=False, p2pc_conv=False, pitches=288, stay_sixth=False,
+                 denseblock=False):
         super().__init__()
+        if denseblock:                                                            # channel algebra of models.py:267-278
+            g = nf * conv_layers
+            prev_p, prev_pc = 1, 1 + g
+            for _ in range(layer_num - 1):
+                prev_p += g + prev_pc
+                prev_pc += g + prev_p
+            if layer_num == 0:
+                self.pool_semi = nn.Conv2d(1, 1, 3, stride=(3, 1), padding=(0, 1), padding_mode="circular")
+                self.pool_semi_b = nn.BatchNorm2d(1)
+                self.pool_semi_a = nn.LeakyReLU()
+                self.pc2pc = _dense_stack(1, nf, k, conv_layers, True)
+                self.out_pc = 1 + g
+                return
+            out_p = prev_p + g + prev_pc
+            self.up_sixth = nn.ConvTranspose2d(prev_pc, prev_pc, kernel_size=(3, 1), stride=(3, 1))
+            self.up_sixth_b = nn.BatchNorm2d(prev_pc)
+            self.up_sixth_a = nn.LeakyReLU()
+            self.p2p = _dense_stack(prev_pc + prev_p, nf, k, conv_layers, False)
+            self.pool_semi = nn.Conv2d(out_p, out_p, (3, 3), stride=(3, 1), padding=(0, 1), padding_mode="circular")
+            self.pool_semi_b = nn.BatchNorm2d(out_p)
+            self.pool_semi_a = nn.LeakyReLU()
+            self.pc2pc = _dense_stack(out_p + prev_pc, nf, k, conv_layers, True)
+            self.out_pc = out_p + prev_pc + g                                     # = final_channels of models.py:686-689
+            return
         if layer_num == 0:
             self.pool_semi = nn.Conv2d(1, 1, 3, stride=(3, 1), padding=(0, 1), padding_mode="circular")
             self.pool_semi_b = nn.BatchNorm2d(1)
@@ -205,11 +265,17 @@ class PitchClassNet(LightningModule):
         self.pc2p_mem = bool(_opt_get(opt, "pc2p_mem", False))
         self.p2pc_conv = bool(_opt_get(opt, "p2pc_conv", False))
         self.stay_sixth = bool(_opt_get(opt, "stay_sixth", False))
+        # --denseblock (models.py:188-189, 225-226, 456-648): DenseNet-style stacks.  Inference only here.
+        self.denseblock = bool(_opt_get(opt, "denseblock", False))
+        if self.denseblock and (self.resblock or self.pc2p_mem or self.p2pc_conv or self.stay_sixth or self.local):
+            raise NotImplementedError("--denseblock together with --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth / --local is not built")
         if self.stay_sixth and self.pc2p_mem:
             raise NotImplementedError("--stay_sixth together with --pc2p_mem is not built")
         self.model = nn.Sequential(*[PitchClassNetLayer(i, nf, k, self.conv_layers, self.resblock, self.pc2p_mem, self.p2pc_conv, pitches,
-                                                        self.stay_sixth) for i in range(num_layers)])
+                                                        self.stay_sixth, self.denseblock) for i in range(num_layers)])
         final = nf if num_layers == 1 else self.model[num_layers - 1].out_pc          # models.py:694-710
+        if self.denseblock:
+            final = self.model[num_layers - 1].out_pc                                 # models.py:678-689
         self.head_layers = _opt_get(opt, "head_layers", 2)
         self.genre = bool(_opt_get(opt, "genre", False))
         t, kk, g = [], [], []
@@ -258,6 +324,7 @@ class PitchClassNet(LightningModule):
         c.pc2p_mem = 1 if self.pc2p_mem else 0
         c.p2pc_conv = 1 if self.p2pc_conv else 0
         c.stay_sixth = 1 if self.stay_sixth else 0
+        c.denseblock = 1 if self.denseblock else 0
         return c
 
     def _layout(self):
@@ -430,8 +497,8 @@ class PitchClassNet(LightningModule):
         ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream().cuda_stream
-            if self.training and (self.resblock or self.pc2p_mem or self.p2pc_conv or self.stay_sixth):
-                raise NotImplementedError("training a --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth net is not built on the HIP path "
+            if self.training and (self.resblock or self.pc2p_mem or self.p2pc_conv or self.stay_sixth or self.denseblock):
+                raise NotImplementedError("training a --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth / --denseblock net is not built on the HIP path "
                                           "(inference only)")
             if self.training:
                 # BatchNorm with batch statistics; with autograd enabled the call becomes one autograd node whose backward

@@ -337,6 +337,31 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "pcnet_staysixth_T40.npz"), opt=json.dumps(vars(opt_s)), x=xs.numpy(), seq_length=seq_s.numpy(),
                         key=ks_.numpy(), tonic=ts_.numpy(), genre=gns_.numpy(), **sd_to_npz(sd_s))
 
+    # ---------------------------------------------------------------- J: --denseblock, B=2, T=40
+    print("J: --denseblock (DenseNet-style stacks: pre-activation BatchNorm, 1-wide bottlenecks, concatenated features), n_filters=2, conv_layers=2, B=2, T=40")
+    opt_d = default_opt(denseblock=True, n_filters=2, conv_layers=2)
+    net_d, sd_d = build_reference_net(opt_d, seed=66)
+    net_d.eval()
+    gd = torch.Generator().manual_seed(146)
+    xd = (torch.rand((2, 1, 288, 40), generator=gd) * 2.5).float()
+    seq_d = torch.tensor([40, 31])
+    kd_, td_, gnd_ = net_d(xd.double(), seq_d)
+    okd, otd, ogd = pcnet_oracle.pcnet_forward(sd_d, xd.double(), seq_d)
+    report["checks"]["J_key"] = check("denseblock key", okd, kd_, 1e-12)
+    report["checks"]["J_tonic"] = check("denseblock tonic", otd, td_, 1e-12)
+    report["checks"]["J_genre"] = check("denseblock genre", ogd, gnd_, 1e-12)
+    # the default widths (n_filters=4, conv_layers=3: 76-channel bottleneck, 51 -> 102 channel heads) are checked here but not stored (4 MB)
+    opt_d2 = default_opt(denseblock=True)
+    net_d2, sd_d2 = build_reference_net(opt_d2, seed=67)
+    net_d2.eval()
+    kd2, td2, gnd2 = net_d2(xd.double(), seq_d)
+    okd2, otd2, ogd2 = pcnet_oracle.pcnet_forward(sd_d2, xd.double(), seq_d)
+    report["checks"]["J_default_widths_key"] = check("denseblock (default widths) key", okd2, kd2, 1e-12)
+    report["checks"]["J_default_widths_tonic"] = check("denseblock (default widths) tonic", otd2, td2, 1e-12)
+    report["checks"]["J_default_widths_genre"] = check("denseblock (default widths) genre", ogd2, gnd2, 1e-12)
+    np.savez_compressed(os.path.join(GOLD, "pcnet_denseblock_T40.npz"), opt=json.dumps(vars(opt_d)), x=xd.numpy(), seq_length=seq_d.numpy(),
+                        key=kd_.numpy(), tonic=td_.numpy(), genre=gnd_.numpy(), **sd_to_npz(sd_d))
+
     with open(os.path.join(GOLD, "PROVENANCE.json"), "w") as f:
         json.dump(report, f, indent=1)
     print("wrote", sorted(os.listdir(GOLD)))

@@ -150,8 +150,33 @@ def _res_blocks(x, sd, prefix, conv, training, taps):
     return x
 
 
+def _dense_block(x, sd, prefix, conv, training, taps):
+    """--denseblock (DenseBlock / DenseBlockEquivariant, models.py:584-648; layers _DenseLayer / _DenseLayerEquivariant, :456-582):
+    every layer reads the concatenation of the block input and all earlier layers' outputs,
+        new = conv2(relu(norm2(conv1(leaky_relu(norm1(cat))))))          (:473-476, 516-517 / :536-539, 579-580)
+    (pre-activation BatchNorm; relu1 is a LeakyReLU, relu2 a plain ReLU; conv1 is the 1-wide bottleneck), and the block returns the
+    concatenation of everything (:614 / :647).  drop_rate is 0.0 at both call sites (:189, 226).  ``conv(x, key_prefix, same)``
+    applies the stack's convolution type."""
+    feats = [x]
+    j = 1
+    while f"{prefix}denselayer{j}.norm1.weight" in sd:
+        lp = f"{prefix}denselayer{j}."
+        cat = torch.cat(feats, dim=1)
+        h = conv(_lrelu(_bn(cat, sd, lp + "norm1.", training)), lp + "conv1")
+        new = conv(F.relu(_bn(h, sd, lp + "norm2.", training)), lp + "conv2")
+        feats.append(new)
+        if taps is not None:
+            taps[f"{prefix}denselayer{j}"] = new
+        j += 1
+    return torch.cat(feats, dim=1)
+
+
 def pc2pc_stack(pc, sd, prefix, training=False, taps=None):
-    """PitchClass2PitchClass default branch, models.py:190-197, 201-203; --resblock branch :181-187."""
+    """PitchClass2PitchClass default branch, models.py:190-197, 201-203; --resblock branch :181-187; --denseblock branch :188-189."""
+    if f"{prefix}layer.0.denselayer1.norm1.weight" in sd:
+        # conv1: EquivariantPitchClassConvolutionSimple with kernel_depth 1 (12 x 1, no time padding needed), conv2: 12 x k, same padding
+        return _dense_block(pc, sd, prefix + "layer.0.", lambda x, q: equiv_pc_conv(x, sd[q + ".conv2d.weight"], sd[q + ".conv2d.bias"], same=True),
+                            training, taps)
     if f"{prefix}layer.3.b1.weight" in sd:
         pc = equiv_pc_conv(pc, sd[prefix + "layer.0.conv2d.weight"], sd[prefix + "layer.0.conv2d.bias"], same=True)
         pc = _lrelu(_bn(pc, sd, prefix + "layer.1.", training))
@@ -167,7 +192,11 @@ def pc2pc_stack(pc, sd, prefix, training=False, taps=None):
 
 
 def p2p_stack(p, sd, prefix, training=False, taps=None):
-    """Pitch2Pitch default branch, models.py:227-234, 239-243: circular on both axes; --resblock branch :218-224."""
+    """Pitch2Pitch default branch, models.py:227-234, 239-243: circular on both axes; --resblock branch :218-224; --denseblock
+    branch :225-226 (plain nn.Conv2d without bias: 1 x 1, then k x k with ZERO padding k // 2 on both axes, :464, 468)."""
+    if f"{prefix}layer.0.denselayer1.norm1.weight" in sd:
+        return _dense_block(p, sd, prefix + "layer.0.", lambda x, q: F.conv2d(x, sd[q + ".weight"], None, padding=sd[q + ".weight"].shape[2] // 2),
+                            training, taps)
     if f"{prefix}layer.3.b1.weight" in sd:
         circ = lambda x, q: _circular_conv(x, sd[q + ".weight"], sd[q + ".bias"], (1, 1), (sd[q + ".weight"].shape[2] // 2,) * 2)
         p = _lrelu(_bn(circ(p, prefix + "layer.0"), sd, prefix + "layer.1.", training))
@@ -208,7 +237,8 @@ def forward_features(sd, mel, time_pool_size=2, training=False, taps=None):
     """nn.Sequential of PitchClassNetLayer.forward, models.py:352-399 (default flags; --pc2p_mem when the first pitch conv of a
     layer takes only the pitch stream's channels)."""
     num_layers = 0
-    while f"model.{num_layers}.pc2pc.layer.0.conv2d.weight" in sd:       # (pool_semi is absent from --stay_sixth layers >= 1)
+    while (f"model.{num_layers}.pc2pc.layer.0.conv2d.weight" in sd       # (pool_semi is absent from --stay_sixth layers >= 1)
+           or f"model.{num_layers}.pc2pc.layer.0.denselayer1.norm1.weight" in sd):
         num_layers += 1
     p, pc = mel, None
     pitches = mel.shape[2]
@@ -244,7 +274,7 @@ def forward_features(sd, mel, time_pool_size=2, training=False, taps=None):
             p_sixth = _lrelu(_bn(p_sixth, sd, pre + "up_sixth_b.", training))     # :373-374
             if taps is not None:
                 taps[pre + "up_sixth_a"] = p_sixth
-            if sd[pre + "p2p.layer.0.weight"].shape[1] == p.shape[1]:       # --pc2p_mem: :376-377, no concat (:382)
+            if pre + "p2p.layer.0.weight" in sd and sd[pre + "p2p.layer.0.weight"].shape[1] == p.shape[1]:       # --pc2p_mem: :376-377, no concat (:382)
                 p = pitchclass2pitch_memory(p, p_sixth)
             else:
                 p2 = pitchclass2pitch(p_sixth, pitches)             # :378

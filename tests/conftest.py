@@ -71,6 +71,11 @@ def gold_staysixth():
 
 
 @pytest.fixture(scope="session")
+def gold_denseblock():
+    return load_golden("pcnet_denseblock_T40.npz")
+
+
+@pytest.fixture(scope="session")
 def gold_mirex():
     return load_golden("mirex_loss_cases.npz")
 

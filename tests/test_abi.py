@@ -87,7 +87,7 @@ def test_set_tensor_validation_and_strict_finalize(gold_default):
     lib.ake_pcnet_destroy(h)
 
 
-@pytest.mark.parametrize("flag", ["denseblock", "only_semitones"])
+@pytest.mark.parametrize("flag", ["only_semitones"])
 def test_variant_flags_are_refused(flag):
     rc, h = _create({flag: 1})
     assert rc == -5 and b"not built" in _lib.lib().ake_last_error()
@@ -108,6 +108,24 @@ def test_variant_tensor_registry_equals_reference_state_dict(flag, gold_resblock
         got[name.value.decode()] = tuple(shape[d] for d in range(ndim.value))
     assert got == want
     lib.ake_pcnet_destroy(h)
+
+
+def test_denseblock_tensor_registry_equals_reference_state_dict(gold_denseblock):
+    """cfg.denseblock = 1 (with the fixture's n_filters / conv_layers): the handle expects exactly the float entries of the reference's
+    state_dict; combinations with the other variants are refused."""
+    lib = _lib.lib()
+    rc, h = _create({"denseblock": 1, "n_filters": 2, "conv_layers": 2})
+    assert rc == 0
+    want = {k[3:]: tuple(gold_denseblock[k].shape) for k in gold_denseblock.files if k.startswith("sd/") and gold_denseblock[k].dtype.kind == "f"}
+    got = {}
+    for i in range(lib.ake_pcnet_num_tensors(h)):
+        name, shape, ndim = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+        assert lib.ake_pcnet_tensor_info(h, i, C.byref(name), shape, C.byref(ndim)) == 0
+        got[name.value.decode()] = tuple(shape[d] for d in range(ndim.value))
+    assert got == want
+    lib.ake_pcnet_destroy(h)
+    rc, _ = _create({"denseblock": 1, "resblock": 1})
+    assert rc == -5 and b"not built" in lib.ake_last_error()
 
 
 def test_local_config_is_the_pooling_window():

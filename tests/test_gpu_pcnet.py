@@ -335,6 +335,49 @@ def test_stay_sixth_against_reference_fixture(gold_staysixth):
         net.train()(x, seq)
 
 
+def test_denseblock_against_reference_fixture(gold_denseblock):
+    """--denseblock (models.py:188-189, 225-226, 456-648), inference: the reference's own outputs for its own seeded weights (n_filters = 2,
+    conv_layers = 2), then other shapes against the oracle, then the DEFAULT widths (n_filters = 4, conv_layers = 3: 28- and 76-channel
+    bottlenecks, 51 -> 102 channel heads) with seeded weights against the oracle (which make_golden.py pinned on the reference at those
+    widths too)."""
+    net, opt = make_net(gold_denseblock)
+    assert net.denseblock
+    x = torch.from_numpy(gold_denseblock["x"]).to(DEV)
+    seq = torch.from_numpy(gold_denseblock["seq_length"]).to(DEV)
+    for got, name in zip(net(x, seq), ("key", "tonic", "genre")):
+        assert rel_err(got.cpu(), gold_denseblock[name]) < TOL, name
+    g = torch.Generator().manual_seed(48)
+    sd = golden_state_dict(gold_denseblock, torch.float64)
+    for B, T in ((5, 76), (1, 33), (2, 151)):
+        x2 = torch.rand((B, 1, 288, T), generator=g) * 2.5
+        seq2 = torch.randint(T - 6, T + 1, (B,), generator=g)
+        ref = pcnet_oracle.pcnet_forward(sd, x2.double(), seq2)
+        for a, b in zip(net(x2.to(DEV), seq2.to(DEV)), ref):
+            assert rel_err(a.cpu(), b) < TOL, (B, T)
+    with pytest.raises(NotImplementedError):
+        net.train()(x, seq)
+    # default widths
+    torch.manual_seed(7)
+    big = ake_amd.PitchClassNet(288, 12, 2, 7, Namespace(genre=True, denseblock=True))
+    gb = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for name, buf in big.named_buffers():                       # non-trivial running statistics, as make_golden.py does
+            if name.endswith("running_mean"):
+                buf.copy_(torch.randn(buf.shape, generator=gb) * 0.2)
+            elif name.endswith("running_var"):
+                buf.copy_(torch.rand(buf.shape, generator=gb) * 1.5 + 0.5)
+        for name, p in big.named_parameters():
+            if p.dim() == 1 and ("norm" in name or "_b." in name or name.split(".")[-2].isdigit()):
+                p.copy_(torch.rand(p.shape, generator=gb) + 0.5 if name.endswith("weight") else torch.randn(p.shape, generator=gb) * 0.1)
+    sd_big = {k: (v.detach().double().clone() if v.is_floating_point() else v.clone()) for k, v in big.state_dict().items()}
+    big = big.to(DEV).eval()
+    x3 = torch.rand((3, 1, 288, 60), generator=g) * 2.5
+    seq3 = torch.tensor([60, 51, 44])
+    ref = pcnet_oracle.pcnet_forward(sd_big, x3.double(), seq3)
+    for a, b in zip(big(x3.to(DEV), seq3.to(DEV)), ref):
+        assert rel_err(a.cpu(), b) < TOL
+
+
 @pytest.mark.parametrize("variant", ["resblock", "pc2p_mem", "p2pc_conv", "stay_sixth", "local"])
 def test_variants_keep_the_circular_shift_equivariance(variant, gold_default, gold_resblock, gold_pc2pmem, gold_p2pcconv, gold_staysixth):
     """The invariant of equivariance_test.py on every built variant: rolling the CQT by 3 s bins (one semitone = 3 bins) rolls the key and

@@ -62,7 +62,7 @@ def test_forward_fails_loudly_without_a_gpu_tensor():
         net.train()(torch.zeros(1, 1, 288, 76), None)            # the train-mode forward is HIP-only as well
 
 
-@pytest.mark.parametrize("flag", ["denseblock", "only_semitones"])
+@pytest.mark.parametrize("flag", ["only_semitones"])
 def test_variant_flags_raise(flag):
     with pytest.raises(NotImplementedError):
         ake_amd.PitchClassNet(288, 12, 2, 7, Namespace(**{flag: True}))
@@ -78,6 +78,24 @@ def test_variant_state_dict_equals_reference(flag, gold_resblock, gold_pc2pmem, 
     assert list(sd.keys()) == list(ref.keys())
     assert all(tuple(sd[k].shape) == ref[k].shape for k in ref)
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ref.items()}, strict=True)
+
+
+def test_denseblock_state_dict_equals_reference(gold_denseblock):
+    """--denseblock: keys, order and shapes of the state_dict equal the reference's (its own n_filters / conv_layers from the fixture)."""
+    import json
+    opt = Namespace(**json.loads(str(gold_denseblock["opt"])))
+    net = ake_amd.PitchClassNet(288, 12, opt.num_layers, opt.kernel_size, opt)
+    ref = {k[3:]: gold_denseblock[k] for k in gold_denseblock.files if k.startswith("sd/")}
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    assert all(tuple(sd[k].shape) == ref[k].shape for k in ref)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ref.items()}, strict=True)
+    # default widths: the channel algebra of models.py:267-278, 678-689
+    big = ake_amd.PitchClassNet(288, 12, 2, 7, Namespace(genre=True, denseblock=True))
+    assert big.state_dict()["model.1.pc2pc.layer.0.denselayer3.conv2.conv2d.weight"].shape == (4, 76, 12, 7)
+    assert big.state_dict()["key_classifier.0.conv2d.weight"].shape == (102, 51, 12, 7)
+    with pytest.raises(NotImplementedError):
+        ake_amd.PitchClassNet(288, 12, 2, 7, Namespace(denseblock=True, resblock=True))
 
 
 def test_local_flag_keeps_the_state_dict_and_sets_the_window():

@@ -145,6 +145,20 @@ def test_stay_sixth_against_reference_fixture(gold_staysixth):
     assert np.abs(g.numpy() - gold_staysixth["genre"]).max() <= 1e-12
 
 
+def test_denseblock_against_reference_fixture(gold_denseblock):
+    """--denseblock (models.py:188-189, 225-226, 456-648; n_filters = 2, conv_layers = 2 to keep the fixture small -- make_golden.py also
+    checks the default widths against the reference, without storing them): DenseNet-style stacks whose layers read the concatenation of
+    everything before them through a BatchNorm of their own."""
+    sd = golden_state_dict(gold_denseblock, torch.float64)
+    assert sd["model.1.p2p.layer.0.denselayer2.conv1.weight"].shape == (6, 8, 1, 1)          # bn_size 3 x growth 2 <- 6 + 2 channels
+    assert sd["model.1.pc2pc.layer.0.denselayer1.conv1.conv2d.weight"].shape == (14, 15, 12, 1)
+    assert "model.1.p2p.layer.0.denselayer1.conv1.bias" not in sd                             # bias=False, models.py:464
+    k, t, g = pcnet_oracle.pcnet_forward(sd, torch.from_numpy(gold_denseblock["x"]).double(), torch.from_numpy(gold_denseblock["seq_length"]))
+    assert np.abs(k.numpy() - gold_denseblock["key"]).max() <= 1e-12
+    assert np.abs(t.numpy() - gold_denseblock["tonic"]).max() <= 1e-12
+    assert np.abs(g.numpy() - gold_denseblock["genre"]).max() <= 1e-12
+
+
 def test_max_pool_quirk(gold_default):
     """--max_pool with seq_length: only sample 0 takes the max (models.py:764-785)."""
     sd = golden_state_dict(gold_default, torch.float64)
