@@ -107,10 +107,11 @@ typedef struct ake_pcnet_config {
     int time_pool_size; /* opt.time_pool_size, default 2 */
     int genre;          /* opt.genre: 1 adds the 11-way genre head */
     int max_pool;       /* opt.max_pool (models.py:766-797, sample-0 quirk kept) */
-    /* Non-default architecture variants (models.py:108-133,145-166,456-648): must be 0 (resblock, stay_sixth, p2pc_conv and pc2p_mem excepted),
+    /* Non-default architecture variants (models.py:108-133,145-166,456-648): only_semitones must be 0 (it does not run in the reference either),
      * ake_pcnet_create returns AKE_ERR_UNSUPPORTED otherwise. */
     int resblock;       /* opt.resblock (models.py:181-187, 218-224, 402-454): 1 builds the residual-block stacks; inference only */
-    int denseblock;
+    int denseblock;     /* opt.denseblock (models.py:188-189, 225-226, 456-648): 1 builds the DenseNet-style stacks (pre-activation BatchNorm applied on
+                         * load, 1-wide bottlenecks, features concatenated in place); not combinable with the other variants; inference only */
     int stay_sixth;     /* opt.stay_sixth (models.py:322-323, 336, 366-367): 1 keeps the pitch stream at semitone resolution after layer 0; inference only */
     int only_semitones;
     int p2pc_conv;      /* opt.p2pc_conv (models.py:108-133): 1 folds the octaves with a learned dilated conv + BN + LeakyReLU instead of the max; inference only */
