@@ -70,6 +70,27 @@ def test_ragged_pipeline_equals_per_clip_pipeline(net):
     assert (t1[1] - t1[0]).abs().max() > 0 and not torch.equal(mel[1], mel[0])  # the clips do differ
 
 
+def test_two_streams_give_the_same_results(net):
+    """KeyEstimator(streams=2): consecutive calls run on two side streams with a workspace each (one batch's CQT under another's
+    convolutions); every call's outputs must equal the single-stream call's bit for bit, ragged batches included."""
+    est1 = ake_amd.KeyEstimator(net, 22050, 5)
+    est2 = ake_amd.KeyEstimator(net, 22050, 5, streams=2)
+    batches = []
+    for i in range(5):
+        audio, _ = synthetic.make_batch_device(range(7 * i, 7 * i + 6), torch.device(DEV))
+        batches.append(audio[:, : 330750 - 4410 * i].contiguous())
+    lengths = torch.tensor([300000, 250000, 200000, 150000, 120000, 290000], device=DEV)
+    outs = [est2(a) for a in batches] + [est2(batches[0], lengths)]
+    est2.join()
+    torch.cuda.synchronize()
+    want = [est1(a) for a in batches] + [est1(batches[0], lengths)]
+    for got, ref in zip(outs, want):
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+    assert est2._slots[0]["stream"] is not None and est2._slots[1]["stream"] is not None
+    assert est2._slots[0]["ws"].data_ptr() != est2._slots[1]["ws"].data_ptr()
+
+
 def test_config5_sharded_equivariance_two_ranks():
     """BASELINE configs[4] / SURVEY 8d config 5: the 25 shifted guard-octave inputs dealt to two ranks (both on this GPU, gloo for
     the gather), roll identity <= 1e-5 and equality with the reference's table asserted by the tool itself."""
