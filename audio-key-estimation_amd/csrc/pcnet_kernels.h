@@ -1035,16 +1035,9 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         __syncthreads();              // ... every wave's; and every wave is done with the other half
         const bool more = tile + nwg < a.n_tiles;
-        if (more) {
-            if (IN_NCHW) load_regs(tile + nwg);
-            else issue_loads(tile + nwg, cur ^ 1);
-        }
         if (has_prev) {
             if (OUT_SEMI) semi_stage(cur ^ 1, prev_base, prev_mblk);
-            else {
-                if (late) epilogue(acc, 0);
-                store_pending();
-            }
+            else if (late) epilogue(acc, 0);
         }
         const uint4* const pH = lds4 + (cur * 2) * a.plane_pos;
         const uint4* const pL = pH + a.plane_pos;
@@ -1052,6 +1045,14 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
         for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 14; ++ks) {
+            // the next tile's loads and the previous tile's stores are issued from inside the multiply loop rather than in front of it,
+            // where both waves of a SIMD sit right after the barrier with the matrix pipe idle (-2 % per launch; switched off
+            // altogether, loads and stores account for 11 + 15 us of a 128 us launch wherever they are placed -- see DESIGN.md)
+            if (ks == 2 && more) {
+                if (IN_NCHW) load_regs(tile + nwg);
+                else issue_loads(tile + nwg, cur ^ 1);
+            }
+            if (ks == 6 && !OUT_SEMI && has_prev) store_pending();
             const int dy = ks >> 1, h = ks & 1;
             const bf16x8c bh = __builtin_bit_cast(bf16x8c, breg[2 * ks]), bl = __builtin_bit_cast(bf16x8c, breg[2 * ks + 1]);
             bf16x8c ah[MT], al[MT];
