@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""MFMA utilisation per kernel from one rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY
+SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE) taken together with --kernel-trace:
+
+    python3 tools/mfma_util.py <dir with */*_counter_collection.csv and */*_kernel_trace.csv> [out.md]
+
+Units as /opt/skills/guides/MI355X_MICROARCH.md states them: SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles summed over the SIMDs
+(16 per v_mfma_f32_16x16x32_bf16), SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over the waves,
+GRBM_GUI_ACTIVE counts cycles per XCD (8 of them).  MFMA utilisation = MFMA busy cycles / (kernel cycles x 1024 SIMDs), kernel cycles =
+GRBM_GUI_ACTIVE / 8; effective clock = kernel cycles / traced duration."""
+import csv, glob, sys
+from collections import defaultdict
+
+d = sys.argv[1]
+cc = glob.glob(d + "/*/*counter_collection.csv")[0]
+kt = glob.glob(d + "/*/*kernel_trace.csv")[0]
+dur = {}
+for r in csv.DictReader(open(kt)):
+    dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+per = defaultdict(lambda: defaultdict(dict))          # kernel -> dispatch -> counter -> value
+for r in csv.DictReader(open(cc)):
+    name = r["Kernel_Name"]
+    if "ake_k::" not in name and "cqt_" not in name:
+        continue
+    short = name.replace("void ", "").replace("ake_k::", "").split("(")[0][:48]
+    per[short + "|grid=" + r["Grid_Size"]][r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+rows = []
+for k, disp in per.items():
+    n = len(disp)
+    mean = lambda c: sum(v.get(c, 0.0) for v in disp.values()) / n
+    ns = sum(dur.get(i, 0) for i in disp) / n
+    cyc = mean("GRBM_GUI_ACTIVE") / 8.0
+    if cyc <= 0 or ns <= 0:
+        continue
+    wave_q = mean("SQ_WAVE_CYCLES")
+    rows.append((ns, k, n, cyc / ns, mean("SQ_VALU_MFMA_BUSY_CYCLES") / (cyc * 1024.0), mean("SQ_VALU_MFMA_COEXEC_CYCLES") / (cyc * 1024.0),
+                 mean("SQ_WAIT_ANY") / wave_q if wave_q else 0, mean("SQ_WAIT_INST_ANY") / wave_q if wave_q else 0,
+                 mean("SQ_ACTIVE_INST_ANY") / wave_q if wave_q else 0, mean("SQ_INSTS_VALU"), mean("SQ_VALU_MFMA_BUSY_CYCLES")))
+rows.sort(reverse=True)
+out = ["| kernel (grid) | launches | avg us (under the profiler) | clock GHz | MFMA busy | MFMA + VALU together | waves parked (waitcnt / barrier) | issue stalls | issuing | VALU instructions | MFMA busy cycles |",
+       "|---|---|---|---|---|---|---|---|---|---|---|"]
+for ns, k, n, ghz, util, coex, w_any, w_inst, act, valu, busy in rows:
+    out.append(f"| `{k}` | {n} | {ns / 1e3:.1f} | {ghz:.2f} | {util:.3f} | {coex:.3f} | {w_any:.2f} | {w_inst:.2f} | {act:.2f} | {valu / 1e6:.2f} M | {busy / 1e6:.1f} M |")
+text = "\n".join(out)
+print(text)
+if len(sys.argv) > 2:
+    with open(sys.argv[2], "w") as f:
+        f.write("# MFMA utilisation of the network kernels (rocprofv3 --pmc, one pass)\n\n"
+                "Command: `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
+                "SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 tools/net_only.py 3`\n"
+                "(256 clips x 76 frames; counters serialise the dispatches, durations are longer than in the bench).  Columns: see tools/mfma_util.py.\n\n" + text + "\n")
