@@ -49,6 +49,7 @@ struct PackedConv {          // device-resident folded + packed convolution
     size_t w_off = 0, b_off = 0;   // float offsets into the blob (VALU layout [group][ci][dy][dx][CO])
     // f32-MFMA fragment layout [ci][dy][s][ntile][64 lanes] (Toeplitz over TB frames), see pcnet_kernels.h
     int tb = 0, ku = 0, ntiles = 0, nt = 1;
+    int row_k = 0;                 // 1: 12 x 1 kernel in the row-k fragment form (k = four consecutive rows, kh / 4 steps per channel)
     size_t f_off = 0;
     long long bf_off = -1;         // 16-byte offset of the bf16x3 fragments in ake_pcnet::bf_frags_dev (8 -> 8 channel 7x7 pitch convs), or -1
     long long l0_off = -1;         // ... of the layer-0 form (layer0_mfma_kernel: <= 4 channels, 12 x 7), or -1
@@ -257,6 +258,29 @@ PackedConv dense_conv_pack(ake_pcnet* n, const std::string& wkey, const std::str
         else w[r * 7 + 3] = w32[r];
     }
     if (!bkey.empty()) { const auto& b32 = T(n, bkey); for (int co = 0; co < cout; ++co) b[co] = b32[co]; }
+    if (kw_src == 1 && kh % 4 == 0) {   // 12 x 1: fragments [ci][row group g < kh / 4][ntile][64 lanes], lane = (k = row 4g + (l >> 4), n = co)
+        PackedConv p;
+        p.cin = cin; p.cout = cout; p.kh = kh; p.kw = 1; p.co = pick_co(cout); p.groups = (cout + p.co - 1) / p.co;
+        p.tb = 1; p.ku = 4; p.ntiles = (cout + 15) / 16; p.nt = 1; p.row_k = 1;
+        auto& blob = n->blob;
+        blob.resize(ake::align_up(blob.size(), 64));
+        p.w_off = blob.size();                                   // (no VALU-layout copy: only the MFMA kernel runs this form)
+        p.b_off = blob.size();
+        blob.resize(blob.size() + static_cast<size_t>(p.groups) * p.co, 0.f);
+        for (int co = 0; co < cout; ++co) blob[p.b_off + co] = static_cast<float>(b[co]);
+        blob.resize(ake::align_up(blob.size(), 64));
+        p.f_off = blob.size();
+        const int steps = kh / 4;
+        blob.resize(blob.size() + static_cast<size_t>(cin + 1) * steps * p.ntiles * 64, 0.f);   // + one channel of zero padding (prefetch)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int g = 0; g < steps; ++g)
+                for (int nt = 0; nt < p.ntiles; ++nt)
+                    for (int l = 0; l < 64; ++l) {
+                        const int dy = 4 * g + (l >> 4), co = nt * 16 + (l & 15);
+                        if (co < cout) blob[p.f_off + ((static_cast<size_t>(ci) * steps + g) * p.ntiles + nt) * 64 + l] = static_cast<float>(w32[(static_cast<size_t>(co) * cin + ci) * kh + dy]);
+                    }
+        return p;
+    }
     return pack_conv(n, w, b, cout, cin, kh, 7);
 }
 
@@ -321,6 +345,7 @@ int launch_mfma_t(const PackedConv& pc, const MfmaArgs& a, int MT, dim3 grid, di
     if (pc.ku == 8 && pc.nt == 2) { AKE_MFMA(8, 2, 3); }
     if (pc.ku == 12 && pc.nt == 1) { AKE_MFMA(12, 1, 3); }
     if (pc.ku == 24 && pc.nt == 1) { AKE_MFMA(24, 1, 3); }
+    if (pc.ku == 4 && pc.nt == 1) { AKE_MFMA(4, 1, 3); }
 #undef AKE_MFMA
     ake::set_error("conv: no MFMA kernel for KU=%d NT=%d", pc.ku, pc.nt);
     return AKE_ERR_UNSUPPORTED;
@@ -349,7 +374,7 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
              const float* residual = nullptr, bool rows_zero = false) {
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
-    AKE_REQUIRE(pc.kw == 7, AKE_ERR_UNSUPPORTED, "conv: kernel width %d not built (only 7)", pc.kw);
+    AKE_REQUIRE(pc.kw == 7 || pc.row_k, AKE_ERR_UNSUPPORTED, "conv: kernel width %d not built (only 7)", pc.kw);
     AKE_REQUIRE(src.c0 + src.c1 == pc.cin, AKE_ERR_STATE, "conv %s: cin mismatch", name);
     a.src0 = src.p0; a.c0 = src.c0; a.src1 = src.p1; a.c1 = src.c1; a.h1 = src.h1 > 0 ? src.h1 : 1;
     a.H = H; a.T_in = T_in;
@@ -380,7 +405,8 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
     a.R = t.R; a.TT = t.TT; a.Tp = t.Tp; a.n_row_tiles = t.n_row_tiles; a.n_time_tiles = t.n_time_tiles;
     a.w = n->blob_dev + pc.f_off;
     MfmaArgs ma;
-    ma.c = a; ma.TB = pc.tb; ma.KH = pc.kh; ma.ntiles_total = pc.ntiles; ma.cin_chunk = mtile.cin_chunk;
+    ma.c = a; ma.TB = pc.tb; ma.KH = pc.row_k ? pc.kh / 4 : pc.kh; ma.ntiles_total = pc.ntiles; ma.cin_chunk = mtile.cin_chunk;
+    ma.row_k = pc.row_k;
     ma.ksplit = 0;
     ma.h1_magic = (65536 + a.h1 - 1) / a.h1;
     static const int ablate = std::getenv("AKE_ABLATE") ? std::atoi(std::getenv("AKE_ABLATE")) : 0;

@@ -305,6 +305,8 @@ struct MfmaArgs {
     int cin_chunk;        // input channels staged in LDS at a time
     int h1_magic;         // ceil(2^16 / h1): (row * h1_magic) >> 16 == row / h1 for the row counts used here
     int dbg;              // ablation (AKE_ABLATE): 1 = skip the MFMA steps, 2 = skip the staging loads (results wrong, timing only)
+    int row_k;            // 1: 1-wide kernels over KH = 4 * (steps per channel) circular rows (--denseblock's 12 x 1 bottleneck): the four k
+                          //    of a step are four consecutive ROWS of one frame instead of four taps of one row; `KH` counts steps
     int ksplit;           // 1: the layer has <= MT M-tiles per workgroup (1-channel head convs): all waves share them and
                           //    split the (channel, dy) steps of every chunk (step = wave, wave + W, ...); partial sums are
                           //    reduced through LDS
@@ -323,8 +325,9 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
     const int clip = blockIdx.z;
     const int y0 = row_tile * a.R;
     const int t0 = time_tile * a.TT;
-    const int R_in = a.R + KH - 1;               // patch rows: the row halo is always materialised (wrapped rows are copied)
+    const int R_in = a.R + (ma.row_k ? 4 * KH : KH) - 1;   // patch rows: the row halo is always materialised (wrapped rows are copied)
     const int Tp = a.Tp;
+    const int rstep = ma.row_k ? 4 * Tp : Tp;    // LDS floats from one step of a channel to the next
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
         int m = (grp * MT + mt) * 16 + r16;
         if (m >= Mblk) m = Mblk - 1;
         const int r = m / J, j = m - r * J;
-        abase[mt] = r * Tp + TB * j + q;
+        abase[mt] = r * Tp + TB * j + (ma.row_k ? q * Tp : q);
     }
     // two independent accumulator chains per tile (even / odd k-steps): back-to-back MFMAs never depend on each other
     f32x4 acc[MT][NT], acc2[MT][NT];
@@ -483,16 +486,16 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
         const int nsteps = (steps_total - first + sstride - 1) / sstride;
         int pf_dy = first, pf_cl = 0;
         while (pf_dy >= KH) { pf_dy -= KH; ++pf_cl; }
-        int a_off = pf_cl * cstride + pf_dy * Tp, b_off = first * GF;
+        int a_off = pf_cl * cstride + pf_dy * rstep, b_off = first * GF;
         float Ac[KS][MT], Bc[KS][NT];
         load_a(Ac, a_off);
         load_b(Bc, b_off);
         for (int st = 0; st < nsteps; ++st) {
             if (st + 1 < nsteps) {                                       // (the last iteration re-fetches its own step)
                 pf_dy += sstride;
-                a_off += sstride * Tp;
+                a_off += sstride * rstep;
                 b_off += sstride * GF;
-                while (pf_dy >= KH) { pf_dy -= KH; a_off += cstride - KH * Tp; }
+                while (pf_dy >= KH) { pf_dy -= KH; a_off += cstride - KH * rstep; }
             }
             float An[KS][MT], Bn[KS][NT];
             load_a(An, a_off);
