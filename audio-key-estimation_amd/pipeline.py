@@ -59,6 +59,8 @@ class KeyEstimator:
             with torch.cuda.stream(slot["stream"]):
                 out = self._run(slot, audio, lengths)
         self._pending.extend(out)
+        if len(self._pending) > 96:                      # a caller that never joins must not grow this list without bound
+            self._pending = self._pending[-96:]
         return out
 
     def _run(self, slot, audio, lengths):
