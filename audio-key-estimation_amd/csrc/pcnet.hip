@@ -597,7 +597,7 @@ bool pc2pc_fuses(const ake_pcnet* n, int i, int T) {
     if (!pc2pc_uses_bf16(n, i, T) || T % 4 || 12 * T > 1024) return false;
     for (const PackedConv& pc : n->pc2pc[i])
         if (pc.cout != 16 || pc.cin > 16 || pc.kh != 12) return false;
-    return static_cast<size_t>(4) * 12 * (T + 8) * 2 * sizeof(uint4) <= 150 * 1024;
+    return (static_cast<size_t>(4) * 12 * (T + 8) * 2 + 2 * 512) * sizeof(uint4) <= 160 * 1024;     // two maps + the weight ring
 }
 
 int run_pc2pc_fused(const ake_pcnet* n, int i, const float* src, int cin, int batch, int T, float* pooled, unsigned short* feat_cl, hipStream_t s) {
@@ -609,10 +609,10 @@ int run_pc2pc_fused(const ake_pcnet* n, int i, const float* src, int cin, int ba
     a.pooled = pooled;
     if (feat_cl) { a.fh = feat_cl; a.fl = feat_cl + static_cast<long long>(batch) * 12 * (T / 2) * 16; }
     a.T = T; a.Tp = T + 8;
-    const size_t lds = static_cast<size_t>(4) * 12 * a.Tp * 2 * sizeof(uint4);
+    const size_t lds = (static_cast<size_t>(4) * 12 * a.Tp * 2 + 2 * 512) * sizeof(uint4);
     static bool attr_set = false;
     if (!attr_set) {
-        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc2pc_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc2pc_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     ake::ProfScope ps("pc2pc_fused_kernel", s);

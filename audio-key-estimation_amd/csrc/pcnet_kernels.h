@@ -1276,7 +1276,13 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
     const int n16 = 12 * Tp * 2;                              // uint4 per plane
     uint4* const map0 = lds4;                                 // two maps, each: hi plane, lo plane
     uint4* const map1 = lds4 + 2 * n16;
+    // weight fragments of one kernel row dy (4 k-steps x (hi | lo) x 64 lanes = 8 KB), double-buffered: the workgroup fetches every
+    // fragment ONCE and its 16 waves read it from here.  Streamed per wave from L1 they were 16 x 2 KB per k-step -- two thirds of the
+    // L1's 64 B / clk next to 768 cycles of MFMAs -- and 49 of the launch's 130 us (measured by leaving the loads out)
+    uint4* const wring = lds4 + 4 * n16;
+    constexpr int kRow = 4 * 2 * 64;                          // uint4 per kernel row
     for (int i = threadIdx.x; i < 4 * n16; i += 1024) lds4[i] = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < kRow) wring[threadIdx.x] = a.bfrag[0][threadIdx.x];
     __syncthreads();
     {   // input: NCHW f32 -> split channels-last, frame t at patch position t + 3
         const float* src = a.src + clip * a.src_clip_stride;
@@ -1325,14 +1331,19 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
         //  and every load from it then drains the weight prefetch)
         const uint4* const bfrag_j = j == 0 ? a.bfrag[0] : (j == 1 ? a.bfrag[1] : (j == 2 ? a.bfrag[2] : a.bfrag[3]));
         const float* const bias_j = j == 0 ? a.bias[0] : (j == 1 ? a.bias[1] : (j == 2 ? a.bias[2] : a.bias[3]));
-        if (active) {
+        const uint4* const bfrag_n = j == 0 ? a.bfrag[1] : (j == 1 ? a.bfrag[2] : a.bfrag[3]);     // the next convolution's (if any)
+        {
             f32x4c acc[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
-            const uint4* __restrict__ bg = bfrag_j + lane;
-            uint4 nbh = bg[0], nbl = bg[64];
 #pragma unroll 1
             for (int dy = 0; dy < 12; ++dy) {   // (not unrolled: with all 48 k-steps in one block hipcc serialises every load against its MFMA)
+                // the next kernel row's fragments travel to registers during this row's MFMAs and into the other half of the ring after them
+                uint4 wpre = make_uint4(0, 0, 0, 0);
+                const bool fetch = threadIdx.x < kRow && (dy + 1 < 12 || j + 1 < a.n_conv);
+                if (fetch) wpre = dy + 1 < 12 ? bfrag_j[(dy + 1) * kRow + threadIdx.x] : bfrag_n[threadIdx.x];
+                const uint4* const wr = wring + (dy & 1) * kRow + lane;
+                if (active) {
                 int rowoff[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -1343,9 +1354,7 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int ks = dy * 4 + p;
-                    const bf16x8c bh = __builtin_bit_cast(bf16x8c, nbh), bl = __builtin_bit_cast(bf16x8c, nbl);
-                    const int kn = ks + 1 < 48 ? ks + 1 : ks;            // next k-step's weights, in flight during this one's MFMAs
-                    nbh = bg[(kn * 2 + 0) * 64]; nbl = bg[(kn * 2 + 1) * 64];
+                    const bf16x8c bh = __builtin_bit_cast(bf16x8c, wr[(p * 2 + 0) * 64]), bl = __builtin_bit_cast(bf16x8c, wr[(p * 2 + 1) * 64]);
                     bf16x8c ah[MT], al[MT];
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
@@ -1359,7 +1368,12 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt], 0, 0, 0);
                 }
+                }
+                // (12 is even: row 11 read half 1, so the next convolution's row 0 lands in half 0, where it expects it)
+                if (fetch) wring[((dy + 1) & 1) * kRow + threadIdx.x] = wpre;
+                if (dy + 1 < 12) __syncthreads();             // (after the last row the barrier at the end of the convolution serves)
             }
+            if (active) {
             // ---- epilogue: D[row m = 4q + i][col = co]; T % 4 == 0: the four positions of a lane share a row, frames t0 .. t0 + 3 ----
             const int co = r16;
             const float bias = bias_j[co];
@@ -1397,6 +1411,7 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
                         }
                     }
                 }
+            }
             }
         }
         __syncthreads();
