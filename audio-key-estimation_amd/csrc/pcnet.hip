@@ -644,7 +644,7 @@ int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
         a.bfrag2 = n->bf_frags_dev + pc2->bf_off; a.bias2 = n->blob_dev + pc2->b_off;
         a.oh2 = planes_out2; a.ol2 = planes_out2 + static_cast<long long>(batch) * H_out * a.T_out * pc.cout;
     }
-    const size_t lds = static_cast<size_t>(2) * 12 * a.Tp * 2 * sizeof(uint4);
+    const size_t lds = (static_cast<size_t>(2) * 12 * a.Tp * 2 + 2 * 4 * (pc.cout / 16) * 2 * 64) * sizeof(uint4);   // patch + weight ring
     AKE_REQUIRE(lds <= 150 * 1024, AKE_ERR_UNSUPPORTED, "conv %s: %d frames do not fit the bf16 kernel's LDS patch", name, T_in);
     static bool attr_set = false;
     if (!attr_set) {

@@ -1136,9 +1136,25 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
     constexpr int MT = 4;
     const int H_out = a.circular ? 12 : 12 - a.KH + 1;
     const int Mtot = H_out * a.T_out;
-    const int nks = a.KH * 4;
     uint4* const pH = lds4;                                  // [12][Tp][2 halves of 8 channels]
     uint4* const pL = lds4 + 12 * Tp * 2;
+    // weight fragments of one kernel row (4 k-steps x NT x (hi | lo) x 64 lanes), double-buffered: fetched ONCE per workgroup by LDS-DMA,
+    // one row ahead, and read from here by every wave (streamed per wave from L1 they cost a third of the fused stack's time, see
+    // pc2pc_fused_kernel)
+    uint4* const wring = lds4 + 2 * 12 * Tp * 2;
+    constexpr int kRow = 4 * NT * 2 * 64;                    // uint4 per kernel row
+    const bool second = blockIdx.y == 1;
+    const uint4* const bfr = second ? a.bfrag2 : a.bfrag;
+    auto fetch_row = [&](int dyn) {                          // pieces of 64 lanes x 16 bytes, dealt to the waves
+        for (int pc = wave; pc < kRow / 64; pc += nw) {
+            const uint4* src = bfr + dyn * kRow + pc * 64 + lane;
+            const unsigned int lds_dst = static_cast<unsigned int>(reinterpret_cast<unsigned long long>(wring + (dyn & 1) * kRow + pc * 64));
+            unsigned int keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+        }
+    };
+    fetch_row(0);
     {   // patch frame f <-> input frame f - pad_l, zeros outside [0, T_in)
         const long long cbase = static_cast<long long>(clip) * 12 * a.T_in * 2;
         const uint4* gh = reinterpret_cast<const uint4*>(a.xh) + cbase;
@@ -1156,9 +1172,10 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
             pH[i] = vh; pL[i] = vl;
         }
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): this wave's share of row 0 has landed
     __syncthreads();
     const int tile0 = (blockIdx.x * nw + wave) * MT;          // first M-tile of this wave
-    if (tile0 * 16 >= Mtot) return;
+    const bool active = tile0 * 16 < Mtot;                    // (idle waves still fetch and meet the barriers)
     int ay[MT], at[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -1173,13 +1190,11 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4c{0.f, 0.f, 0.f, 0.f};
-    const bool second = blockIdx.y == 1;
-    const uint4* __restrict__ bg = (second ? a.bfrag2 : a.bfrag) + lane;
-    uint4 nbh[NT], nbl[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { nbh[nt] = bg[(nt * 2 + 0) * 64]; nbl[nt] = bg[(nt * 2 + 1) * 64]; }
     const int dxq = q >> 1, half = q & 1;
     for (int dy = 0; dy < a.KH; ++dy) {
+        if (dy + 1 < a.KH) fetch_row(dy + 1);                 // lands in the other half during this row's MFMAs
+        const uint4* const wr = wring + (dy & 1) * kRow + lane;
+        if (active) {
         int rowoff[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -1189,13 +1204,12 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int ks = dy * 4 + p;
             bf16x8c bh[NT], bl[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) { bh[nt] = __builtin_bit_cast(bf16x8c, nbh[nt]); bl[nt] = __builtin_bit_cast(bf16x8c, nbl[nt]); }
-            const int kn = ks + 1 < nks ? ks + 1 : ks;                // next k-step's weights, in flight during this one's MFMAs
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) { nbh[nt] = bg[((kn * NT + nt) * 2 + 0) * 64]; nbl[nt] = bg[((kn * NT + nt) * 2 + 1) * 64]; }
+            for (int nt = 0; nt < NT; ++nt) {
+                bh[nt] = __builtin_bit_cast(bf16x8c, wr[((p * NT + nt) * 2 + 0) * 64]);
+                bl[nt] = __builtin_bit_cast(bf16x8c, wr[((p * NT + nt) * 2 + 1) * 64]);
+            }
             bf16x8c ah[MT], al[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -1212,7 +1226,13 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
                 for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
             }
         }
+        }
+        if (dy + 1 < a.KH) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);               // this wave's share of the next row has landed ...
+            __syncthreads();                                  // ... everybody's; and everybody is done with this row's half
+        }
     }
+    if (!active) return;
     // ---- epilogue: D[row m = 4q + i][col = co within the N-tile] ----
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -1353,7 +1373,6 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
                 }
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    const int ks = dy * 4 + p;
                     const bf16x8c bh = __builtin_bit_cast(bf16x8c, wr[(p * 2 + 0) * 64]), bl = __builtin_bit_cast(bf16x8c, wr[(p * 2 + 1) * 64]);
                     bf16x8c ah[MT], al[MT];
 #pragma unroll
