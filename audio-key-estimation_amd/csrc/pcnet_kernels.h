@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
 //   n = output channel (NT tiles of 16)  B[k][n] = w[co][ci][dy][dx]
 //   k-step = (dy, tap pair p): lane q holds tap dx = 2p + (q >> 1), channels 8 (q & 1) .. +7   -> 12 x 4 = 48 k-steps (dx = 7 is
 //   a zero tap), three MFMAs per k-step, M-tile and N-tile.  The whole clip (12 rows, all frames) is one LDS patch; the weight
-//   fragments (96 KB per N-tile) stream from L2 one k-step ahead.
+//   fragments (96 KB per N-tile) come through a double-buffered LDS ring, one kernel row (4 k-steps) ahead, fetched once per workgroup.
 // ==========================================================================================
 struct PcBfArgs {
     const unsigned short* xh;     // [clip][12][T_in][16]
