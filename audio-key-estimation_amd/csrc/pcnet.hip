@@ -2046,6 +2046,7 @@ struct Fwd {
                             {&n->head_tonic, &n->head_tonic_t, b.hid_t, b.map_t, 1, "tonic_classifier"},
                             {&n->head_genre, &n->head_genre_t, b.hid_g, b.map_g, 2, "genre_classifier"}};
         int Tm = Tf;
+        int pooled_heads = 0;                     // heads whose outputs conv_head1_bf16_kernel already wrote
         // key / tonic heads: the first convolution (16 -> 32 channels, most of a head's work) on the bf16 kernel; both read the same
         // channels-last copy of the features
         unsigned short* feat_cl = b.feat_cl;
@@ -2079,7 +2080,16 @@ struct Fwd {
             }
             ha.T_in = T1; ha.T_out = T2; ha.JB = (T2 + 15) / 16; ha.Tp = 16 * (ha.JB - 1) + 22;
             // the patch, and after the multiply loop the partial tiles of the 8 waves in the same bytes (two workgroups per CU fit)
-            const size_t lds = std::max(static_cast<size_t>(2) * 12 * ha.Tp * 4 * sizeof(uint4), static_cast<size_t>(8) * kHead1MT * 4 * 64 * sizeof(float));
+            size_t lds = std::max(static_cast<size_t>(2) * 12 * ha.Tp * 4 * sizeof(uint4), static_cast<size_t>(8) * kHead1MT * 4 * 64 * sizeof(float));
+            if (c.local == 0) {   // the masked mean + sigmoid of each finished map in the same launch (its LDS copy sits behind the patch / partial tiles)
+                ha.fin_off = static_cast<int>(lds / sizeof(float));
+                lds += static_cast<size_t>(12) * T2 * sizeof(float);
+                float* outs[3] = {key_out, tonic_out, genre_out};
+                for (int h = 0; h < nh; ++h) ha.pout[h] = outs[h];
+                ha.seq = reinterpret_cast<const long long*>(seq);
+                ha.n_pool_layers = L - 1; ha.tp = tp; ha.shrink = (c.kernel_size - 1) * c.head_layers; ha.max_pool = c.max_pool; ha.clip0 = 0;
+                pooled_heads = nh;
+            }
             static bool h1_attr = false;
             if (!h1_attr) {
                 AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head1_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -2129,6 +2139,8 @@ struct Fwd {
         PoolHeadArgs pa;
         std::memset(&pa, 0, sizeof(pa));
         pa.maps[0] = b.map_k; pa.maps[1] = b.map_t; pa.maps[2] = c.genre ? b.map_g : nullptr;
+        for (int h = 0; h < pooled_heads; ++h) pa.maps[h] = nullptr;
+        if (!pa.maps[0] && !pa.maps[1] && !pa.maps[2]) return AKE_OK;
         pa.outs[0] = key_out; pa.outs[1] = tonic_out; pa.outs[2] = genre_out;
         pa.rows[0] = 12; pa.rows[1] = 12; pa.rows[2] = 11;
         pa.Tm = Tm; pa.seq = reinterpret_cast<const long long*>(seq);

@@ -217,6 +217,20 @@ struct PoolHeadArgs {
     int clip0;                // global index of the first clip of this chunk (for the max_pool sample-0 quirk)
 };
 
+// frames pooled for `clip` (models.py:754-785) and whether the maximum is taken instead of the mean
+__device__ __forceinline__ int pool_frames(const long long* seq, int clip, int Tm, int n_pool_layers, int tp, int shrink, int clip0, bool* use_max) {
+    int L = Tm;
+    if (seq) {
+        long long l = seq[clip];
+        for (int k = 0; k < n_pool_layers; ++k) l = l / tp;          // floor (models.py:759)
+        L = static_cast<int>(l) - shrink;                             // models.py:760
+        if (L > Tm) L = Tm;                                           // x[..., :L] clamps at the end ...
+        if (L < 0) L = Tm + L > 0 ? Tm + L : 0;                       // ... and counts from the end when negative
+        *use_max = *use_max && (clip0 + clip == 0);                   // models.py:764-785 quirk
+    }
+    return L;
+}
+
 __global__ void head_pool_kernel(PoolHeadArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int which = blockIdx.y;
@@ -224,16 +238,8 @@ __global__ void head_pool_kernel(PoolHeadArgs a) {
     const int rows = a.rows[which];
     if (i >= a.batch * rows) return;
     const int clip = i / rows;
-    int L = a.Tm;
     bool use_max = a.max_pool != 0;
-    if (a.seq) {
-        long long l = a.seq[clip];
-        for (int k = 0; k < a.n_pool_layers; ++k) l = l / a.tp;      // floor (models.py:759)
-        L = static_cast<int>(l) - a.shrink;                           // models.py:760
-        if (L > a.Tm) L = a.Tm;                                       // x[..., :L] clamps at the end ...
-        if (L < 0) L = a.Tm + L > 0 ? a.Tm + L : 0;                   // ... and counts from the end when negative
-        use_max = use_max && (a.clip0 + clip == 0);                   // models.py:764-785 quirk
-    }
+    const int L = pool_frames(a.seq, clip, a.Tm, a.n_pool_layers, a.tp, a.shrink, a.clip0, &use_max);
     const float* m = a.maps[which] + static_cast<long long>(i) * a.Tm;
     float v;
     if (use_max) {
@@ -1454,6 +1460,11 @@ struct Head1BfArgs {
     float* dst[3];                // per head: [clip][H_out][T_out]
     int KH[3], H_out[3], circular[3];   // key / tonic: 12 rows over circular pitch classes; genre: 2 rows, valid (11 output rows)
     int T_in, T_out, Tp, JB;
+    // masked temporal mean + sigmoid of the finished map (models.py:754-804) in the same launch: pout[head] = [clip][H_out] or null
+    float* pout[3];
+    const long long* seq;
+    int n_pool_layers, tp, shrink, max_pool, clip0;
+    int fin_off;                  // float offset of the finished map's LDS copy [H_out][T_out] (behind the reduction buffer)
 };
 
 constexpr int kHead1MT = 4;       // M-tiles (12 * JB positions / 16): T_out <= 80
@@ -1551,8 +1562,29 @@ __global__ __launch_bounds__(512) void conv_head1_bf16_kernel(Head1BfArgs a) {
             const int m = wave * 16 + 4 * q + i;
             const int jb = m / HO, y = m - jb * HO;
             const int t = 16 * jb + r16;
-            if (m < Mtot && t < a.T_out) a.dst[head][(static_cast<long long>(clip) * HO + y) * a.T_out + t] = v;
+            if (m < Mtot && t < a.T_out) {
+                a.dst[head][(static_cast<long long>(clip) * HO + y) * a.T_out + t] = v;
+                if (a.pout[head]) reinterpret_cast<float*>(lds4)[a.fin_off + y * a.T_out + t] = v;
+            }
         }
+    }
+    if (a.pout[head] == nullptr) return;
+    __syncthreads();
+    if (threadIdx.x < HO) {                                   // one lane per output row, as head_pool_kernel
+        bool use_max = a.max_pool != 0;
+        const int L = pool_frames(a.seq, clip, a.T_out, a.n_pool_layers, a.tp, a.shrink, a.clip0, &use_max);
+        const float* m = reinterpret_cast<const float*>(lds4) + a.fin_off + threadIdx.x * a.T_out;
+        float v;
+        if (use_max) {
+            v = -INFINITY;
+            for (int t = 0; t < L; ++t) v = fmaxf(v, m[t]);
+        } else {
+            float sum = 0.f;
+            for (int t = 0; t < L; ++t) sum += m[t];
+            v = sum / static_cast<float>(L > 0 ? L : 0);              // empty slice -> NaN, as torch.mean
+        }
+        if (head == 0) v = 1.f / (1.f + expf(-v));                    // self.sig(key_out), models.py:802
+        a.pout[head][clip * HO + threadIdx.x] = v;
     }
 }
 
