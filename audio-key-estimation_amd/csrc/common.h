@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -43,6 +44,15 @@ struct ProfScope {
     hipStream_t stream;
 };
 bool prof_active();
+
+// One-time setup that must happen once PER DEVICE (hipFuncSetAttribute applies to the current device only; a handle may be
+// recreated on another GPU of the same process).  Racing threads at worst repeat an idempotent call.
+struct DeviceOnce {
+    std::atomic<uint64_t> done{0};
+    static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+    bool need() const { return !((done.load(std::memory_order_acquire) >> dev()) & 1); }
+    void mark() { done.fetch_or(1ull << dev(), std::memory_order_release); }
+};
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -465,12 +465,12 @@ int run_p2p_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short*
     while (a.R > 1 && lds_of(a.R) > 76 * 1024) --a.R;
     AKE_REQUIRE(lds_of(a.R) <= 150 * 1024, AKE_ERR_UNSUPPORTED, "conv %s: %d frames do not fit the bf16 kernel's LDS patch", name, T);
     a.n_row_tiles = (H + a.R - 1) / a.R;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ake::DeviceOnce attr_set;
+    if (attr_set.need()) {
         AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
+        attr_set.mark();
     }
     dim3 grid(a.n_row_tiles, 1, batch), block(512);
     ake::ProfScope ps(name, s);
@@ -549,14 +549,14 @@ bool run_p2p_bf16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sh
     if (dst_nchw && !semi_pc) {   // 16-byte stores of 4 consecutive frames
         if ((a.R * T) % 4 || (static_cast<long long>(H) * T) % 4 || a.dst_clip_stride % 4 || (reinterpret_cast<uintptr_t>(dst_nchw) & 15)) return false;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ake::DeviceOnce attr_set;
+    if (attr_set.need()) {
         const void* fns[] = {reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<1, 0>), reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<1, 5>),
                              reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<1, 8>), reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<0, 0>),
                              reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<2, 0>)};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
-        attr_set = true;
+        attr_set.mark();
     }
     dim3 grid(std::min(n_cus / 8 * 8, (a.n_tiles + 7) / 8 * 8)), block(512);
     ake::ProfScope ps(name, s);
@@ -610,10 +610,10 @@ int run_pc2pc_fused(const ake_pcnet* n, int i, const float* src, int cin, int ba
     if (feat_cl) { a.fh = feat_cl; a.fl = feat_cl + static_cast<long long>(batch) * 12 * (T / 2) * 16; }
     a.T = T; a.Tp = T + 8;
     const size_t lds = (static_cast<size_t>(4) * 12 * a.Tp * 2 + 2 * 512) * sizeof(uint4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ake::DeviceOnce attr_set;
+    if (attr_set.need()) {
         AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc2pc_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set.mark();
     }
     ake::ProfScope ps("pc2pc_fused_kernel", s);
     hipLaunchKernelGGL(pc2pc_fused_kernel, dim3(batch), dim3(1024), lds, s, a);
@@ -646,13 +646,13 @@ int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
     }
     const size_t lds = (static_cast<size_t>(2) * 12 * a.Tp * 2 + 2 * 4 * (pc.cout / 16) * 2 * 64) * sizeof(uint4);   // patch + weight ring
     AKE_REQUIRE(lds <= 150 * 1024, AKE_ERR_UNSUPPORTED, "conv %s: %d frames do not fit the bf16 kernel's LDS patch", name, T_in);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ake::DeviceOnce attr_set;
+    if (attr_set.need()) {
         AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
+        attr_set.mark();
     }
     const int tiles = (H_out * a.T_out + 15) / 16;
     const int waves = std::min(8, (tiles + 3) / 4);
@@ -1755,12 +1755,12 @@ struct Fwd {
         a.uw = n->blob_dev + n->up[1].w_off; a.ub = n->blob_dev + n->up[1].b_off;
         a.fold0 = b.fold0; a.psix = b.psix[1];
         a.H = P; a.T = T0; a.NF = NF; a.n_conv = c.conv_layers;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static ake::DeviceOnce attr_set;
+        if (attr_set.need()) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(layer0_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(layer0_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
                 return false;
-            attr_set = true;
+            attr_set.mark();
         }
         // the convolution stack on bf16 MFMA when the fragments exist and the maps fit (AKE_PC_F32=1: the exact-f32 VALU form)
         bool mfma = !g_pc_f32_only;
@@ -2090,10 +2090,10 @@ struct Fwd {
                 ha.n_pool_layers = L - 1; ha.tp = tp; ha.shrink = (c.kernel_size - 1) * c.head_layers; ha.max_pool = c.max_pool; ha.clip0 = 0;
                 pooled_heads = nh;
             }
-            static bool h1_attr = false;
-            if (!h1_attr) {
+            static ake::DeviceOnce h1_attr;
+            if (h1_attr.need()) {
                 AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head1_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-                h1_attr = true;
+                h1_attr.mark();
             }
             AKE_REQUIRE(lds <= 150 * 1024, AKE_ERR_UNSUPPORTED, "heads: %d frames do not fit conv_head1_bf16_kernel", T1);
             ake::ProfScope ps("conv_head1_bf16_kernel", s);

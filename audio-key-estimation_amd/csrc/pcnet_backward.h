@@ -59,10 +59,10 @@ struct Bwd {
             w.rows_per_wg = (H + wgs_per_clip - 1) / wgs_per_clip;
             dim3 grid((H + w.rows_per_wg - 1) / w.rows_per_wg, 1, B);
             const size_t lds = (static_cast<size_t>(6) * 64 * kWgKP + kWgKP) * sizeof(unsigned short);
-            static bool attr_set = false;
-            if (!attr_set) {
+            static ake::DeviceOnce attr_set;
+            if (attr_set.need()) {
                 AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_p2p_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-                attr_set = true;
+                attr_set.mark();
             }
             ake::ProfScope ps("conv_wgrad_p2p_bf16_kernel", s);
             hipLaunchKernelGGL(conv_wgrad_p2p_bf16_kernel, grid, dim3(256), lds, s, w);

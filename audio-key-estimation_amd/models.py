@@ -208,8 +208,14 @@ class _TrainStep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, x, seq, *params):
-        key, tonic, genre = net._forward_train_raw(x, seq)
-        ctx.net, ctx.x, ctx.seq, ctx.key = net, x, seq, key
+        # The backward kernels read the activations this forward leaves in its workspace, so the workspace belongs to THIS node
+        # until its backward has run (plain autograd keeps the activations per graph, the reference relies on it: two forwards
+        # before one backward, a validation forward in between, a larger batch in between).  It comes from the module's pool of
+        # free training workspaces and goes back there after backward; a node that is dropped without backward frees it.
+        B, Tn = x.shape[0], x.shape[3]
+        ws = net._train_ws_acquire(B, Tn, x.device)
+        key, tonic, genre = net._forward_train_raw(x, seq, ws)
+        ctx.net, ctx.x, ctx.seq, ctx.key, ctx.ws = net, x, seq, key, ws
         ctx.param_meta = [(p.dtype, p.shape) for p in params]
         ctx.set_materialize_grads(True)
         if genre is None:
@@ -218,11 +224,18 @@ class _TrainStep(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_key, d_tonic, d_genre=None):
-        net = ctx.net
-        if net._grads_in_place():
-            net._backward_raw(ctx.x, ctx.seq, ctx.key, d_key, d_tonic, d_genre, into=net._flat_grad)
-            return (None, None, None) + (None,) * len(ctx.param_meta)
-        flat = net._backward_raw(ctx.x, ctx.seq, ctx.key, d_key, d_tonic, d_genre)
+        net, ws = ctx.net, ctx.ws
+        if ws is None:
+            raise _lib.AkeError("backward through the same PitchClassNet forward twice: its activations were released after the first "
+                                "backward (as autograd does without retain_graph)")
+        ctx.ws = None
+        try:
+            if net._grads_in_place():
+                net._backward_raw(ctx.x, ctx.seq, ctx.key, d_key, d_tonic, d_genre, into=net._flat_grad, ws=ws)
+                return (None, None, None) + (None,) * len(ctx.param_meta)
+            flat = net._backward_raw(ctx.x, ctx.seq, ctx.key, d_key, d_tonic, d_genre, ws=ws)
+        finally:
+            net._train_ws_release(ws)
         grads = []
         for (name, _), (dtype, shape) in zip(net.named_parameters(), ctx.param_meta):
             off = net._grad_offsets()[name]
@@ -302,7 +315,9 @@ class PitchClassNet(LightningModule):
         self._h = None
         self._h_device = None
         self._h_stamp = None
-        self._ws = None
+        self._ws = None              # workspace of the forwards that no backward depends on (inference, train mode without autograd)
+        self._ws_last = None         # workspace of the most recent forward (what `tap` reads)
+        self._train_ws_free = []     # training workspaces no autograd node owns at the moment
         self._flat = None            # one float32 device buffer holding every float state_dict entry (layout: ake_pcnet_grad_offset)
         self._flat_grad = None       # same layout; every p.grad is a view of it
         self._attached = False       # parameters/buffers are views of _flat
@@ -453,7 +468,23 @@ class PitchClassNet(LightningModule):
     def _workspace(self, nbytes, device):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
             self._ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        self._ws_last = self._ws
         return self._ws
+
+    def _train_ws_acquire(self, B, Tn, device):
+        """A training workspace that no pending backward reads: the smallest free one that is large enough, else a new one."""
+        nbytes = int(_lib.lib().ake_pcnet_train_workspace_bytes(self._h, B, Tn))
+        fit = [w for w in self._train_ws_free if w.numel() >= nbytes and w.device == device]
+        if fit:
+            ws = min(fit, key=lambda w: w.numel())
+            self._train_ws_free = [w for w in self._train_ws_free if w is not ws]
+            return ws
+        self._train_ws_free = [w for w in self._train_ws_free if w.device == device][-1:]      # drop outgrown buffers, keep at most one
+        return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+
+    def _train_ws_release(self, ws):
+        if len(self._train_ws_free) < 2:
+            self._train_ws_free.append(ws)
 
     @property
     def handle(self):
@@ -543,8 +574,9 @@ class PitchClassNet(LightningModule):
             return key.to(out_dtype), tonic.to(out_dtype), genre.to(out_dtype)
         return key.to(out_dtype), tonic.to(out_dtype)
 
-    def _forward_train_raw(self, x, seq):
-        """x (B,1,P,T) float32 contiguous on the device -> float32 outputs; updates the BatchNorm running statistics."""
+    def _forward_train_raw(self, x, seq, ws=None):
+        """x (B,1,P,T) float32 contiguous on the device -> float32 outputs; updates the BatchNorm running statistics.  ``ws``: the
+        workspace the activations are left in (an autograd node's own, see _TrainStep); default: the module's shared one."""
         device = x.device
         B, _, _, Tn = x.shape
         L = _lib.lib()
@@ -553,7 +585,9 @@ class PitchClassNet(LightningModule):
         genre = torch.empty((B, 11), dtype=torch.float32, device=device) if self.genre else None
         ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(device):
-            ws = self._workspace(L.ake_pcnet_train_workspace_bytes(self._h, B, Tn), device)
+            if ws is None:
+                ws = self._workspace(L.ake_pcnet_train_workspace_bytes(self._h, B, Tn), device)
+            self._ws_last = ws
             n_ch = sum(c for _, c, _ in self._bn_layers())
             stats = torch.empty((n_ch, 3), dtype=torch.float32, device=device)
             _lib.check(L.ake_pcnet_forward_train_f32(self._h, x.data_ptr(), B, Tn, ptr(seq), key.data_ptr(), tonic.data_ptr(),
@@ -576,7 +610,7 @@ class PitchClassNet(LightningModule):
             self.__dict__["_nbt_cache"] = (self._h, [mods[name] for name, _, _ in self._bn_layers()])
         return [m.num_batches_tracked for m in self._nbt_cache[1]]
 
-    _DEVICE_STATE = ("_h", "_h_device", "_h_stamp", "_ws", "_flat", "_flat_grad", "_layout_cache", "_goff_cache", "_bn_cache", "_nbt_cache")
+    _DEVICE_STATE = ("_h", "_h_device", "_h_stamp", "_ws", "_ws_last", "_flat", "_flat_grad", "_layout_cache", "_goff_cache", "_bn_cache", "_nbt_cache")
 
     def __getstate__(self):
         """copy.deepcopy / pickle: the device handle and the flat buffers belong to this object only."""
@@ -584,6 +618,7 @@ class PitchClassNet(LightningModule):
         for k in self._DEVICE_STATE:
             d[k] = None
         d["_attached"] = False
+        d["_train_ws_free"] = []
         return d
 
     def _grad_offsets(self):
@@ -594,8 +629,10 @@ class PitchClassNet(LightningModule):
             self.__dict__["_goff_cache"] = (self._h, offs)
         return self._goff_cache[1]
 
-    def _backward_raw(self, x, seq, key, d_key, d_tonic, d_genre, into=None):
-        """Flat float32 gradient buffer (state_dict order) for the forward that just ran on (x, seq); ``into`` accumulates."""
+    def _backward_raw(self, x, seq, key, d_key, d_tonic, d_genre, into=None, ws=None):
+        """Flat float32 gradient buffer (state_dict order) for the train-mode forward of (x, seq) whose activations are in ``ws``
+        (default: the workspace of the most recent forward); ``into`` accumulates."""
+        ws = ws if ws is not None else self._ws_last
         device = x.device
         B, _, _, Tn = x.shape
         L = _lib.lib()
@@ -607,7 +644,7 @@ class PitchClassNet(LightningModule):
         ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(device):
             _lib.check(L.ake_pcnet_backward_f32(self._h, x.data_ptr(), B, Tn, ptr(seq), key.data_ptr(), d_key.data_ptr(), d_tonic.data_ptr(),
-                                                ptr(d_genre), flat.data_ptr(), 1 if into is not None else 0, self._ws.data_ptr(), self._ws.numel(),
+                                                ptr(d_genre), flat.data_ptr(), 1 if into is not None else 0, ws.data_ptr(), ws.numel(),
                                                 torch.cuda.current_stream().cuda_stream), "ake_pcnet_backward_f32")
         return flat
 
@@ -651,7 +688,7 @@ class PitchClassNet(LightningModule):
         _lib.check(L.ake_pcnet_tap_info(self._h, name.encode(), B, Tn, shape), "ake_pcnet_tap_info")
         out = torch.empty(tuple(shape), dtype=torch.float32, device=self._h_device)
         with torch.cuda.device(self._h_device):
-            _lib.check(L.ake_pcnet_tap_copy(self._h, name.encode(), B, Tn, self._ws.data_ptr(), out.data_ptr(),
+            _lib.check(L.ake_pcnet_tap_copy(self._h, name.encode(), B, Tn, self._ws_last.data_ptr(), out.data_ptr(),
                                             torch.cuda.current_stream().cuda_stream), "ake_pcnet_tap_copy")
         return out
 

@@ -4,6 +4,14 @@ One ``ake_adam_step_f32`` launch over the module's flat parameter buffer replace
 ~100 small tensors; the kernel's arithmetic follows torch's ``_single_tensor_adam`` (tests/test_gpu_training.py compares
 them step by step).  Subclasses ``torch.optim.Optimizer`` so that ``param_groups``, ``zero_grad`` and the
 ``ExponentialLR`` scheduler the reference attaches keep working.
+
+Deviation from ``torch.optim.Adam`` (documented): every trainable element is updated on every step
+with ONE global step count.  torch skips a parameter whose ``.grad`` is None and counts steps per parameter.  On this path a
+gradient is never None: the genre loss is a masked mean on the device (no host sync), so the genre head of a batch without
+genre labels has an exact-zero gradient, as it has in the reference's pinned environment (torch 1.8 / Lightning 1.6.4:
+``zero_grad()`` zero-fills, requirements.txt:235,244) from the first labelled batch on.  The difference is confined to the
+steps BEFORE the first genre-labelled batch (torch: genre head untouched, its bias correction starts later) and to
+``--reg > 0`` there (decay applied here).
 """
 from __future__ import annotations
 
@@ -19,6 +27,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count = 0
         self.grad_scale = 1.0          # e.g. 1/world_size after a summed all-reduce of the flat gradient buffer
         self.exp_avg = self.exp_avg_sq = self._trainable = None
+        self._trainable_names = None
 
     def _buffers(self):
         flat, grad = self.net.flat_parameters()
@@ -27,12 +36,14 @@ class FusedAdam(torch.optim.Optimizer):
                                 "use torch.optim.Adam for other dtypes")
         if self.exp_avg is None or self.exp_avg.data_ptr() == 0 or self.exp_avg.device != flat.device or self.exp_avg.numel() != flat.numel():
             self.exp_avg, self.exp_avg_sq = torch.zeros_like(flat), torch.zeros_like(flat)
+            self._trainable_names = None
+        names = frozenset(n for n, p in self.net.named_parameters() if p.requires_grad)
+        if names != self._trainable_names:                     # requires_grad may change between steps (freezing a head)
             mask = torch.zeros(flat.numel(), dtype=torch.uint8)
-            names = {n for n, p in self.net.named_parameters() if p.requires_grad}
             for name, off, cnt in self.net._layout():
                 if name in names:
                     mask[off:off + cnt] = 1
-            self._trainable = mask.to(flat.device)
+            self._trainable, self._trainable_names = mask.to(flat.device), names
         return flat, grad
 
     @torch.no_grad()

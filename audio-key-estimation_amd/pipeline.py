@@ -27,7 +27,6 @@ class KeyEstimator:
         self.streams = max(1, int(streams))
         self._slots = [{"ws": None, "stream": None} for _ in range(self.streams)]
         self._turn = 0
-        self._pending = []
 
     def join(self):
         """Make the caller's current stream wait for every call issued so far (``streams`` > 1; a no-op otherwise)."""
@@ -37,9 +36,6 @@ class KeyEstimator:
         for slot in self._slots:
             if slot["stream"] is not None:
                 cur.wait_stream(slot["stream"])
-        for t in self._pending:
-            t.record_stream(cur)
-        self._pending = []
 
     @torch.no_grad()
     def __call__(self, audio: torch.Tensor, lengths: torch.Tensor | None = None):
@@ -56,11 +52,15 @@ class KeyEstimator:
             if slot["stream"] is None:
                 slot["stream"] = torch.cuda.Stream(self.device)
             slot["stream"].wait_stream(torch.cuda.current_stream(self.device))      # the inputs were produced on the caller's stream
+            cur = torch.cuda.current_stream(self.device)
             with torch.cuda.stream(slot["stream"]):
                 out = self._run(slot, audio, lengths)
-        self._pending.extend(out)
-        if len(self._pending) > 96:                      # a caller that never joins must not grow this list without bound
-            self._pending = self._pending[-96:]
+            # the outputs were allocated on the side stream and will be read on the caller's: tell the allocator now (nothing to
+            # remember until join(), nothing to drop when a caller never joins)
+            for t in out:
+                if t is not None:
+                    t.record_stream(cur)
+            audio.record_stream(slot["stream"])
         return out
 
     def _run(self, slot, audio, lengths):

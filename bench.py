@@ -16,8 +16,19 @@ Extra objects on the line (tier contract):
                 split-bf16 operands (3 MFMA products per MAC), so `frac_of_split_ceiling` = 3 x frac
                 is the fraction of what this formulation can reach.
   roofline_cqt  the CQT stage against the 8 TB/s HBM peak (1 410 552 algorithmic bytes per clip).
-  cpu_baseline  the CPU oracle (direct-form CQT as BLAS matmuls + the float64 network, the
-                reference's dtype) timed on this box's host cores on a bounded sample.
+  cpu_baseline  the CPU oracle (direct-form CQT as BLAS matmuls + the oracle network) timed on this
+                box's host cores on a bounded sample: BASELINE.md section 3's cases (fp32 / fp64, B = 1 /
+                B = 32, CQT and network separately, best of several thread counts); `value` = the
+                float64 (reference dtype) B = 1 (eval.py's batch size) whole-path rate.
+  parity        max relative error of four clips of the LAST timed step against the CPU oracle
+                (outside the timed region) and a MIREX sanity score of the whole batch.
+  sustained     >= 2 s of steps rotating over >= 4 distinct resident batches (> 256 MiB of audio, so
+                no step is served from the Infinity Cache), with its own ms_per_step and the dominant
+                kernel's mean launch duration at that steady state.
+
+`--gpus N` without a launcher (WORLD_SIZE unset) starts N fresh rank processes itself
+(torch.distributed.run, one per GPU, RCCL) BEFORE this process touches the GPU and relays their
+output; a world size that differs from --gpus is a hard error.
 """
 from __future__ import annotations
 
@@ -49,16 +60,38 @@ PEAK_FP32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
+def kernel_set_hash():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, *.cpp, build.sh): identifies the kernel set a profile was taken with."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(REPO, "audio-key-estimation_amd", "csrc")
+    for p in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.cpp"))
+                    + [os.path.join(csrc, "build.sh")]):
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 counter passes (tools/pmc_traffic.py; FETCH_SIZE x2 on gfx950, see
     DESIGN.md "Measurement").  bench.py cannot collect PMC counters itself (they need the profiler around the process), so the
-    line carries the numbers of the newest profile in profiles/ that was taken with this same command and batch size."""
+    line carries the numbers of the newest profile in profiles/ that was taken with this same command and batch size -- and ONLY
+    if that profile was taken with the kernel sources as they are now (`kernel_set` hash stored by tools/pmc_traffic.py);
+    otherwise -> (name, {}, reason): `traffic` is null and the line says why."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None, {}
+        return None, {}, "no profiles/r*_pmc_traffic.json"
     with open(files[-1]) as f:
-        return os.path.basename(files[-1]), json.load(f)["kernels"]
+        d = json.load(f)
+    name, have, want = os.path.basename(files[-1]), d.get("kernel_set"), kernel_set_hash()
+    if have != want:
+        why = f"STALE: profiles/{name} was taken with kernel set {have}, the sources now hash to {want}; re-run tools/collect_round.sh"
+        print("bench.py: PMC traffic " + why, file=sys.stderr)
+        return name, {}, why
+    return name, d["kernels"], None
 
 
 def load_fixture_weights():
@@ -66,29 +99,97 @@ def load_fixture_weights():
     return {k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("sd/")}
 
 
-def cpu_baseline(sd, n_clips=24, batch=8):
-    """Oracle ("port") on the host cores: same synthetic clips, CQT then network (float64, the reference dtype)."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def _median_time(fn, budget_s, min_iters=1, max_iters=20):
+    """Median wall time of fn() over as many runs as fit the budget (one untimed warm-up first)."""
+    fn()
+    ts, t_end = [], time.perf_counter() + budget_s
+    while len(ts) < max_iters and (len(ts) < min_iters or time.perf_counter() < t_end):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), len(ts)
+
+
+def cpu_baseline(sd, budget_s=20.0):
+    """Oracle ("port") on the host cores, BASELINE.md section 3: the same synthetic clips; float32 and float64 (the reference's
+    dtype); B = 1 (eval.py's batch size, BASELINE configs[0]) and B = 32; CQT and network timed separately; best of the thread
+    counts {8, 32, all}.  Bounded: every (case, thread count) gets an equal share of `budget_s`."""
     from ake_amd import synthetic
     from oracle import cqt_oracle, pcnet_oracle
-    threads = torch.get_num_threads()
-    audio, _ = synthetic.make_batch(range(n_clips))
-    cqt = cqt_oracle.FastDirectCQT(SR, HOP, dtype=torch.float32)
-    sd64 = pcnet_oracle.to_dtype(sd, torch.float64)
-    seq = torch.full((batch,), T_FRAMES)
-    with torch.no_grad():
-        pcnet_oracle.pcnet_forward(sd64, cqt(audio[:1])[:, None].double(), seq[:1])       # warm-up
-        t0 = time.perf_counter()
-        t_cqt = 0.0
-        for s in range(0, n_clips, batch):
-            c0 = time.perf_counter()
-            mel = cqt(audio[s:s + batch])
-            t_cqt += time.perf_counter() - c0
-            pcnet_oracle.pcnet_forward(sd64, mel[:, None].double(), seq[: mel.shape[0]])
-        dt = time.perf_counter() - t0
-    return {"value": round(n_clips / dt, 2), "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": f"{n_clips} synthetic 15 s clips, batches of {batch}: oracle direct-form CQT (fp32 BLAS matmuls, "
-                      f"{t_cqt / dt:.0%} of the time) + oracle PitchClassNet forward in float64 (reference dtype), "
-                      f"torch CPU ops on {threads} threads, {dt:.1f} s"}
+    ncpu = os.cpu_count() or 1
+    prev = torch.get_num_threads()
+    thread_opts = sorted({min(8, ncpu), min(32, ncpu), ncpu})
+    audio, _ = synthetic.make_batch(range(32))
+    cases, share = [], budget_s / (2 * 2 * 2 * len(thread_opts))
+    try:
+        for dtype, dname in ((torch.float32, "f32"), (torch.float64, "f64")):
+            cqt = cqt_oracle.FastDirectCQT(SR, HOP, dtype=dtype)
+            sdd = pcnet_oracle.to_dtype(sd, dtype)
+            for B in (1, 32):
+                y = torch.from_numpy(audio[:B])
+                seq = torch.full((B,), T_FRAMES)
+                with torch.no_grad():
+                    mel = cqt(y)[:, None].contiguous()
+                    best = {}
+                    for stage, fn in (("cqt", lambda: cqt(y)), ("net", lambda: pcnet_oracle.pcnet_forward(sdd, mel, seq))):
+                        for th in thread_opts:
+                            torch.set_num_threads(th)
+                            t, n = _median_time(fn, share)
+                            if stage not in best or t < best[stage][0]:
+                                best[stage] = (t, th, n)
+                t_all = best["cqt"][0] + best["net"][0]
+                cases.append({"dtype": dname, "batch": B,
+                              "cqt_ms": round(best["cqt"][0] * 1e3, 2), "cqt_threads": best["cqt"][1],
+                              "net_ms": round(best["net"][0] * 1e3, 2), "net_threads": best["net"][1],
+                              "iters": [best["cqt"][2], best["net"][2]],
+                              "clips_per_s": round(B / t_all, 2), "cqt_clips_per_s": round(B / best["cqt"][0], 2),
+                              "net_clips_per_s": round(B / best["net"][0], 2)})
+    finally:
+        torch.set_num_threads(prev)
+    ref = next(c for c in cases if c["dtype"] == "f64" and c["batch"] == 1)
+    top = max(cases, key=lambda c: c["clips_per_s"])
+    return {"value": ref["clips_per_s"], "unit": "clips/s", "cores": max(ref["cqt_threads"], ref["net_threads"]), "kind": "port",
+            "sample": f"oracle direct-form CQT (BLAS matmuls) + oracle PitchClassNet forward (torch CPU ops) on 1 and 32 synthetic 15 s clips; "
+                      f"value = float64 (the reference's dtype), batch 1 (eval.py), median of {ref['iters']} runs (CQT, net), best of "
+                      f"{thread_opts} threads per stage; every case in `cases`",
+            "cpu_model": _cpu_model(), "host_cores": ncpu, "thread_counts_tried": thread_opts,
+            "best": {"value": top["clips_per_s"], "dtype": top["dtype"], "batch": top["batch"]},
+            "cases": cases}
+
+
+def launch_ranks(n):
+    """--gpus N without a launcher: start N fresh rank processes (one per GPU, RCCL) from THIS process, which has made no GPU
+    call, relay their output, and exit with their code.  The ranks re-enter this file with WORLD_SIZE set."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        print(f"bench.py: the {n}-rank launch failed with exit code {rc} (no single-rank or gloo fallback)", file=sys.stderr)
+    sys.exit(rc)
+
+
+def require_world(world, gpus):
+    if world != gpus:
+        sys.exit(f"bench.py: WORLD_SIZE={world} but --gpus {gpus}: refusing to print a line for a world size that was not asked for")
 
 
 def init_ranks(D):
@@ -97,7 +198,7 @@ def init_ranks(D):
     if os.environ.get("AKE_REHEARSE_ONE_GPU"):
         rank, world, _ = D.init_from_env("gloo")
         return rank, world, 0
-    return D.init_from_env()
+    return D.init_from_env("nccl")                                     # RCCL; an init failure raises (non-zero exit), never gloo
 
 
 def train_main(args):
@@ -107,6 +208,7 @@ def train_main(args):
     import ake_amd
     from ake_amd import distributed as D, synthetic
     rank, world, local_rank = init_ranks(D)
+    require_world(world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -161,12 +263,47 @@ def train_main(args):
         "kernel_ms_per_step": kernel_ms}))
 
 
+def parity_and_mirex(rows, audio_last, first_clip, world, B):
+    """Outside the timed region: four clips of the last timed step (rank 0's shard: first, last and two inner M-tile boundaries of the
+    CQT bank's 16-clip tiles) against the CPU oracle (float64 direct-form CQT -> float64 network), and a MIREX sanity score of
+    every rank's rows against the synthetic labels (seeded fixture weights: a sanity signal, not a quality claim)."""
+    import ake_amd
+    from ake_amd import synthetic
+    from oracle import cqt_oracle, pcnet_oracle
+    sd64 = pcnet_oracle.to_dtype(load_fixture_weights(), torch.float64)
+    pick = sorted({0, min(B - 1, 15), min(B - 1, B // 2 + 16), B - 1})
+    y = audio_last[pick].cpu()
+    with torch.no_grad():
+        mel = cqt_oracle.FastDirectCQT(SR, HOP, dtype=torch.float64)(y)
+        ref = torch.cat(pcnet_oracle.pcnet_forward(sd64, mel[:, None], torch.full((len(pick),), T_FRAMES)), 1)
+    got = rows[pick].double().cpu()
+    errs = {}
+    for name, sl in (("key", slice(0, 12)), ("tonic", slice(12, 24)), ("genre", slice(24, 35))):
+        errs[name] = float((got[:, sl] - ref[:, sl]).abs().max() / ref[:, sl].abs().max().clamp_min(1e-6))
+    labs = [synthetic.clip_recipe(first_clip(r) + i)[4] for r in range(world) for i in range(B)]
+    L = {k: torch.from_numpy(np.stack([l[k] for l in labs])) for k in labs[0]}
+    r = rows.float().cpu()
+    m = ake_amd.metrics.mirex_score(L["key_labels"], r[:, :12], L["tonic_labels"], r[:, 12:24], L["key_signature_id"])
+    return ({"max_rel_err": round(max(errs.values()), 8), "per_output": {k: round(v, 8) for k, v in errs.items()}, "tolerance": 1e-3,
+             "clips_checked": [int(i) for i in pick],
+             "against": "oracle: float64 direct-form CQT (build's own spec, unpinned vs librosa) -> float64 PitchClassNet restatement (pinned "
+                        "on the reference); max |a-b| / max |b| per output tensor, last timed step, outside the timed region"},
+            {"score": round(float(m[0]), 4), "correct": round(float(m[1]), 4), "fifths": round(float(m[2]), 4), "relative": round(float(m[3]), 4),
+             "parallel": round(float(m[4]), 4), "other": round(float(m[5]), 4), "clips": int(r.shape[0]),
+             "note": "sanity only: seeded random fixture weights on synthetic labelled sine-mix clips (models.py:1065-1116 scoring)"})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
+    ap.add_argument("--rotate", type=int, default=4,
+                    help="distinct resident audio batches the steps rotate over (4 x 339 MB > the 256 MiB Infinity Cache: no step re-reads "
+                         "audio that is still on chip)")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0,
+                    help="length of the extra 'sustained' pass (same steps, same rotation, long enough for DVFS steady state); 0: skip")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent steps in flight per GPU in the TIMED region: steps are issued round-robin on this many streams (own "
                          "workspace each), so one batch's CQT overlaps another's convolutions; 1 (default) = strictly one step after the "
@@ -174,9 +311,12 @@ def main():
     ap.add_argument("--pipelined-streams", type=int, default=2,
                     help="an extra, separately timed pass of the same steps with this many in flight, reported as 'pipelined' (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the last step's rows (profiler runs)")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[3] instead of the headline: one fwd + bwd + gradient all-reduce + fused Adam step per GPU batch")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)                                         # never returns; nothing here has touched the GPU yet
     if args.train:
         return train_main(args)
 
@@ -184,7 +324,7 @@ def main():
     from ake_amd import distributed as D, synthetic
 
     rank, world, local_rank = init_ranks(D)
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    require_world(world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -195,15 +335,15 @@ def main():
     net = net.to(dev).eval()
     est = ake_amd.KeyEstimator(net, SR, FRAMES, streams=args.streams)
     est1 = est if args.streams == 1 else ake_amd.KeyEstimator(net, SR, FRAMES)      # second, untimed pass: one step after the other
-    B = args.batch
-    lo = rank * B                                                       # each rank synthesises its own clips
-    audio, _ = synthetic.make_batch_device(range(lo, lo + B), dev)
-    assert audio.shape == (B, N_SAMPLES)
+    B, R = args.batch, max(1, args.rotate)
+    first_clip = lambda r, j=0: (r * R + j) * B                         # each rank synthesises R batches of its own clips
+    batches = [synthetic.make_batch_device(range(first_clip(rank, j), first_clip(rank, j) + B), dev)[0] for j in range(R)]
+    assert all(a.shape == (B, N_SAMPLES) for a in batches)
 
-    for _ in range(max(args.warmup, 1)):
-        out = est(audio)
+    for i in range(max(args.warmup, 1)):
+        out = est(batches[i % R])
         if est1 is not est:
-            est1(audio)
+            est1(batches[i % R])
     est.join()
     torch.cuda.synchronize()
     # timed region: hipEvents (on the launch stream) bracket only the dominant kernel -- 3 launches per step
@@ -212,18 +352,19 @@ def main():
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = est(audio)
+    for i in range(args.steps):
+        out = est(batches[i % R])
     est.join()
     torch.cuda.synchronize()
     D.barrier()
     dt = time.perf_counter() - t0
     prof = ake_amd._lib.prof_results()
+    last_j = (args.steps - 1) % R
     # second, untimed pass, one step after the other on one stream with every kernel bracketed: per-kernel breakdown, the CQT stage's
     # roofline, and the dominant kernel's duration when nothing else shares the GPU with it
     ake_amd._lib.prof_enable("", True)
-    for _ in range(args.steps):
-        est1(audio)
+    for i in range(args.steps):
+        est1(batches[i % R])
     torch.cuda.synchronize()
     prof_all = ake_amd._lib.prof_results()
     ake_amd._lib.prof_enable("", False)
@@ -232,24 +373,52 @@ def main():
     dt_pipe = None
     if args.pipelined_streams > 1 and args.streams == 1:
         estp = ake_amd.KeyEstimator(net, SR, FRAMES, streams=args.pipelined_streams)
-        for _ in range(2 * args.pipelined_streams):
-            estp(audio)
+        for i in range(2 * args.pipelined_streams):
+            estp(batches[i % R])
         estp.join()
         D.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            estp(audio)
+        for i in range(args.steps):
+            estp(batches[i % R])
         estp.join()
         torch.cuda.synchronize()
         D.barrier()
         dt_pipe = D.max_over_ranks(time.perf_counter() - t0, dev)
+    # sustained pass: the timed region's steps again, for >= --sustained-seconds (the step count is fixed from the timed region's
+    # rate so that every rank runs the same number), dominant kernel bracketed as in the timed region
+    sustained = None
+    if args.sustained_seconds > 0:
+        n_sus = max(args.steps, int(args.sustained_seconds / (dt / args.steps) * 1.1) + 1)
+        ake_amd._lib.lib().ake_prof_reset()
+        ake_amd._lib.prof_enable("conv_p2p_bf16_kernel", True)
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_sus):
+            est1(batches[i % R])
+        torch.cuda.synchronize()
+        D.barrier()
+        dt_sus = D.max_over_ranks(time.perf_counter() - t0, dev)
+        prof_sus = ake_amd._lib.prof_results()
+        ake_amd._lib.prof_enable("", False)
+        s_ms, s_n = prof_sus.get("conv_p2p_bf16_kernel", (0.0, 0))
+        s_tf = 2.0 * P2P_MACS_PER_CLIP * B * n_sus / (s_ms * 1e-3) / 1e12 if s_ms > 0 else None
+        sustained = {"seconds": round(dt_sus, 3), "steps": n_sus, "distinct_batches": R, "resident_audio_bytes": R * B * N_SAMPLES * 4,
+                     "value": round(B * world * n_sus / dt_sus, 1), "unit": "clips/s", "ms_per_step": round(dt_sus / n_sus * 1e3, 4),
+                     "dominant_kernel_avg_launch_ms": round(s_ms / s_n, 4) if s_n else None,
+                     "dominant_kernel_tflops": round(s_tf, 2) if s_tf else None,
+                     "dominant_kernel_frac": round(s_tf / PEAK_BF16_TFLOPS, 4) if s_tf else None}
 
     # result collection (outside the timed region): 35 floats per clip, rank order
     rows = D.gather_rows(torch.cat(out, 1), B * world)
     if rank != 0:
         return
     assert rows.shape == (B * world, 35) and bool(torch.isfinite(rows).all())
+    parity = mirex = None
+    if not args.no_parity:
+        parity, mirex = parity_and_mirex(rows, batches[last_j], lambda r: first_clip(r, last_j), world, B)
+        assert parity["max_rel_err"] < 1e-3, f"parity vs the oracle: {parity}"
 
     clips = B * world * args.steps
     value = clips / dt
@@ -263,7 +432,7 @@ def main():
     kernel_ms = {k: round(v[0] / args.steps, 4) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}
     p2p1_ms, p2p1_n = prof_all.get("conv_p2p_bf16_kernel", (0.0, 0))
     achieved1 = p2p_flops / (p2p1_ms * 1e-3) / 1e12 if p2p1_ms > 0 else None
-    traffic_src, traffic = pmc_traffic()
+    traffic_src, traffic, traffic_stale = pmc_traffic()
     p2p_traffic = cqt_traffic = None
     if B == 256 and traffic:
         bf_rows = [v for k, v in traffic.items() if k.startswith("conv_p2p_bf16")]
@@ -277,6 +446,7 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: batch={B} synthetic 15 s sine-mix clips per GPU, HIP CQT (288 bins, hop 4410) "
                                f"+ default PitchClassNet inference (genre head on), audio resident in HBM",
                    "clips_per_gpu": B, "n_samples": N_SAMPLES, "frames": T_FRAMES, "weights": "tests/golden/pcnet_default.npz (seeded)",
+                   "distinct_batches": R, "resident_audio_bytes_per_gpu": R * B * N_SAMPLES * 4,
                    "parallelism": f"clip-sharded x{world}, no data-path collective",
                    "streams": args.streams,
                    "steps_in_flight": f"{args.streams}: every step is the whole path over one batch; consecutive steps go round-robin to "
@@ -290,7 +460,7 @@ def main():
                      "mfma_products_per_mac": 3,
                      "frac_of_split_ceiling": round(3 * achieved / PEAK_BF16_TFLOPS, 4) if achieved else None,
                      "traffic": p2p_traffic,
-                     "traffic_source": f"profiles/{traffic_src}: mean HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE" if p2p_traffic else None,
+                     "traffic_source": f"profiles/{traffic_src}: mean HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE" if p2p_traffic else traffic_stale,
                      # mean over the three launches: (1 CQT + 4 x 36-row up_sixth channels -> 8 channels), (8 -> 8), (8 -> 8 semitone channels of P / 3 rows)
                      "algorithmic_bytes_per_launch": B * T_FRAMES * 4 * ((P + 4 * 36 + 8 * P) + (8 * P + 8 * P) + (8 * P + 8 * P // 3)) // 3,
                      "avg_launch_ms": round(p2p_ms / p2p_n, 4) if p2p_n else None, "launches_per_step": launches_per_step,
@@ -311,6 +481,7 @@ def main():
                               "(KeyEstimator(streams=...)): one batch's VALU / HBM-bound CQT runs under another's MFMA-bound convolutions; "
                               "not the headline value because overlapping kernels blur the per-kernel durations the roofline is made of"} if dt_pipe else None,
         "net_algorithmic_tflops": round(2.0 * NET_MACS_PER_CLIP * value / world / 1e12, 2),
+        "sustained": sustained, "parity": parity, "max_rel_err": parity["max_rel_err"] if parity else None, "mirex": mirex,
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(sd)

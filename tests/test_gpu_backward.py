@@ -164,3 +164,68 @@ def test_max_pool_gradients(gold_default, with_seq):
     for name in ("key_classifier.3.conv2d.weight", "tonic_classifier.3.conv2d.weight", "genre_classifier.3.weight"):
         assert by_name[name] < 1e-4, (name, by_name[name])
     assert rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 1e-4, rows[:5]
+
+
+def test_backward_after_other_forwards_uses_its_own_activations(gold_default):
+    """the backward kernels read the activations their forward left in a workspace.  Every autograd node owns its
+    workspace until its backward has run, so -- as with plain autograd in the reference -- a second train forward, an eval forward
+    or a LARGER batch between a forward and its backward change nothing: the gradients equal those of the undisturbed step bit
+    for bit up to the float-atomic weight-gradient sums (compared at 1e-5 of each tensor's max), and loss(a) + loss(b) gives
+    grad(a) + grad(b)."""
+    opt = Namespace(**json.loads(str(gold_default["opt"])))
+    sd32 = golden_state_dict(gold_default)
+
+    def fresh():
+        n = ake_amd.PitchClassNet(288, 12, 2, 7, opt)
+        n.load_state_dict(sd32, strict=True)
+        return n.to(DEV).train()
+
+    xa, sa, la = make_case(4, 40, 1)
+    xb, sb, lb = make_case(3, 52, 2)
+    xc = torch.rand((6, 1, 288, 64)) * 2.5                           # larger than a and b: the shared workspace would be reallocated
+    dev = lambda ts: tuple(t.to(DEV) for t in ts)
+
+    def loss_of(net, x, s, l):
+        o = net(x.to(DEV), s.to(DEV))
+        return loss_fn(o[0], o[1], o[2], *dev(l))
+
+    def grads(net):
+        return {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+
+    net = fresh()
+    loss_of(net, xa, sa, la).backward()
+    ga = grads(net)
+    net = fresh()
+    loss_of(net, xb, sb, lb).backward()
+    gb = grads(net)
+
+    # forward a, then (train forward b, eval forward, larger train forward without grad), then backward a
+    net = fresh()
+    loss_a = loss_of(net, xa, sa, la)
+    loss_b = loss_of(net, xb, sb, lb)                                # second node, alive at the same time
+    net.eval()
+    with torch.no_grad():
+        net(xc.to(DEV), torch.full((6,), 64, device=DEV))
+    net.train()
+    with torch.no_grad():
+        net(xc.to(DEV), torch.full((6,), 64, device=DEV))
+    loss_a.backward()
+    for n, g in grads(net).items():
+        assert float((g - ga[n]).abs().max()) <= 1e-5 * max(float(ga[n].abs().max()), 1e-12), n
+    # ... and the second node still has its activations: accumulating its backward gives grad(a) + grad(b)
+    loss_b.backward()
+    for n, g in grads(net).items():
+        want = ga[n] + gb[n]
+        assert float((g - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1e-12), n
+    # one loss over two forwards
+    net = fresh()
+    (loss_of(net, xa, sa, la) + loss_of(net, xb, sb, lb)).backward()
+    for n, g in grads(net).items():
+        want = ga[n] + gb[n]
+        assert float((g - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1e-12), n
+    # a second backward through the same node is refused (its activations are gone), as autograd refuses without retain_graph
+    net = fresh()
+    l2 = loss_of(net, xa, sa, la)
+    l2.backward(retain_graph=True)
+    with pytest.raises(Exception):
+        l2.backward()

@@ -153,3 +153,50 @@ def test_kernel_timer_reports_the_launched_kernels(net):
     assert "conv_mfma_kernel/p2p" not in res and res["conv_p2p_bf16_kernel"][1] == 3
     assert res["cqt_cascade_kernel"][1] == 1                                               # 7 decimation stages, one launch
     assert all(ms > 0 for ms, _ in res.values())
+
+
+def test_pipeline_at_the_bench_batch(net, gold_default):
+    """BASELINE configs[1] exactly as bench.py runs it: KeyEstimator on make_batch_device(range(256)).  The CQT bank tiles M over
+    CLIPS (16 waves x 16 clips), so 256 clips is a shape of its own: the first and last clip of every 16-clip M-tile go through the
+    CPU oracle chain (float64 direct-form CQT -> float64 network) at <= 1e-3, and the whole batch must be permutation-equivariant
+    (clips are independent: reversing the batch reverses the rows, bit for bit)."""
+    est = ake_amd.KeyEstimator(net, 22050, 5)
+    audio, _ = synthetic.make_batch_device(range(256), torch.device(DEV))
+    out = torch.cat(est(audio), 1)
+    assert out.shape == (256, 35) and bool(torch.isfinite(out).all())
+    pick = sorted({i for g in range(16) for i in (16 * g, 16 * g + 15)})
+    sd = golden_state_dict(gold_default, torch.float64)
+    with torch.no_grad():
+        mel_ref = cqt_oracle.FastDirectCQT(22050, 4410, dtype=torch.float64)(audio[pick].cpu())
+        ref = torch.cat(pcnet_oracle.pcnet_forward(sd, mel_ref[:, None], torch.full((len(pick),), 76)), 1)
+    got = out[pick].cpu()
+    for sl in (slice(0, 12), slice(12, 24), slice(24, 35)):
+        assert rel_err(got[:, sl], ref[:, sl]) < 1e-3
+    perm = torch.arange(255, -1, -1, device=DEV)
+    out_p = torch.cat(est(audio[perm].contiguous()), 1)
+    assert torch.equal(out_p, out[perm])
+    # a different permutation that moves clips between M-tiles and between the network's persistent-kernel tiles
+    perm2 = (torch.arange(256, device=DEV) * 37 + 11) % 256
+    assert torch.equal(torch.cat(est(audio[perm2].contiguous()), 1), out[perm2])
+
+
+def test_bench_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` with NO launcher must start two rank processes itself and print an n_gpus: 2 line (both ranks on
+    this GPU, gloo collectives: AKE_REHEARSE_ONE_GPU); a world size that differs from --gpus is a hard error."""
+    import json, os, subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["AKE_REHEARSE_ONE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "32", "--rotate", "2",
+           "--sustained-seconds", "0.2", "--pipelined-streams", "0", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["clips_per_gpu"] == 32 and line["max_rel_err"] < 1e-3
+    assert line["mirex"]["clips"] == 64 and line["sustained"]["steps"] >= 3
+    # world size != --gpus: refused, no line
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu-baseline"], env=env2,
+                         capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in bad.stderr and not [l for l in bad.stdout.splitlines() if l.startswith("{")]

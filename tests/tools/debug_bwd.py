@@ -31,7 +31,7 @@ def tap(name):
     L = ake_amd._lib.lib(); shape = (C.c_int64 * 4)()
     ake_amd._lib.check(L.ake_pcnet_tap_info(net._h, name.encode(), B, T, shape), "tap_info")
     t = torch.empty(tuple(shape), dtype=torch.float32, device="cuda")
-    ake_amd._lib.check(L.ake_pcnet_tap_copy(net._h, name.encode(), B, T, net._ws.data_ptr(), t.data_ptr(), torch.cuda.current_stream().cuda_stream), "tap_copy")
+    ake_amd._lib.check(L.ake_pcnet_tap_copy(net._h, name.encode(), B, T, net._ws_last.data_ptr(), t.data_ptr(), torch.cuda.current_stream().cuda_stream), "tap_copy")
     return t.cpu().double()
 
 

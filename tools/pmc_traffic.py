@@ -10,8 +10,11 @@ Launches are keyed by kernel name + grid size (the three 7x7 pitch convolutions 
 pitch-class convolutions; the grid tells them apart)."""
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def load(path, counter):
@@ -35,7 +38,9 @@ def main(fetch_csv, write_csv, out):
         f = fe.get(k, [0.0]); w = wr.get(k, [0.0])
         res[k] = {"dispatches": len(f), "fetch_bytes": round(2 * 1024 * sum(f) / len(f)), "write_bytes": round(1024 * sum(w) / len(w))}
         res[k]["hbm_bytes"] = res[k]["fetch_bytes"] + res[k]["write_bytes"]
-    json.dump({"units": "bytes per launch (mean); fetch = 2 x FETCH_SIZE KiB (gfx950), write = WRITE_SIZE KiB", "kernels": res}, open(out, "w"), indent=1)
+    from bench import kernel_set_hash                        # the kernel sources these counters belong to: bench.py refuses a stale profile
+    json.dump({"units": "bytes per launch (mean); fetch = 2 x FETCH_SIZE KiB (gfx950), write = WRITE_SIZE KiB",
+               "kernel_set": kernel_set_hash(), "kernels": res}, open(out, "w"), indent=1)
     for k, v in res.items():
         print(f"{k:60s} x{v['dispatches']:3d}  fetch {v['fetch_bytes']/1e6:9.2f} MB  write {v['write_bytes']/1e6:9.2f} MB")
 
