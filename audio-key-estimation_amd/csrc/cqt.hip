@@ -27,6 +27,7 @@
 #include <cstring>
 #include <algorithm>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -82,6 +83,8 @@ struct BankCall {
 
 }  // namespace
 
+#include "cqt_fused.h"
+
 struct ake_cqt_plan {
     ake_cqt_config cfg;
     int n_oct;
@@ -99,6 +102,10 @@ struct ake_cqt_plan {
     uint4* table2_dev = nullptr;
     int ppad = 0;                        // pad of the split planes (covers every tap window)
     size_t bank2_lds = 0;
+    std::vector<fz::Level> flv;          // engine 4: one entry per octave (ring fields are filled per launch)
+    uint4* table4_dev = nullptr;
+    uint4* toep_dev = nullptr;
+    int n_cu = 256;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -676,6 +683,10 @@ int len_store(const ake_cqt_plan* p, int o, int64_t n) {   // floats stored per 
     return (static_cast<int>(l) + 2 * pad_of(p) + 3) / 4 * 4;
 }
 
+// engine 4: level-4 signal handed from the first launch to the second (f32, sample m at index m + kNextPad)
+constexpr int kNextPad = 24;
+int next_len(int64_t n) { return (static_cast<int>((n + 15) / 16) + 2 * kNextPad + 3) / 4 * 4; }
+
 int plane_len(const ake_cqt_plan* p, int l, int64_t n) {   // split words per clip of level l (multiple of 8)
     const int64_t ln = (n + (1ll << l) - 1) >> l;
     return (static_cast<int>(ln) + 2 * pad_of(p) + 2 * p->ppad + 8 + 7) / 8 * 8;
@@ -819,8 +830,134 @@ int ake_cqt_plan_create(const ake_cqt_config* cfg_in, ake_cqt_plan** out) {
         const bool can_bf16 = can_fuse && n_oct >= 2 && n_oct - 1 <= kCascMax;
         if (want == 3 && !can_bf16) { ake::set_error("cqt: engine 3 needs 2..%d octaves and decim_half_len <= 23", kCascMax + 1); ake_cqt_plan_destroy(p); return AKE_ERR_UNSUPPORTED; }
         if (want == 2 && !can_fuse) { ake::set_error("cqt: engine 2 needs decim_half_len <= 23"); ake_cqt_plan_destroy(p); return AKE_ERR_UNSUPPORTED; }
-        p->engine = (want >= 1 && want <= 3) ? want : (can_bf16 ? 3 : (can_fuse ? 2 : 1));
+        // engine 4 (fused cascade + bank): 47-tap half-band, <= 8 octaves, tap windows that fit the LDS rings
+        int uh_max = 0;
+        for (int o = 0; o < n_oct; ++o) {
+            const int k0 = cfg.n_bins - bpo * (o + 1);
+            uh_max = std::max(uh_max, static_cast<int>(std::ceil(-std::floor(-len[k0] / 2.0) / (1 << o))) + 1);
+        }
+        const int w4 = (2 * uh_max + 8 + 31) / 32 * 32;
+        const bool can_fz = p->half_len == 23 && n_oct <= 2 * fz::kMaxLv && w4 <= 32 * fz::kMaxBlk && (480 + 4 * w4) * 64 <= 160 * 1024;
+        if (want == 4 && !can_fz) { ake::set_error("cqt: engine 4 needs decim_half_len 23, <= 8 octaves and tap windows <= %d samples (got %d)", 32 * fz::kMaxBlk, w4); ake_cqt_plan_destroy(p); return AKE_ERR_UNSUPPORTED; }
+        p->engine = (want >= 1 && want <= 4) ? want : (can_fz ? 4 : (can_bf16 ? 3 : (can_fuse ? 2 : 1)));
         p->cfg.engine = p->engine;
+    }
+    if (p->engine == 4) {
+        auto bf16_rne = [](float v) -> uint16_t {
+            uint32_t u;
+            std::memcpy(&u, &v, 4);
+            u += 0x7FFFu + ((u >> 16) & 1u);
+            return static_cast<uint16_t>(u >> 16);
+        };
+        auto bf16_f32 = [](uint16_t hh) { uint32_t u = static_cast<uint32_t>(hh) << 16; float f; std::memcpy(&f, &u, 4); return f; };
+        // half-band Toeplitz A fragments: A[n][k] = h[k - 24 - 2n], k = 32 ks + 8 (lane >> 4) + e, n = lane & 15 (outputs P + n read inputs 2P - 24 + k)
+        std::vector<uint16_t> tp(3 * 2 * 64 * 8, 0);
+        for (int ks = 0; ks < 3; ++ks)
+            for (int ln = 0; ln < 64; ++ln)
+                for (int e = 0; e < 8; ++e) {
+                    const int jj = 32 * ks + 8 * (ln >> 4) + e - 24 - 2 * (ln & 15);
+                    float v = 0.f;
+                    if (jj == 0) v = p->taps.h0;
+                    else if (std::abs(jj) <= p->half_len && (std::abs(jj) & 1)) v = p->taps.hodd[(std::abs(jj) - 1) / 2];
+                    const uint16_t hi = bf16_rne(v);
+                    tp[((ks * 2 + 0) * 64 + ln) * 8 + e] = hi;
+                    tp[((ks * 2 + 1) * 64 + ln) * 8 + e] = bf16_rne(v - bf16_f32(hi));
+                }
+        // one filter bank per octave and per anchored phase (t * hop - uh * 2^o) mod (8 * 2^o), MFMA A-fragment order
+        // [phase][32-tap block][N-tile][hi | lo][64 lanes] x 8 bf16
+        size_t total16 = 0;                                                     // 16-byte units
+        for (int o = 0; o < n_oct; ++o) {
+            const int dec = 1 << o;
+            fz::Level g;
+            std::memset(&g, 0, sizeof(g));
+            g.k0 = cfg.n_bins - bpo * (o + 1);
+            g.n_bins = bpo;
+            g.n_tiles = (bpo + kTileBins - 1) / kTileBins;
+            auto uh_of = [&](int k) { return static_cast<int>(std::ceil(-std::floor(-len[k] / 2.0) / dec)) + 1; };
+            g.uh = uh_of(g.k0);
+            g.n_blk = (2 * g.uh + 8 + 31) / 32;
+            for (int j = 0; j < g.n_tiles; ++j) {
+                const int uh_j = uh_of(g.k0 + kTileBins * j);
+                g.blk_lo[j] = std::max(0, (g.uh - uh_j) / 32);
+                g.blk_hi[j] = std::min(g.n_blk - 1, (g.uh + uh_j + 7) / 32);
+            }
+            const long long m8 = 8ll * dec;
+            g.period = static_cast<int>(m8 / std::gcd(static_cast<long long>(cfg.hop_length), m8));
+            g.phase_stride = static_cast<long long>(g.n_blk) * kMaxTiles * 2 * 64;
+            g.table_off = static_cast<long long>(total16);
+            total16 += static_cast<size_t>(g.period) * g.phase_stride;
+            p->flv.push_back(g);
+        }
+        std::vector<uint16_t> t4(total16 * 8, 0);
+        struct Job { int o, pi; };
+        std::vector<Job> jobs;
+        for (int o = 0; o < n_oct; ++o) for (int pi = 0; pi < p->flv[o].period; ++pi) jobs.push_back({o, pi});
+        auto fill = [&](size_t j0, size_t j1) {
+            for (size_t ji = j0; ji < j1; ++ji) {
+                const int o = jobs[ji].o, pi = jobs[ji].pi;
+                const fz::Level& g = p->flv[o];
+                const int dec = 1 << o;
+                const long long m8 = 8ll * dec;
+                long long phi = (static_cast<long long>(pi) * cfg.hop_length - static_cast<long long>(g.uh) * dec) % m8;
+                if (phi < 0) phi += m8;
+                uint16_t* dst = t4.data() + (static_cast<size_t>(g.table_off) + static_cast<size_t>(pi) * g.phase_stride) * 8;
+                for (int b = 0; b < bpo; ++b) {
+                    const int k = g.k0 + b;
+                    const int j = b / kTileBins;
+                    const double lo = std::floor(-len[k] / 2.0);
+                    const double L = std::floor(len[k] / 2.0) - lo;
+                    const double scale = dec * std::sqrt(len[k]) / (L / 2.0) / cascade_gain(freq[k], o);
+                    for (int tap = 0; tap < 32 * g.n_blk; ++tap) {
+                        const double pos = static_cast<double>(dec) * (tap - g.uh) - static_cast<double>(phi);   // full-rate offset from the frame centre
+                        if (!(pos >= lo && pos <= lo + L)) continue;
+                        const double win = 0.5 - 0.5 * std::cos(2.0 * M_PI * (pos - lo) / L);
+                        const double arg = 2.0 * M_PI * freq[k] * pos / sr;
+                        const int blk = tap / 32, qq = (tap % 32) / 8, e = tap % 8;
+                        const float vals[2] = {static_cast<float>(scale * win * std::cos(arg)), static_cast<float>(-scale * win * std::sin(arg))};
+                        for (int ri = 0; ri < 2; ++ri) {
+                            const int lane_i = qq * 16 + 2 * (b % kTileBins) + ri;
+                            const uint16_t hi = bf16_rne(vals[ri]);
+                            const size_t f = ((static_cast<size_t>(blk) * kMaxTiles + j) * 2) * 64;
+                            dst[(f + lane_i) * 8 + e] = hi;
+                            dst[(f + 64 + lane_i) * 8 + e] = bf16_rne(vals[ri] - bf16_f32(hi));
+                        }
+                    }
+                }
+            }
+        };
+        {
+            const unsigned nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+            std::vector<std::thread> pool;
+            const size_t per = (jobs.size() + nth - 1) / nth;
+            for (unsigned ti = 0; ti < nth; ++ti) {
+                const size_t j0 = std::min(jobs.size(), ti * per), j1 = std::min(jobs.size(), j0 + per);
+                if (j0 < j1) pool.emplace_back(fill, j0, j1);
+            }
+            for (auto& th : pool) th.join();
+        }
+        const char* what = "hipMalloc(table4)";
+        hipError_t e4 = hipMalloc(&p->table4_dev, t4.size() * sizeof(uint16_t));
+        if (e4 == hipSuccess) { what = "hipMalloc(toeplitz)"; e4 = hipMalloc(&p->toep_dev, tp.size() * sizeof(uint16_t)); }
+        if (e4 == hipSuccess) { what = "hipMemcpy(table4)"; e4 = hipMemcpy(p->table4_dev, t4.data(), t4.size() * sizeof(uint16_t), hipMemcpyHostToDevice); }
+        if (e4 == hipSuccess) { what = "hipMemcpy(toeplitz)"; e4 = hipMemcpy(p->toep_dev, tp.data(), tp.size() * sizeof(uint16_t), hipMemcpyHostToDevice); }
+        if (e4 == hipSuccess) {
+            what = "hipFuncSetAttribute(max dynamic LDS)";
+            const void* fns[] = {reinterpret_cast<const void*>(fz::cqt_fused_kernel<1, false>), reinterpret_cast<const void*>(fz::cqt_fused_kernel<2, false>),
+                                 reinterpret_cast<const void*>(fz::cqt_fused_kernel<3, false>), reinterpret_cast<const void*>(fz::cqt_fused_kernel<4, false>),
+                                 reinterpret_cast<const void*>(fz::cqt_fused_kernel<4, true>)};
+            for (const void* f : fns)
+                if (e4 == hipSuccess) e4 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+        if (e4 == hipSuccess) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) p->n_cu = prop.multiProcessorCount;
+        }
+        if (e4 != hipSuccess) {
+            ake::set_error("cqt plan (engine 4, %zu MB of phase tables): %s failed: %s", t4.size() * 2 >> 20, what, hipGetErrorString(e4));
+            ake_cqt_plan_destroy(p);
+            return AKE_ERR_HIP;
+        }
     }
     if (p->engine == 3) {
         auto bf16_rne = [](float v) -> uint16_t {
@@ -910,6 +1047,8 @@ void ake_cqt_plan_destroy(ake_cqt_plan* p) {
     if (p->octs_dev) (void)hipFree(p->octs_dev);
     if (p->table2_dev) (void)hipFree(p->table2_dev);
     if (p->octs2_dev) (void)hipFree(p->octs2_dev);
+    if (p->table4_dev) (void)hipFree(p->table4_dev);
+    if (p->toep_dev) (void)hipFree(p->toep_dev);
     delete p;
 }
 
@@ -925,7 +1064,9 @@ int64_t ake_cqt_num_frames(const ake_cqt_plan* p, int64_t n_samples) {
 size_t ake_cqt_workspace_bytes(const ake_cqt_plan* p, int batch, int64_t n_samples) {
     if (!p || batch <= 0 || n_samples <= 0) return 0;
     ake::Carver c(nullptr, 0);
-    if (p->engine == 3) {
+    if (p->engine == 4) {
+        if (p->n_oct > fz::kMaxLv) c.take<float>(static_cast<size_t>(batch) * next_len(n_samples));                        // level 4 between the two launches
+    } else if (p->engine == 3) {
         for (int l = 0; l < p->n_oct; ++l) c.take<unsigned int>(static_cast<size_t>(batch) * plane_len(p, l, n_samples));   // split-bf16 level signals
     } else {
         for (int o = 1; o < p->n_oct; ++o) c.take<float>(static_cast<size_t>(batch) * len_store(p, o, n_samples));
@@ -952,7 +1093,7 @@ int ake_cqt_logmag_ragged_f32(const ake_cqt_plan* p, const float* audio, int bat
                               const int64_t* n_samples_dev, float* out, int64_t out_frames, void* workspace, size_t ws_bytes,
                               ake_stream_t stream_) {
     AKE_REQUIRE(n_samples_dev, AKE_ERR_INVALID, "ake_cqt_logmag_ragged_f32: null n_samples_dev");
-    AKE_REQUIRE(p && p->engine == 3, AKE_ERR_UNSUPPORTED, "cqt: ragged batches need engine 3 (the default up to 8 octaves)");
+    AKE_REQUIRE(p && (p->engine == 3 || p->engine == 4), AKE_ERR_UNSUPPORTED, "cqt: ragged batches need engine 3 or 4 (the defaults up to 8 octaves)");
     return cqt_logmag_impl(p, audio, batch, n_max, audio_stride, n_samples_dev, out, out_frames, workspace, ws_bytes, stream_);
 }
 
@@ -996,7 +1137,73 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
         else if (split) hipLaunchKernelGGL((cqt_cascade_kernel<12, C, NT, true>), grid, dim3(NT), 0, stream, a);
         else hipLaunchKernelGGL((cqt_cascade_kernel<12, C, NT, false>), grid, dim3(NT), 0, stream, a);
     };
-    if (p->engine == 3) {
+    if (p->engine == 4) {
+        float* next = p->n_oct > fz::kMaxLv ? c.take<float>(static_cast<size_t>(batch) * next_len(n)) : nullptr;
+        scratch = c.take<float>(static_cast<size_t>(batch) * T * p->cfg.n_bins);
+        const int n_groups = (batch + fz::kClips - 1) / fz::kClips;
+        for (int pass = 0; pass * fz::kMaxLv < p->n_oct; ++pass) {
+            fz::Args a;
+            std::memset(&a, 0, sizeof(a));
+            const int L0 = pass * fz::kMaxLv;
+            const int NL = std::min(fz::kMaxLv, p->n_oct - L0);
+            const bool emit = pass == 0 && p->n_oct > fz::kMaxLv;
+            a.L0 = L0; a.hop = p->cfg.hop_length; a.batch = batch; a.T = static_cast<int>(T);
+            a.n_clip = reinterpret_cast<const long long*>(n_clip);
+            a.out = scratch; a.out_clip_stride = static_cast<long long>(T) * p->cfg.n_bins; a.n_bins_total = p->cfg.n_bins;
+            a.table = p->table4_dev; a.toep = p->toep_dev;
+            long long m_end;                                              // exclusive end of what somebody must own, level-L0 sample numbers
+            if (pass == 0) {
+                a.x = audio; a.x_stride = audio_stride; a.n_valid = n; a.pad_in = 0;
+                AKE_REQUIRE(static_cast<unsigned long long>(batch) * audio_stride * 4 < 0xFFF00000ull, AKE_ERR_UNSUPPORTED,
+                            "cqt engine 4: the audio tensor must stay below 4 GiB per call (%d clips x %lld samples): split the batch", batch,
+                            static_cast<long long>(audio_stride));
+                a.x_bytes = static_cast<unsigned>(static_cast<unsigned long long>(batch) * audio_stride * 4);
+                a.M_begin = emit ? -16ll * kNextPad / 128 * 128 - (16 * kNextPad % 128 ? 128 : 0) : 0;
+                m_end = n + 1;
+                if (emit) {
+                    a.next = next; a.next_stride = next_len(n); a.next_count = next_len(n); a.pad_next = kNextPad;
+                    m_end = std::max<long long>(m_end, 16ll * (a.next_count - kNextPad));
+                }
+            } else {
+                a.x = next; a.x_stride = next_len(n); a.n_valid = next_len(n); a.pad_in = kNextPad;
+                a.x_bytes = static_cast<unsigned>(static_cast<unsigned long long>(batch) * a.x_stride * 4);
+                a.M_begin = 0;
+                m_end = (((T - 1) * static_cast<long long>(a.hop)) >> L0) + 1;
+            }
+            // rings: level l holds (256 >> l) + W samples (what a step produces twice over + one tap window), see cqt_fused.h
+            int lds_units = 0;
+            for (int l = 0; l < NL; ++l) {
+                a.lv[l] = p->flv[L0 + l];
+                a.lv[l].ring_units = ((256 >> l) + 32 * a.lv[l].n_blk) / 8;
+                a.lv[l].lds_off = lds_units;
+                lds_units += 2 * a.lv[l].ring_units * 16;
+            }
+            const size_t lds_bytes = static_cast<size_t>(lds_units) * 16;
+            AKE_REQUIRE(lds_bytes <= 160 * 1024, AKE_ERR_UNSUPPORTED, "cqt engine 4: rings need %zu B of LDS", lds_bytes);
+            // warm-up / tail steps: the deepest level's window reaches (uh + 8) * 2^D samples back and W - uh forward of a frame centre,
+            // its samples depend on 23 * (2^D - 1) inputs either side, and level D runs lag_D samples behind the audio
+            const int D = NL - 1;
+            const fz::Level& ld = a.lv[D];
+            const int lag_d = D == 0 ? -127 : (D == 1 ? 17 : 65);
+            a.h_pre = (((ld.uh + 8) << D) + 23 * ((1 << D) - 1) + 32 + fz::kStep - 1) / fz::kStep;
+            a.h_post = 1 + std::max(0, (((32 * ld.n_blk - ld.uh - 1 + lag_d) << D) + fz::kStep - 1) / fz::kStep);
+            if (emit) { a.h_pre = std::max(a.h_pre, 4); a.h_post = std::max(a.h_post, 9); }
+            const long long total = m_end - a.M_begin;
+            const int min_seg = 1024;
+            int n_seg = std::max(1, (p->n_cu + n_groups - 1) / n_groups);
+            n_seg = static_cast<int>(std::max<long long>(1, std::min<long long>(n_seg, total / min_seg)));
+            a.seg_len = static_cast<int>((total + n_seg - 1) / n_seg + fz::kStep - 1) / fz::kStep * fz::kStep;
+            a.n_seg = static_cast<int>((total + a.seg_len - 1) / a.seg_len);
+            const int n_wg = n_groups * a.n_seg;
+            dim3 grid((n_wg + 7) / 8 * 8);
+            ake::ProfScope ps(pass == 0 ? "cqt_fused_kernel" : "cqt_fused_kernel/deep", stream);
+            if (emit) hipLaunchKernelGGL((fz::cqt_fused_kernel<4, true>), grid, dim3(fz::kNT), lds_bytes, stream, a);
+            else if (NL == 4) hipLaunchKernelGGL((fz::cqt_fused_kernel<4, false>), grid, dim3(fz::kNT), lds_bytes, stream, a);
+            else if (NL == 3) hipLaunchKernelGGL((fz::cqt_fused_kernel<3, false>), grid, dim3(fz::kNT), lds_bytes, stream, a);
+            else if (NL == 2) hipLaunchKernelGGL((fz::cqt_fused_kernel<2, false>), grid, dim3(fz::kNT), lds_bytes, stream, a);
+            else hipLaunchKernelGGL((fz::cqt_fused_kernel<1, false>), grid, dim3(fz::kNT), lds_bytes, stream, a);
+        }
+    } else if (p->engine == 3) {
         BankCall2 call2;
         std::memset(&call2, 0, sizeof(call2));
         CascArgs a;
