@@ -6,7 +6,7 @@ OUT=../libake_hip.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
 mkdir -p build
-HEADERS="common.h pcnet_kernels.h pcnet_bwd_kernels.h pcnet_backward.h ../../include/ake_hip.h"
+HEADERS="common.h cqt_fused.h pcnet_kernels.h pcnet_bwd_kernels.h pcnet_backward.h ../../include/ake_hip.h"
 pids=()
 for f in common.cpp cqt.hip pcnet.hip pipeline.hip optim.hip; do
   obj=build/${f%.*}.o

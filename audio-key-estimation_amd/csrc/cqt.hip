@@ -837,7 +837,7 @@ int ake_cqt_plan_create(const ake_cqt_config* cfg_in, ake_cqt_plan** out) {
             uh_max = std::max(uh_max, static_cast<int>(std::ceil(-std::floor(-len[k0] / 2.0) / (1 << o))) + 1);
         }
         const int w4 = (2 * uh_max + 8 + 31) / 32 * 32;
-        const bool can_fz = p->half_len == 23 && n_oct <= 2 * fz::kMaxLv && w4 <= 32 * fz::kMaxBlk && (480 + 4 * w4) * 64 <= 160 * 1024;
+        const bool can_fz = p->half_len == 23 && n_oct <= 2 * fz::kMaxLv && w4 <= 32 * fz::kMaxBlk && (480 + 4 * w4) * 64 + fz::kStage * fz::kNT * 16 <= 160 * 1024;
         if (want == 4 && !can_fz) { ake::set_error("cqt: engine 4 needs decim_half_len 23, <= 8 octaves and tap windows <= %d samples (got %d)", 32 * fz::kMaxBlk, w4); ake_cqt_plan_destroy(p); return AKE_ERR_UNSUPPORTED; }
         p->engine = (want >= 1 && want <= 4) ? want : (can_fz ? 4 : (can_bf16 ? 3 : (can_fuse ? 2 : 1)));
         p->cfg.engine = p->engine;
@@ -1151,6 +1151,7 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
             a.n_clip = reinterpret_cast<const long long*>(n_clip);
             a.out = scratch; a.out_clip_stride = static_cast<long long>(T) * p->cfg.n_bins; a.n_bins_total = p->cfg.n_bins;
             a.table = p->table4_dev; a.toep = p->toep_dev;
+            if (const char* e = std::getenv("AKE_CQT_FZ_DBG")) a.dbg = std::atoi(e);
             long long m_end;                                              // exclusive end of what somebody must own, level-L0 sample numbers
             if (pass == 0) {
                 a.x = audio; a.x_stride = audio_stride; a.n_valid = n; a.pad_in = 0;
@@ -1178,7 +1179,7 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
                 a.lv[l].lds_off = lds_units;
                 lds_units += 2 * a.lv[l].ring_units * 16;
             }
-            const size_t lds_bytes = static_cast<size_t>(lds_units) * 16;
+            const size_t lds_bytes = static_cast<size_t>(lds_units) * 16 + static_cast<size_t>(fz::kStage) * fz::kNT * 16;   // rings + audio staging
             AKE_REQUIRE(lds_bytes <= 160 * 1024, AKE_ERR_UNSUPPORTED, "cqt engine 4: rings need %zu B of LDS", lds_bytes);
             // warm-up / tail steps: the deepest level's window reaches (uh + 8) * 2^D samples back and W - uh forward of a frame centre,
             // its samples depend on 23 * (2^D - 1) inputs either side, and level D runs lag_D samples behind the audio

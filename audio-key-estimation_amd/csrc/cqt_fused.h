@@ -5,7 +5,8 @@
 // kernel (132 MB written + 202 MB read per 256 clips next to the 339 MB of audio), and their cascade is a VALU FIR with 8
 // workgroup barriers per 4096 samples.  Here a workgroup owns 16 clips x one time segment and walks it in steps of 128 samples:
 //
-//   phase A  every thread splits 4 prefetched audio samples into (bf16 hi, bf16 lo) and writes them to the level-0 ring
+//   phase A  every thread takes 4 audio samples from the LDS staging ring (filled kStage steps ahead by LDS-DMA: no registers, no
+//            unrolling, ~40 KB in flight per CU), splits them into (bf16 hi, bf16 lo) and writes them to the level-0 ring
 //   barrier  (the only one per step)
 //   phase B  wave w computes ONE 16-outputs x 16-clips tile of the cascade -- waves 0-3 level 0->1, 4-5 level 1->2, 6 level 2->3,
 //            7 level 3->4 (every other step) -- as D[output n][clip] = Toeplitz(h)[n][k] . X[k][clip]: the filter taps are 6 constant
@@ -30,7 +31,7 @@ constexpr int kClips = 16;     // clips per workgroup = MFMA N
 constexpr int kStep = 128;     // input samples per step
 constexpr int kNT = 512;       // threads (8 waves)
 constexpr int kMaxLv = 4;      // octaves per launch
-constexpr int kPF = 3;         // audio tiles in flight per thread
+constexpr int kStage = 5;      // audio tiles (8 KB each) in flight per workgroup, LDS-DMA into a staging ring
 constexpr int kMaxBlk = 10;    // 32-tap blocks of a window (LDS bounds it: see rings())
 
 struct Level {
@@ -59,6 +60,7 @@ struct Args {
     Level lv[kMaxLv];
     const uint4* table;
     const uint4* toep;         // half-band Toeplitz fragments [3 k-steps][hi | lo][64 lanes]
+    int dbg;                   // timing experiments only (AKE_CQT_FZ_DBG): 1 no filter banks, 2 no cascade tiles, 4 no ring-0 writes, 8 no table touch
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -86,13 +88,18 @@ __device__ __forceinline__ f32x4 mfma3(const uint4& ah, const uint4& al, const u
     return acc;
 }
 
+// Stores the compiler must not count: hipcc waits (s_waitcnt vmcnt) before it reuses the registers of a pending store, and on the
+// step loop's common path such a wait drains the LDS-DMA queue it knows nothing about.  (s_nop 1: the store reads its data registers
+// after issue, cdna_hip_programming.md section 5.7.)
+__device__ __forceinline__ void store_f32x4(float* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_f32(float* p, float v) {
+    asm volatile("global_store_dword %0, %1, off\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ int wrap_once(int u, int n) { return u >= n ? u - n : u; }
 __device__ __forceinline__ int wrap_any(long long u, int n) { int r = static_cast<int>(u % n); return r < 0 ? r + n : r; }
-
-// last valid relative index of level l once phase A of step k has been written (level 0) / once phase B of step k - 1 is done
-__device__ __forceinline__ long long frontier(int l, int k) {
-    return l == 0 ? 128ll * k + 127 : (l == 1 ? 64ll * k - 17 : (l == 2 ? 32ll * k - 65 : 16ll * k - 65));
-}
 
 template <int NL, bool EMIT>
 __global__ __launch_bounds__(kNT) void cqt_fused_kernel(Args a) {
@@ -122,23 +129,34 @@ __global__ __launch_bounds__(kNT) void cqt_fused_kernel(Args a) {
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) { th[ks] = a.toep[(ks * 2 + 0) * 64 + lane]; tl[ks] = a.toep[(ks * 2 + 1) * 64 + lane]; }
 
-    // ---- audio loader: thread = (clip tid >> 5, samples 4 * (tid & 31) .. + 3 of the step's 128) ----
-    const int ld_c = tid >> 5, ld_s = tid & 31;
+    // ---- audio loader.  Thread -> (clip (wave & 1) * 8 + (lane & 7), samples 4 * ((wave >> 1) * 8 + (lane >> 3)) .. + 3 of the step's
+    // 128): a wave instruction fetches 8 clips x 128 contiguous bytes, and the ring-0 stores of a 16-lane group (8 clips x 2 halves
+    // of one 8-sample unit) fall on 32 different banks.  The tile goes global -> LDS staging slot by LDS-DMA (asm: hipcc would order
+    // every later LDS access behind a builtin DMA with vmcnt(0)); each thread later reads back exactly the 16 bytes its own lane
+    // fetched, so the only ordering needed is this wave's own counted vmcnt. ----
+    const int ld_c = (wave & 1) * 8 + (lane & 7), ld_s = (wave >> 1) * 8 + (lane >> 3);
     const int ld_clip = grp * kClips + ld_c < a.batch ? grp * kClips + ld_c : a.batch - 1;
     long long nv = a.n_valid;
     if (a.n_clip && a.L0 == 0) { const long long nc = a.n_clip[ld_clip]; nv = nc < 0 ? 0 : (nc < nv ? nc : nv); }
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
     const long long ld_row = static_cast<long long>(ld_clip) * a.x_stride;
     const long long ld_i0 = M0 + a.pad_in + 4 * ld_s;                 // array index of this thread's samples in step 0
-    f32x4 pre[kPF];
-    auto fetch = [&](int k) -> f32x4 {
-        const long long gi = ld_i0 + static_cast<long long>(k) * kStep;
-        // byte offset into the whole tensor; a negative index of clip 0 wraps to a huge offset = out of range = 0
-        const unsigned off = static_cast<unsigned>((ld_row + gi) * 4);
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    const long long ld_max = static_cast<long long>(a.x_bytes / 4) - 4;   // last float4 inside the tensor
+    uint4* const stage = lds + lds_total;                             // [kStage][512] float4, lane-linear per wave
+    auto dma = [&](int k) {                                           // tile k -> slot k % kStage (out-of-clip samples are masked at use)
+        long long gi = ld_row + ld_i0 + static_cast<long long>(k) * kStep;
+        if (a.dbg & 128) {                                            // timing experiment: 1 KiB of ONE clip per wave instruction
+            const int cl = grp * kClips + 2 * wave + (k & 1);
+            gi = static_cast<long long>(cl < a.batch ? cl : a.batch - 1) * a.x_stride + M0 + a.pad_in + static_cast<long long>(k >> 1) * 256 + 4 * lane;
+        }
+        gi = gi < 0 ? 0 : (gi > ld_max ? ld_max : gi);                // any in-tensor address will do where the samples are masked
+        const float* src = a.x + gi;
+        const unsigned int dst = static_cast<unsigned int>(reinterpret_cast<unsigned long long>(stage + (k % kStage) * kNT + wave * 64));
+        unsigned int keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     };
 #pragma unroll
-    for (int i = 0; i < kPF; ++i) pre[i] = fetch(i);
+    for (int i = 0; i < kStage; ++i) dma(i);
 
     // ---- cascade role of this wave: stage s, tile tw; ring units of its input window and output tile at step 0 ----
     const int st = wave < 4 ? 0 : (wave < 6 ? 1 : (wave == 6 ? 2 : 3));
@@ -165,17 +183,19 @@ __global__ __launch_bounds__(kNT) void cqt_fused_kernel(Args a) {
     auto tb = [&](long long X) -> long long { return X <= 0 ? 0 : ((X << a.L0) + a.hop - 1) / a.hop; };
     const int t_first = static_cast<int>(tb(Ms));
     const int t_end = static_cast<int>(tb(Me) < a.T ? tb(Me) : a.T);
-    // Per level: next frame, its filter-bank phase, and the step at which its tap window is complete.  The Level records are read
-    // through a laundered kernel-argument pointer INSIDE the (rare) blocks that need them: as plain kernel arguments the compiler
-    // keeps all ~100 of their dwords live in SGPRs across the step loop and spills them (measured: 1 700 SGPR spills, 70 VGPRs to scratch)
-    const char* kargs = (const char*)__builtin_amdgcn_kernarg_segment_ptr();   // (C cast: address space 4 -> generic)
-    auto level_ptr = [&](int l) -> const Level* {
-        const Level* pL = reinterpret_cast<const Level*>(kargs + offsetof(Args, lv)) + l;
+    // Per level: next frame, its filter-bank phase, the step at which its tap window is complete and the step at which its table
+    // lines are pulled into this XCD's L2.  The Level records are read with scalar loads through a laundered kernel-argument pointer
+    // INSIDE the (rare) blocks that need them: as plain kernel arguments the compiler keeps all ~100 of their dwords live in SGPRs
+    // across the step loop and spills them (measured: 1 700 SGPR spills, 70 VGPRs to scratch)
+    typedef const __attribute__((address_space(4))) Level* LevelCP;
+    typedef const __attribute__((address_space(4))) char* CharCP;
+    auto level_ptr = [&](int l) -> LevelCP {
+        LevelCP pL = (LevelCP)((CharCP)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(Args, lv)) + l;
         asm volatile("" : "+s"(pL));
         return pL;
     };
     // anchored window start of (t, level l): relative index / 8, and the first step whose frontier covers the window
-    auto window_of = [&](const Level* L, int l, int t, long long& a_unit) -> int {
+    auto window_of = [&](LevelCP L, int l, int t, long long& a_unit) -> int {
         const int sh = a.L0 + l;
         const long long E = static_cast<long long>(t) * a.hop - (static_cast<long long>(L->uh) << sh);   // nominal start, full-rate position
         a_unit = (E >> (sh + 3)) - ((M0 >> l) >> 3);
@@ -186,7 +206,7 @@ __global__ __launch_bounds__(kNT) void cqt_fused_kernel(Args a) {
     int tn[NL], pi[NL], kfire[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-        const Level* L = level_ptr(l);
+        LevelCP L = level_ptr(l);
         tn[l] = t_first;
         pi[l] = t_first % L->period;
         long long au;
@@ -196,29 +216,50 @@ __global__ __launch_bounds__(kNT) void cqt_fused_kernel(Args a) {
     const int my_clip = grp * kClips + c16;                           // MFMA column of this lane
     int tc = a.T;                                                     // frames of this clip (the rest is zero padding)
     if (a.n_clip && my_clip < a.batch) { const long long nc = a.n_clip[my_clip]; const long long f = nc < 0 ? 0 : 1 + nc / a.hop; tc = f < tc ? static_cast<int>(f) : tc; }
+    {   // Materialise every loop invariant that came from a (tracked) load BEFORE the step loop: hipcc waits for a pending load at its
+        // first use, and a first use inside the loop becomes an s_waitcnt vmcnt(0) on EVERY step -- which drains the untracked DMA queue
+        // (measured: the staging ring then holds one tile in flight instead of kStage)
+        unsigned int nlo = static_cast<unsigned int>(nv), nhi = static_cast<unsigned int>(static_cast<unsigned long long>(nv) >> 32);
+        asm volatile("" : "+v"(nlo), "+v"(nhi), "+v"(tc));
+        nv = static_cast<long long>((static_cast<unsigned long long>(nhi) << 32) | nlo);
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            asm volatile("" : "+v"(th[ks].x), "+v"(th[ks].y), "+v"(th[ks].z), "+v"(th[ks].w));
+            asm volatile("" : "+v"(tl[ks].x), "+v"(tl[ks].y), "+v"(tl[ks].z), "+v"(tl[ks].w));
+        }
+    }
     __syncthreads();
 
     for (int k = 0; k < n_steps; ++k) {
-        // ================= phase A: audio tile k -> level-0 ring =================
+        // ================= phase A: audio tile k (staging slot k % kStage) -> level-0 ring =================
         {
-            const f32x4 v = pre[0];
-#pragma unroll
-            for (int i = 0; i + 1 < kPF; ++i) pre[i] = pre[i + 1];
-            pre[kPF - 1] = fetch(k + kPF);
+            // the kStage - 1 younger DMA tiles may still be in flight; anything issued after them only makes this wait longer
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kStage - 1) : "memory");
+            const f32x4 v = __builtin_bit_cast(f32x4, stage[(k % kStage) * kNT + tid]);
             const long long gi = ld_i0 + static_cast<long long>(k) * kStep;
             const long long left = gi < 0 ? 0 : nv - gi;              // valid samples from gi on (gi is a multiple of 4)
-            const float r0 = left > 0 ? v[0] : 0.f, r1 = left > 1 ? v[1] : 0.f, r2 = left > 2 ? v[2] : 0.f, r3 = left > 3 ? v[3] : 0.f;
+            // the last vector of the whole tensor may have been fetched from up to 3 floats earlier (dma() keeps every address inside it)
+            const long long over = ld_row + gi - ld_max;
+            const int sh = over > 0 ? static_cast<int>(over) : 0;
+            const float e0 = sh == 0 ? v[0] : (sh == 1 ? v[1] : (sh == 2 ? v[2] : v[3]));
+            const float e1 = sh == 0 ? v[1] : (sh == 1 ? v[2] : v[3]);
+            const float e2 = sh == 0 ? v[2] : v[3];
+            const float r0 = left > 0 ? e0 : 0.f, r1 = left > 1 ? e1 : 0.f, r2 = left > 2 ? e2 : 0.f, r3 = left > 3 ? v[3] : 0.f;
             uint2 hi, lo;
             split4(r0, r1, r2, r3, hi, lo);
-            const int u = wrap_once(u_a + (ld_s >> 1), ru0);
+            const int u = (a.dbg & 32) ? (ld_s >> 1) : wrap_once(u_a + (ld_s >> 1), ru0);
             uint2* ph = reinterpret_cast<uint2*>(lds + lds_off0);
             uint2* pl = reinterpret_cast<uint2*>(lds + lds_off0 + ru0 * 16);
-            ph[(u * 16 + ld_c) * 2 + (ld_s & 1)] = hi;
-            pl[(u * 16 + ld_c) * 2 + (ld_s & 1)] = lo;
+            if (!(a.dbg & 4) && (!(a.dbg & 64) || wave < 4)) {
+                ph[(u * 16 + ld_c) * 2 + (ld_s & 1)] = hi;
+                pl[(u * 16 + ld_c) * 2 + (ld_s & 1)] = lo;
+            } else if (a.dbg & 16) {
+                asm volatile("" :: "v"(hi.x), "v"(hi.y), "v"(lo.x), "v"(lo.y));     // timing: staging read + split stay, the ring stores go
+            }
         }
         __syncthreads();
         // ================= phase B: one cascade tile per wave =================
-        if (has_stage && (st < 3 || (k & 1) == 0)) {
+        if (has_stage && (st < 3 || (k & 1) == 0) && !(a.dbg & 2)) {
             const uint4* ph = lds + off_in;
             const uint4* pl = ph + ru_in * 16;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -241,14 +282,15 @@ __global__ __launch_bounds__(kNT) void cqt_fused_kernel(Args a) {
                 const long long m = (static_cast<long long>(kStep >> NL) * k - 64) + 4 * q + (M0 >> NL);
                 const long long idx = m + a.pad_next;
                 if (my_clip < a.batch && m >= (Ms >> NL) && m < (Me >> NL) && idx >= 0 && idx + 4 <= a.next_count)
-                    *reinterpret_cast<float4*>(a.next + my_clip * a.next_stride + idx) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                    store_f32x4(a.next + my_clip * a.next_stride + idx, acc);
             }
         }
-        // ================= phase B: filter banks whose tap windows are complete =================
+        // ================= phase B: filter banks =================
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            while (k >= kfire[l]) {
-                const Level* L = level_ptr(l);
+            while (k >= kfire[l]) {                                     // the tap window of frame tn[l] is complete: run its bank
+                if (a.dbg & 1) { kfire[l] = 0x7fffffff; break; }
+                LevelCP L = level_ptr(l);
                 const int t = tn[l];
                 long long a_unit;
                 (void)window_of(L, l, t, a_unit);
@@ -279,6 +321,10 @@ __global__ __launch_bounds__(kNT) void cqt_fused_kernel(Args a) {
                             acc = mfma3(fh[b], fl[b], ph[u * 16 + c16], pl[u * 16 + c16], acc);
                         }
                     }
+                    // every fragment register is read here, also those of the clamped (unused) requests: a load left pending at the end
+                    // of this rare block would make hipcc wait for it wherever its register is next written -- on every step
+#pragma unroll
+                    for (int b = 0; b < kMaxBlk; ++b) asm volatile("" :: "v"(fh[b].x), "v"(fl[b].x));
                     // D[row = 2 * bin + (re | im)][col = clip]: this lane holds bins 2q, 2q + 1 of the tile (re, im, re, im)
                     if (my_clip < a.batch) {
                         float* o = a.out + my_clip * a.out_clip_stride + static_cast<long long>(t) * a.n_bins_total + L->k0 + kTileBins * j + 2 * q;
@@ -286,8 +332,8 @@ __global__ __launch_bounds__(kNT) void cqt_fused_kernel(Args a) {
                         const float m0 = __logf(1.f + __builtin_amdgcn_sqrtf(acc[0] * acc[0] + acc[1] * acc[1]));
                         const float m1 = __logf(1.f + __builtin_amdgcn_sqrtf(acc[2] * acc[2] + acc[3] * acc[3]));
                         const int nb = L->n_bins;
-                        if (kTileBins * j + 2 * q < nb) o[0] = live ? m0 : 0.f;
-                        if (kTileBins * j + 2 * q + 1 < nb) o[1] = live ? m1 : 0.f;
+                        if (kTileBins * j + 2 * q < nb) store_f32(o, live ? m0 : 0.f);
+                        if (kTileBins * j + 2 * q + 1 < nb) store_f32(o + 1, live ? m1 : 0.f);
                     }
                 }
                 ++tn[l];
@@ -296,6 +342,7 @@ __global__ __launch_bounds__(kNT) void cqt_fused_kernel(Args a) {
                 kfire[l] = tn[l] < t_end ? window_of(L, l, tn[l], au) : 0x7fffffff;
             }
         }
+        dma(k + kStage);                                                // refill the slot this step consumed (this wave's own 1 KiB of it)
         // ---- advance the ring positions ----
         u_a = wrap_once(u_a + 16, ru0);
         if (has_stage) {

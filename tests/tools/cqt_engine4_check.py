@@ -55,7 +55,9 @@ def main():
     if "--time" in sys.argv:
         from ake_amd import synthetic
         audio, _ = synthetic.make_batch_device(range(256), torch.device(DEV))
-        for eng in (3, 4):
+        runs = [(3, "0"), (4, "0")] + ([(4, d) for d in ("1", "3", "7", "135", "129")] if "--dbg" in sys.argv else [])
+        for eng, dbg in runs:
+            os.environ["AKE_CQT_FZ_DBG"] = dbg
             p = CQTPlan(22050, 4410, 288, 36, engine=eng)
             for _ in range(3):
                 p.logmag(audio)
@@ -70,7 +72,7 @@ def main():
                 p.logmag(audio)
             res = ake_amd._lib.prof_results()
             ake_amd._lib.prof_enable("", False)
-            print(f"engine {eng}: {dt * 1e3:.3f} ms per 256 clips;", {k: round(v[0] / 5, 4) for k, v in res.items()}, flush=True)
+            print(f"engine {eng} dbg {dbg}: {dt * 1e3:.3f} ms per 256 clips;", {k: round(v[0] / 5, 4) for k, v in res.items()}, flush=True)
     print("BAD CASES:", bad)
 
 
