@@ -837,7 +837,7 @@ int ake_cqt_plan_create(const ake_cqt_config* cfg_in, ake_cqt_plan** out) {
             uh_max = std::max(uh_max, static_cast<int>(std::ceil(-std::floor(-len[k0] / 2.0) / (1 << o))) + 1);
         }
         const int w4 = (2 * uh_max + 8 + 31) / 32 * 32;
-        const bool can_fz = p->half_len == 23 && n_oct <= 2 * fz::kMaxLv && w4 <= 32 * fz::kMaxBlk && (480 + 4 * w4) * 64 + fz::kStage * fz::kNT * 16 <= 160 * 1024;
+        const bool can_fz = p->half_len == 23 && n_oct <= 2 * fz::kMaxLv && w4 <= 32 * fz::kMaxBlk && true;
         if (want == 4 && !can_fz) { ake::set_error("cqt: engine 4 needs decim_half_len 23, <= 8 octaves and tap windows <= %d samples (got %d)", 32 * fz::kMaxBlk, w4); ake_cqt_plan_destroy(p); return AKE_ERR_UNSUPPORTED; }
         p->engine = (want >= 1 && want <= 4) ? want : (can_fz ? 4 : (can_bf16 ? 3 : (can_fuse ? 2 : 1)));
         p->cfg.engine = p->engine;
@@ -944,7 +944,7 @@ int ake_cqt_plan_create(const ake_cqt_config* cfg_in, ake_cqt_plan** out) {
             what = "hipFuncSetAttribute(max dynamic LDS)";
             const void* fns[] = {reinterpret_cast<const void*>(fz::cqt_fused_kernel<1, false>), reinterpret_cast<const void*>(fz::cqt_fused_kernel<2, false>),
                                  reinterpret_cast<const void*>(fz::cqt_fused_kernel<3, false>), reinterpret_cast<const void*>(fz::cqt_fused_kernel<4, false>),
-                                 reinterpret_cast<const void*>(fz::cqt_fused_kernel<4, true>)};
+                                 reinterpret_cast<const void*>(fz::cqt_fused_kernel<4, true>), reinterpret_cast<const void*>(fz::cqt_fused_kernel<4, true, true>)};
             for (const void* f : fns)
                 if (e4 == hipSuccess) e4 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
@@ -1171,15 +1171,17 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
                 a.M_begin = 0;
                 m_end = (((T - 1) * static_cast<long long>(a.hop)) >> L0) + 1;
             }
-            // rings: level l holds (256 >> l) + W samples (what a step produces twice over + one tap window), see cqt_fused.h
+            // rings: level l holds what a step produces twice over + one PART of a tap window (and at least what its cascade stage
+            // reads back), see cqt_fused.h
             int lds_units = 0;
             for (int l = 0; l < NL; ++l) {
                 a.lv[l] = p->flv[L0 + l];
-                a.lv[l].ring_units = ((256 >> l) + 32 * a.lv[l].n_blk) / 8;
+                static const int casc_need[4] = {312, 200, 120, 104};
+                a.lv[l].ring_units = (std::max((256 >> l) + 32 * fz::kPart, casc_need[l]) + 7) / 8;
                 a.lv[l].lds_off = lds_units;
                 lds_units += 2 * a.lv[l].ring_units * 16;
             }
-            const size_t lds_bytes = static_cast<size_t>(lds_units) * 16 + static_cast<size_t>(fz::kStage) * fz::kNT * 16;   // rings + audio staging
+            const size_t lds_bytes = static_cast<size_t>(lds_units) * 16 + static_cast<size_t>(fz::kStage) * fz::kNC * 16 + 6 * 64 * 16;   // rings + audio staging + Toeplitz fragments
             AKE_REQUIRE(lds_bytes <= 160 * 1024, AKE_ERR_UNSUPPORTED, "cqt engine 4: rings need %zu B of LDS", lds_bytes);
             // warm-up / tail steps: the deepest level's window reaches (uh + 8) * 2^D samples back and W - uh forward of a frame centre,
             // its samples depend on 23 * (2^D - 1) inputs either side, and level D runs lag_D samples behind the audio
@@ -1198,7 +1200,24 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
             const int n_wg = n_groups * a.n_seg;
             dim3 grid((n_wg + 7) / 8 * 8);
             ake::ProfScope ps(pass == 0 ? "cqt_fused_kernel" : "cqt_fused_kernel/deep", stream);
-            if (emit) hipLaunchKernelGGL((fz::cqt_fused_kernel<4, true>), grid, dim3(fz::kNT), lds_bytes, stream, a);
+            static const bool stamp_env = std::getenv("AKE_CQT_FZ_STAMP") != nullptr;
+            if (emit && stamp_env) {
+                // diagnostic build: in-kernel cycle stamps of the step loop's sections (workgroup 0), printed to stderr; never timed
+                unsigned long long* sb = nullptr;
+                if (hipMalloc(&sb, 64 * sizeof(unsigned long long)) == hipSuccess) {
+                    (void)hipMemsetAsync(sb, 0, 64 * sizeof(unsigned long long), stream);
+                    a.stamps = sb;
+                    hipLaunchKernelGGL((fz::cqt_fused_kernel<4, true, true>), grid, dim3(fz::kNT), lds_bytes, stream, a);
+                    unsigned long long hb[64];
+                    (void)hipMemcpyAsync(hb, sb, sizeof(hb), hipMemcpyDeviceToHost, stream);
+                    (void)hipStreamSynchronize(stream);
+                    (void)hipFree(sb);
+                    for (int wv = 0; wv < 8; ++wv)
+                        fprintf(stderr, "fz stamps wave %d: steps %llu  cycles/step: barrier %.0f convert %.0f cascade %.0f banks %.0f rest %.0f\n", wv, hb[wv * 8 + 5],
+                                hb[wv * 8 + 0] / double(hb[wv * 8 + 5]), hb[wv * 8 + 1] / double(hb[wv * 8 + 5]), hb[wv * 8 + 2] / double(hb[wv * 8 + 5]),
+                                hb[wv * 8 + 3] / double(hb[wv * 8 + 5]), hb[wv * 8 + 4] / double(hb[wv * 8 + 5]));
+                }
+            } else if (emit) hipLaunchKernelGGL((fz::cqt_fused_kernel<4, true>), grid, dim3(fz::kNT), lds_bytes, stream, a);
             else if (NL == 4) hipLaunchKernelGGL((fz::cqt_fused_kernel<4, false>), grid, dim3(fz::kNT), lds_bytes, stream, a);
             else if (NL == 3) hipLaunchKernelGGL((fz::cqt_fused_kernel<3, false>), grid, dim3(fz::kNT), lds_bytes, stream, a);
             else if (NL == 2) hipLaunchKernelGGL((fz::cqt_fused_kernel<2, false>), grid, dim3(fz::kNT), lds_bytes, stream, a);

@@ -55,7 +55,7 @@ def main():
     if "--time" in sys.argv:
         from ake_amd import synthetic
         audio, _ = synthetic.make_batch_device(range(256), torch.device(DEV))
-        runs = [(3, "0"), (4, "0")] + ([(4, d) for d in ("1", "3", "7", "135", "129")] if "--dbg" in sys.argv else [])
+        runs = [(3, "0"), (4, "0")] + ([(4, d) for d in ("7", "263", "519")] if "--dbg" in sys.argv else [])
         for eng, dbg in runs:
             os.environ["AKE_CQT_FZ_DBG"] = dbg
             p = CQTPlan(22050, 4410, 288, 36, engine=eng)
