@@ -536,14 +536,14 @@ typedef float f32x4b __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(1024) void cqt_bank_bf16_kernel(
     BankCall2 call, const OctDesc2* __restrict__ octs, const uint4* __restrict__ table,
-    int batch, int hop, int hop_twos, float* __restrict__ out, long long out_clip_stride, int n_bins_total, int n_frames) {
+    int batch, int hop, int hop_twos, float* __restrict__ out, long long out_clip_stride, int n_bins_total, int n_frames, int o_first) {
     extern __shared__ __attribute__((aligned(16))) uint4 ldsW[];
     // gridDim.x is a multiple of 8, so blockIdx.x % 8 is the XCD: consecutive frames go to ONE XCD, whose L2 then serves the parts of
     // their tap windows that overlap (the windows of octaves 5..7 overlap 2-8 fold)
     const int per_xcd = gridDim.x >> 3;
     const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (t >= n_frames) return;
-    const int o = blockIdx.y;
+    const int o = blockIdx.y + o_first;                             // (engine 4 runs this kernel for the octaves below its fused four)
     const OctDesc2 g = octs[o];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -837,8 +837,18 @@ int ake_cqt_plan_create(const ake_cqt_config* cfg_in, ake_cqt_plan** out) {
             uh_max = std::max(uh_max, static_cast<int>(std::ceil(-std::floor(-len[k0] / 2.0) / (1 << o))) + 1);
         }
         const int w4 = (2 * uh_max + 8 + 31) / 32 * 32;
-        const bool can_fz = p->half_len == 23 && n_oct <= 2 * fz::kMaxLv && w4 <= 32 * fz::kMaxBlk && true;
-        if (want == 4 && !can_fz) { ake::set_error("cqt: engine 4 needs decim_half_len 23, <= 8 octaves and tap windows <= %d samples (got %d)", 32 * fz::kMaxBlk, w4); ake_cqt_plan_destroy(p); return AKE_ERR_UNSUPPORTED; }
+        // ... whose parts need the windows of consecutive frames disjoint enough at each of its (up to four) levels: hop / 2^l >= window - part;
+        // the octaves below the fourth go through engine 3's cascade + bank (from level 4), which needs at least two of them
+        bool parts_ok = true;
+        for (int l = 0; l < std::min(n_oct, fz::kMaxLv); ++l) parts_ok = parts_ok && (cfg.hop_length >> l) >= w4 - 32 * fz::kPart + 16;
+        const bool can_fz = p->half_len == 23 && w4 <= 32 * fz::kMaxBlk && parts_ok &&
+                            (n_oct <= fz::kMaxLv || (n_oct >= fz::kMaxLv + 2 && n_oct <= fz::kMaxLv + kCascMax + 1));
+        if (want == 4 && !can_fz) {
+            ake::set_error("cqt: engine 4 needs decim_half_len 23, 1-4 or 6-%d octaves, tap windows <= %d samples (got %d) and hop >= %d", fz::kMaxLv + kCascMax + 1,
+                           32 * fz::kMaxBlk, w4, (w4 - 32 * fz::kPart + 16) << (std::min(n_oct, fz::kMaxLv) - 1));
+            ake_cqt_plan_destroy(p);
+            return AKE_ERR_UNSUPPORTED;
+        }
         p->engine = (want >= 1 && want <= 4) ? want : (can_fz ? 4 : (can_bf16 ? 3 : (can_fuse ? 2 : 1)));
         p->cfg.engine = p->engine;
     }
@@ -866,7 +876,8 @@ int ake_cqt_plan_create(const ake_cqt_config* cfg_in, ake_cqt_plan** out) {
         // one filter bank per octave and per anchored phase (t * hop - uh * 2^o) mod (8 * 2^o), MFMA A-fragment order
         // [phase][32-tap block][N-tile][hi | lo][64 lanes] x 8 bf16
         size_t total16 = 0;                                                     // 16-byte units
-        for (int o = 0; o < n_oct; ++o) {
+        const int n_fz = std::min(n_oct, fz::kMaxLv);
+        for (int o = 0; o < n_fz; ++o) {
             const int dec = 1 << o;
             fz::Level g;
             std::memset(&g, 0, sizeof(g));
@@ -891,7 +902,7 @@ int ake_cqt_plan_create(const ake_cqt_config* cfg_in, ake_cqt_plan** out) {
         std::vector<uint16_t> t4(total16 * 8, 0);
         struct Job { int o, pi; };
         std::vector<Job> jobs;
-        for (int o = 0; o < n_oct; ++o) for (int pi = 0; pi < p->flv[o].period; ++pi) jobs.push_back({o, pi});
+        for (int o = 0; o < n_fz; ++o) for (int pi = 0; pi < p->flv[o].period; ++pi) jobs.push_back({o, pi});
         auto fill = [&](size_t j0, size_t j1) {
             for (size_t ji = j0; ji < j1; ++ji) {
                 const int o = jobs[ji].o, pi = jobs[ji].pi;
@@ -959,7 +970,7 @@ int ake_cqt_plan_create(const ake_cqt_config* cfg_in, ake_cqt_plan** out) {
             return AKE_ERR_HIP;
         }
     }
-    if (p->engine == 3) {
+    if (p->engine == 3 || (p->engine == 4 && n_oct > fz::kMaxLv)) {        // (engine 4: for the octaves below its fused four)
         auto bf16_rne = [](float v) -> uint16_t {
             uint32_t u;
             std::memcpy(&u, &v, 4);
@@ -1065,7 +1076,11 @@ size_t ake_cqt_workspace_bytes(const ake_cqt_plan* p, int batch, int64_t n_sampl
     if (!p || batch <= 0 || n_samples <= 0) return 0;
     ake::Carver c(nullptr, 0);
     if (p->engine == 4) {
-        if (p->n_oct > fz::kMaxLv) c.take<float>(static_cast<size_t>(batch) * next_len(n_samples));                        // level 4 between the two launches
+        if (p->n_oct > fz::kMaxLv) {
+            c.take<float>(static_cast<size_t>(batch) * next_len(n_samples));                                              // level 4, f32
+            for (int l = 0; l + fz::kMaxLv < p->n_oct; ++l)                                                               // split-bf16 levels 4.. for the bank
+                c.take<unsigned int>(static_cast<size_t>(batch) * plane_len(p, l, next_len(n_samples)));
+        }
     } else if (p->engine == 3) {
         for (int l = 0; l < p->n_oct; ++l) c.take<unsigned int>(static_cast<size_t>(batch) * plane_len(p, l, n_samples));   // split-bf16 level signals
     } else {
@@ -1114,20 +1129,21 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
     ake::Carver c(workspace, ws_bytes);
     float* scratch = nullptr;
     constexpr int C = 4096, NT = 256;
-    auto fill_cascade = [&](CascArgs& a, int fused) {
+    auto fill_cascade_on = [&](CascArgs& a, int fused, const float* x_in, int64_t x_stride, int64_t n_in, const int64_t* n_clip_in) {
         std::memset(&a, 0, sizeof(a));
-        a.x = audio; a.x_stride = audio_stride; a.n = static_cast<int>(n);
-        a.n_clip = reinterpret_cast<const long long*>(n_clip);
+        a.x = x_in; a.x_stride = x_stride; a.n = static_cast<int>(n_in);
+        a.n_clip = reinterpret_cast<const long long*>(n_clip_in);
         a.pad = pad_of(p); a.hop = p->cfg.hop_length; a.n_stage = fused; a.taps = p->taps;
-        for (int l = 1; l <= fused; ++l) a.y_count[l] = len_store(p, l, n);
+        for (int l = 1; l <= fused; ++l) a.y_count[l] = len_store(p, l, n_in);
         a.g0 = -512;
-        const long long g1 = n + static_cast<long long>(25 + kLagHost[fused]) * (1ll << fused) + 512;
+        const long long g1 = n_in + static_cast<long long>(25 + kLagHost[fused]) * (1ll << fused) + 512;
         a.ticks_total = static_cast<int>((g1 - a.g0 + C - 1) / C);
         static const int segs_env = std::getenv("AKE_CQT_SEGS") ? std::atoi(std::getenv("AKE_CQT_SEGS")) : 0;
         const int segs = std::max(1, std::min(a.ticks_total, segs_env > 0 ? segs_env : 4));
         a.ticks_per_seg = (a.ticks_total + segs - 1) / segs;
         a.warm = 3;                                         // >= 64 * 2^7 / C ticks of history before the first owned tick
     };
+    auto fill_cascade = [&](CascArgs& a, int fused) { fill_cascade_on(a, fused, audio, audio_stride, n, n_clip); };
     auto launch_cascade = [&](const CascArgs& a) {
         dim3 grid((a.ticks_total + a.ticks_per_seg - 1) / a.ticks_per_seg, batch);
         ake::ProfScope ps("cqt_cascade_kernel", stream);
@@ -1138,50 +1154,49 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
         else hipLaunchKernelGGL((cqt_cascade_kernel<12, C, NT, false>), grid, dim3(NT), 0, stream, a);
     };
     if (p->engine == 4) {
-        float* next = p->n_oct > fz::kMaxLv ? c.take<float>(static_cast<size_t>(batch) * next_len(n)) : nullptr;
+        const bool deep = p->n_oct > fz::kMaxLv;
+        const int n_next = next_len(n);
+        float* next = deep ? c.take<float>(static_cast<size_t>(batch) * n_next) : nullptr;
+        unsigned int* planes[kMaxOct] = {nullptr};
+        int plane_n[kMaxOct] = {0};
+        if (deep)
+            for (int l = 0; l + fz::kMaxLv < p->n_oct; ++l) {
+                plane_n[l] = plane_len(p, l, n_next);
+                planes[l] = c.take<unsigned int>(static_cast<size_t>(batch) * plane_n[l]);
+            }
         scratch = c.take<float>(static_cast<size_t>(batch) * T * p->cfg.n_bins);
         const int n_groups = (batch + fz::kClips - 1) / fz::kClips;
-        for (int pass = 0; pass * fz::kMaxLv < p->n_oct; ++pass) {
+        {
             fz::Args a;
             std::memset(&a, 0, sizeof(a));
-            const int L0 = pass * fz::kMaxLv;
-            const int NL = std::min(fz::kMaxLv, p->n_oct - L0);
-            const bool emit = pass == 0 && p->n_oct > fz::kMaxLv;
-            a.L0 = L0; a.hop = p->cfg.hop_length; a.batch = batch; a.T = static_cast<int>(T);
+            const int NL = std::min(fz::kMaxLv, p->n_oct);
+            a.L0 = 0; a.hop = p->cfg.hop_length; a.batch = batch; a.T = static_cast<int>(T);
             a.n_clip = reinterpret_cast<const long long*>(n_clip);
             a.out = scratch; a.out_clip_stride = static_cast<long long>(T) * p->cfg.n_bins; a.n_bins_total = p->cfg.n_bins;
             a.table = p->table4_dev; a.toep = p->toep_dev;
             if (const char* e = std::getenv("AKE_CQT_FZ_DBG")) a.dbg = std::atoi(e);
-            long long m_end;                                              // exclusive end of what somebody must own, level-L0 sample numbers
-            if (pass == 0) {
-                a.x = audio; a.x_stride = audio_stride; a.n_valid = n; a.pad_in = 0;
-                AKE_REQUIRE(static_cast<unsigned long long>(batch) * audio_stride * 4 < 0xFFF00000ull, AKE_ERR_UNSUPPORTED,
-                            "cqt engine 4: the audio tensor must stay below 4 GiB per call (%d clips x %lld samples): split the batch", batch,
-                            static_cast<long long>(audio_stride));
-                a.x_bytes = static_cast<unsigned>(static_cast<unsigned long long>(batch) * audio_stride * 4);
-                a.M_begin = emit ? -16ll * kNextPad / 128 * 128 - (16 * kNextPad % 128 ? 128 : 0) : 0;
-                m_end = n + 1;
-                if (emit) {
-                    a.next = next; a.next_stride = next_len(n); a.next_count = next_len(n); a.pad_next = kNextPad;
-                    m_end = std::max<long long>(m_end, 16ll * (a.next_count - kNextPad));
-                }
-            } else {
-                a.x = next; a.x_stride = next_len(n); a.n_valid = next_len(n); a.pad_in = kNextPad;
-                a.x_bytes = static_cast<unsigned>(static_cast<unsigned long long>(batch) * a.x_stride * 4);
-                a.M_begin = 0;
-                m_end = (((T - 1) * static_cast<long long>(a.hop)) >> L0) + 1;
+            a.x = audio; a.x_stride = audio_stride; a.n_valid = n; a.pad_in = 0;
+            AKE_REQUIRE(static_cast<unsigned long long>(batch) * audio_stride * 4 < 0xFFF00000ull, AKE_ERR_UNSUPPORTED,
+                        "cqt engine 4: the audio tensor must stay below 4 GiB per call (%d clips x %lld samples): split the batch", batch,
+                        static_cast<long long>(audio_stride));
+            a.x_bytes = static_cast<unsigned>(static_cast<unsigned long long>(batch) * audio_stride * 4);
+            a.M_begin = deep ? -(16ll * kNextPad + fz::kStep - 1) / fz::kStep * fz::kStep : 0;
+            long long m_end = n + 1;                                      // exclusive end of what somebody must own (sample numbers)
+            if (deep) {
+                a.next = next; a.next_stride = n_next; a.next_count = n_next; a.pad_next = kNextPad;
+                m_end = std::max<long long>(m_end, 16ll * (n_next - kNextPad));
             }
             // rings: level l holds what a step produces twice over + one PART of a tap window (and at least what its cascade stage
             // reads back), see cqt_fused.h
             int lds_units = 0;
             for (int l = 0; l < NL; ++l) {
-                a.lv[l] = p->flv[L0 + l];
+                a.lv[l] = p->flv[l];
                 static const int casc_need[4] = {312, 200, 120, 104};
                 a.lv[l].ring_units = (std::max((256 >> l) + 32 * fz::kPart, casc_need[l]) + 7) / 8;
                 a.lv[l].lds_off = lds_units;
                 lds_units += 2 * a.lv[l].ring_units * 16;
             }
-            const size_t lds_bytes = static_cast<size_t>(lds_units) * 16 + static_cast<size_t>(fz::kStage) * fz::kNC * 16 + 6 * 64 * 16;   // rings + audio staging + Toeplitz fragments
+            const size_t lds_bytes = static_cast<size_t>(lds_units) * 16 + static_cast<size_t>(fz::kStage) * fz::kNT * 16;   // rings + audio staging
             AKE_REQUIRE(lds_bytes <= 160 * 1024, AKE_ERR_UNSUPPORTED, "cqt engine 4: rings need %zu B of LDS", lds_bytes);
             // warm-up / tail steps: the deepest level's window reaches (uh + 8) * 2^D samples back and W - uh forward of a frame centre,
             // its samples depend on 23 * (2^D - 1) inputs either side, and level D runs lag_D samples behind the audio
@@ -1190,7 +1205,7 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
             const int lag_d = D == 0 ? -127 : (D == 1 ? 17 : 65);
             a.h_pre = (((ld.uh + 8) << D) + 23 * ((1 << D) - 1) + 32 + fz::kStep - 1) / fz::kStep;
             a.h_post = 1 + std::max(0, (((32 * ld.n_blk - ld.uh - 1 + lag_d) << D) + fz::kStep - 1) / fz::kStep);
-            if (emit) { a.h_pre = std::max(a.h_pre, 4); a.h_post = std::max(a.h_post, 9); }
+            if (deep) { a.h_pre = std::max(a.h_pre, 4); a.h_post = std::max(a.h_post, 9); }
             const long long total = m_end - a.M_begin;
             const int min_seg = 1024;
             int n_seg = std::max(1, (p->n_cu + n_groups - 1) / n_groups);
@@ -1199,9 +1214,9 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
             a.n_seg = static_cast<int>((total + a.seg_len - 1) / a.seg_len);
             const int n_wg = n_groups * a.n_seg;
             dim3 grid((n_wg + 7) / 8 * 8);
-            ake::ProfScope ps(pass == 0 ? "cqt_fused_kernel" : "cqt_fused_kernel/deep", stream);
+            ake::ProfScope ps("cqt_fused_kernel", stream);
             static const bool stamp_env = std::getenv("AKE_CQT_FZ_STAMP") != nullptr;
-            if (emit && stamp_env) {
+            if (deep && stamp_env) {
                 // diagnostic build: in-kernel cycle stamps of the step loop's sections (workgroup 0), printed to stderr; never timed
                 unsigned long long* sb = nullptr;
                 if (hipMalloc(&sb, 64 * sizeof(unsigned long long)) == hipSuccess) {
@@ -1217,11 +1232,33 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
                                 hb[wv * 8 + 0] / double(hb[wv * 8 + 5]), hb[wv * 8 + 1] / double(hb[wv * 8 + 5]), hb[wv * 8 + 2] / double(hb[wv * 8 + 5]),
                                 hb[wv * 8 + 3] / double(hb[wv * 8 + 5]), hb[wv * 8 + 4] / double(hb[wv * 8 + 5]));
                 }
-            } else if (emit) hipLaunchKernelGGL((fz::cqt_fused_kernel<4, true>), grid, dim3(fz::kNT), lds_bytes, stream, a);
+            } else if (deep) hipLaunchKernelGGL((fz::cqt_fused_kernel<4, true>), grid, dim3(fz::kNT), lds_bytes, stream, a);
             else if (NL == 4) hipLaunchKernelGGL((fz::cqt_fused_kernel<4, false>), grid, dim3(fz::kNT), lds_bytes, stream, a);
             else if (NL == 3) hipLaunchKernelGGL((fz::cqt_fused_kernel<3, false>), grid, dim3(fz::kNT), lds_bytes, stream, a);
             else if (NL == 2) hipLaunchKernelGGL((fz::cqt_fused_kernel<2, false>), grid, dim3(fz::kNT), lds_bytes, stream, a);
             else hipLaunchKernelGGL((fz::cqt_fused_kernel<1, false>), grid, dim3(fz::kNT), lds_bytes, stream, a);
+        }
+        if (deep) {
+            // Octaves 4.. : engine 3's streaming cascade on level 4 (as its "audio": index i <-> level-4 sample i - kNextPad, so its level l
+            // holds true level 4 + l shifted by kNextPad >> l samples -- an integer for l <= 3) and engine 3's bank on the split planes.
+            const int S = p->n_oct - fz::kMaxLv - 1;                      // half-band stages 4 -> 5 -> ...
+            CascArgs ca;
+            fill_cascade_on(ca, S, next, n_next, n_next, nullptr);
+            ca.ppad = p->ppad;
+            BankCall2 call2;
+            std::memset(&call2, 0, sizeof(call2));
+            call2.pad = p->ppad;
+            for (int l = 0; l <= S; ++l) {
+                ca.ph[l] = planes[l]; ca.p_stride[l] = plane_n[l]; ca.p_count[l] = plane_n[l];
+                ca.need[l] = -1;                                           // every sample: the tap windows of these octaves overlap
+                call2.xw[fz::kMaxLv + l] = planes[l] + (kNextPad >> l);
+                call2.stride[fz::kMaxLv + l] = plane_n[l];
+            }
+            launch_cascade(ca);
+            dim3 grid(static_cast<unsigned>((T + 7) / 8 * 8), p->n_oct - fz::kMaxLv, (batch + 255) / 256);
+            ake::ProfScope ps("cqt_bank_bf16_kernel", stream);
+            hipLaunchKernelGGL(cqt_bank_bf16_kernel, grid, dim3(1024), p->bank2_lds, stream, call2, p->octs2_dev, p->table2_dev, batch,
+                               p->cfg.hop_length, p->hop_twos, scratch, static_cast<long long>(T) * p->cfg.n_bins, p->cfg.n_bins, static_cast<int>(T), fz::kMaxLv);
         }
     } else if (p->engine == 3) {
         BankCall2 call2;
@@ -1245,7 +1282,7 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
         dim3 grid(static_cast<unsigned>((T + 7) / 8 * 8), p->n_oct, (batch + 255) / 256);
         ake::ProfScope ps("cqt_bank_bf16_kernel", stream);
         hipLaunchKernelGGL(cqt_bank_bf16_kernel, grid, dim3(1024), p->bank2_lds, stream, call2, p->octs2_dev, p->table2_dev, batch,
-                           p->cfg.hop_length, p->hop_twos, scratch, static_cast<long long>(T) * p->cfg.n_bins, p->cfg.n_bins, static_cast<int>(T));
+                           p->cfg.hop_length, p->hop_twos, scratch, static_cast<long long>(T) * p->cfg.n_bins, p->cfg.n_bins, static_cast<int>(T), 0);
     } else {
         BankCall call;
         std::memset(&call, 0, sizeof(call));

@@ -14,8 +14,8 @@ from ake_amd.cqt import CQTPlan  # noqa: E402
 
 DEV = "cuda:0"
 CASES = (("full_b3", 3, 330750, 22050, 4410, 288, 36), ("short_b17", 17, 30000, 22050, 4410, 288, 36), ("tiny", 2, 5000, 22050, 4410, 288, 36),
-         ("hop512", 3, 40000, 22050, 512, 84, 12), ("oct7", 2, 60000, 11025, 2205, 252, 36), ("oct4", 2, 20000, 1378, 275, 144, 36),
-         ("oct5", 2, 30000, 2756, 551, 180, 36), ("oct1", 2, 3000, 172, 34, 36, 36), ("b40_odd", 40, 44100 + 13, 22050, 4411, 288, 36))
+         ("hop2205", 3, 40000, 22050, 2205, 288, 36), ("oct7", 2, 60000, 11025, 2205, 252, 36), ("oct4", 2, 20000, 1378, 2205, 144, 36),
+         ("oct6", 2, 30000, 5512, 2300, 216, 36), ("oct1", 2, 3000, 172, 300, 36, 36), ("b40_odd", 40, 44100 + 13, 22050, 4411, 288, 36))
 
 
 def main():
@@ -55,7 +55,7 @@ def main():
     if "--time" in sys.argv:
         from ake_amd import synthetic
         audio, _ = synthetic.make_batch_device(range(256), torch.device(DEV))
-        runs = [(3, "0"), (4, "0")] + ([(4, d) for d in ("7", "263", "519")] if "--dbg" in sys.argv else [])
+        runs = [(3, "0"), (4, "0")] + ([(4, d) for d in ("1", "3", "7")] if "--dbg" in sys.argv else [])
         for eng, dbg in runs:
             os.environ["AKE_CQT_FZ_DBG"] = dbg
             p = CQTPlan(22050, 4410, 288, 36, engine=eng)
