@@ -59,7 +59,10 @@ typedef struct ake_cqt_config {
     double decim_beta;    /* Kaiser beta of the decimator; <=0 selects 8.0 */
     int engine;           /* 0: fastest available; 1: one kernel per decimation stage + f32 filter bank (first version, kept as
                              the in-library cross-check); 2: fused decimator cascade + f32 bank (bit-identical to 1);
-                             3: fused cascade writing split-bf16 level signals + bf16x3 MFMA bank (needs <= 8 octaves) */
+                             3: fused cascade writing split-bf16 level signals + bf16x3 MFMA bank (needs <= 8 octaves);
+                             4 (opt-in): cascade AND bank of the top four octaves in one streaming MFMA kernel, level signals in
+                             LDS only, deeper octaves through engine 3's kernels (needs hop >= ~1700 at 8 octaves; measured
+                             slower than 3 at 256 clips, so 0 never selects it) */
 } ake_cqt_config;
 
 /* hop = round(sample_rate / frames_per_second) (KeyDataset.py:485), n_bins = 36 * octaves. */
