@@ -553,7 +553,7 @@ bool run_p2p_bf16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sh
     if (attr_set.need()) {
         const void* fns[] = {reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<1, 0>), reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<1, 5>),
                              reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<1, 8>), reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<0, 0>),
-                             reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<2, 0>)};
+                             reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<2, 0>), reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<1, 0, true>)};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
         attr_set.mark();
@@ -564,7 +564,24 @@ bool run_p2p_bf16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sh
     else if (dst_nchw) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<0, 0>), grid, block, lds, s, a);
     else if (nchw && a.c0 + a.c1 <= 5) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<1, 5>), grid, block, lds, s, a);
     else if (nchw) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<1, 8>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<1, 0>), grid, block, lds, s, a);
+    else {
+        static const bool stamp_env = std::getenv("AKE_P2P_STAMP") != nullptr;
+        unsigned long long* sb = nullptr;
+        if (stamp_env && hipMalloc(&sb, 64 * sizeof(unsigned long long)) == hipSuccess) {
+            // diagnostic build: in-kernel cycle stamps of the tile loop's sections (workgroup 0), printed to stderr; never timed
+            (void)hipMemsetAsync(sb, 0, 64 * sizeof(unsigned long long), s);
+            a.stamps = sb;
+            hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<1, 0, true>), grid, block, lds, s, a);
+            unsigned long long hb[64];
+            (void)hipMemcpyAsync(hb, sb, sizeof(hb), hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(sb);
+            for (int wv = 0; wv < 8; ++wv)
+                fprintf(stderr, "p2p stamps wave %d: tiles %llu  cycles/tile: vmcnt-wait %.0f barrier %.0f late-epilogue %.0f multiply(+dma+stores) %.0f epilogue %.0f\n", wv,
+                        hb[wv * 8 + 5], hb[wv * 8 + 0] / double(hb[wv * 8 + 5]), hb[wv * 8 + 1] / double(hb[wv * 8 + 5]), hb[wv * 8 + 2] / double(hb[wv * 8 + 5]),
+                        hb[wv * 8 + 3] / double(hb[wv * 8 + 5]), hb[wv * 8 + 4] / double(hb[wv * 8 + 5]));
+        } else hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<1, 0>), grid, block, lds, s, a);
+    }
     return true;
 }
 

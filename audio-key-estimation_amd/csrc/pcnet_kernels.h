@@ -792,7 +792,14 @@ struct P2pPsArgs {
     const uint4* sfrag;           // OUT == 2: B fragments of the semitone conv [3 dy][hi|lo][64 lanes] x 8 bf16, and its bias [8]
     const float* sbias;
     int H, T, R, J, Tp, n_row_tiles, n_tiles, plane_pos;   // plane_pos: (R + 6) * Tp rounded up to 64 positions
+    unsigned long long* stamps;   // diagnostic build (AKE_P2P_STAMP): [8 waves][8] cycle sums of the tile loop's sections, workgroup 0
 };
+
+__device__ __forceinline__ unsigned long long p2p_stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
 
 constexpr int kP2pPsStage = 80;      // uint4 per M-tile of a wave's staging slab (NCHW form: 8 channels x 36 floats, padded)
 
@@ -802,7 +809,8 @@ constexpr int kP2pPsStage = 80;      // uint4 per M-tile of a wave's staging sla
 //   (m = (semitone row, frame pair), n = (tau, co), k-step = one of its 3 rows: 4 positions x 8 channels, the 4th tap zero), one
 //   M-tile per wave, and only the semitone maps [clip][8][H / 3][T] go to memory: the 8 x H x T pitch tensor is never written.
 // NIN: 0 = channels-last split planes in; else the number of f32 channels the loader assembles (5: default net, 8: any)
-template <int OUT, int NIN>
+// STAMP: diagnostic build with s_memtime stamps around the tile loop's sections (tools/p2p_stamp.py; shares, never timed)
+template <int OUT, int NIN, bool STAMP = false>
 __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
     constexpr bool OUT_CL = OUT == 1, OUT_SEMI = OUT == 2;
     constexpr bool IN_NCHW = NIN > 0;
@@ -1038,11 +1046,15 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
     int cur = 0;
+    unsigned long long sm[6] = {0, 0, 0, 0, 0, 0}, ts[6];
     for (int tile = first; tile < a.n_tiles; tile += nwg, cur ^= 1) {
+        if (STAMP) ts[0] = p2p_stamp();
         // this wave's share of the tile's patch has landed (and its stores have left).  The builtin, not asm: hipcc then knows that
         // nothing of its own is pending at the loop top and places no vmcnt wait inside the loop that would also drain the LDS-DMA
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        if (STAMP) ts[1] = p2p_stamp();
         __syncthreads();              // ... every wave's; and every wave is done with the other half
+        if (STAMP) ts[2] = p2p_stamp();
         const bool more = tile + nwg < a.n_tiles;
         if (has_prev) {
             if (OUT_SEMI) semi_stage(cur ^ 1, prev_base, prev_mblk);
@@ -1050,6 +1062,7 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
         }
         const uint4* const pH = lds4 + (cur * 2) * a.plane_pos;
         const uint4* const pL = pH + a.plane_pos;
+        if (STAMP) ts[3] = p2p_stamp();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1078,6 +1091,7 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt], 0, 0, 0);
         }
+        if (STAMP) ts[4] = p2p_stamp();
         if (!late) epilogue(acc, cur);
         if (IN_NCHW && more) write_lds(cur ^ 1);
         {
@@ -1090,6 +1104,16 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
                                  : clip * a.dst_clip_stride + static_cast<long long>(y0) * T;
         }
         has_prev = true;
+        if (STAMP) {
+            ts[5] = p2p_stamp();
+#pragma unroll
+            for (int i = 0; i < 5; ++i) sm[i] += ts[i + 1] - ts[i];
+            sm[5] += 1;
+        }
+    }
+    if (STAMP && blockIdx.x == 0 && lane == 0 && a.stamps) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.stamps[wave * 8 + i] = sm[i];
     }
     if (has_prev) {
         if (OUT_SEMI) {
