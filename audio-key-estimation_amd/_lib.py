@@ -70,6 +70,10 @@ SYMBOLS = {
     "ake_pipeline_workspace_bytes": (_SZ, [_P, _P, _I, _I64]),
     "ake_pipeline_forward_f32": (_I, [_P, _P, _P, _I, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
     "ake_pipeline_forward_ragged_f32": (_I, [_P, _P, _P, _I, _I64, _I64, _P, _P, _P, _P, _P, _SZ, _P]),
+    "ake_resampler_create": (_I, [_I, _I, C.POINTER(_P)]),
+    "ake_resampler_destroy": (None, [_P]),
+    "ake_resampler_out_len": (_I64, [_P, _I64]),
+    "ake_resample_f32": (_I, [_P, _P, _I, _I, _I64, _I64, _I64, _I, _P, _P, _I64, _P, _P]),
     "ake_prof_enable": (_I, [C.c_char_p, _I]),
     "ake_prof_collect": (_I, []),
     "ake_prof_reset": (_I, []),

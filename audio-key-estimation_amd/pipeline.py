@@ -10,6 +10,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
+from .audio import get_resampler
 from .cqt import CQTPlan, hop_for
 from .models import PitchClassNet
 
@@ -18,11 +19,20 @@ class KeyEstimator:
     """``streams`` > 1: consecutive calls are issued round-robin on that many side streams, each with a workspace of its own, so
     that independent batches overlap on the GPU -- the CQT stage is VALU / HBM-bound, the network MFMA-bound, and one batch's CQT
     runs under another's convolutions (measured: +8..12 % clips/s at 2 streams).  The weights and CQT tables are shared (read-only
-    during a forward).  Outputs of such calls belong to their side stream: call ``join()`` before the caller's stream reads them."""
+    during a forward).  Outputs of such calls belong to their side stream: call ``join()`` before the caller's stream reads them.
 
-    def __init__(self, net: PitchClassNet, sample_rate: int = 22050, frames: int = 5, streams: int = 1):
+    ``wrap_mode``: the pitch convolutions are circular in TIME as well (models.py:221,230), and a batch is zero-padded to its
+    longest clip (the reference pads to the longest clip of the whole dataset, KeyDataset.py:243-245), so a shorter clip's last
+    frames wrap into padding and its outputs depend on what it was batched with.  ``"dataset_max"`` (default) is that
+    behaviour, bit for bit.  ``"true_end"`` (opt-in) wraps every clip at its OWN last frame: clips are
+    grouped by frame count and each group runs unpadded, so a clip's outputs are those of the clip alone."""
+
+    def __init__(self, net: PitchClassNet, sample_rate: int = 22050, frames: int = 5, streams: int = 1, wrap_mode: str = "dataset_max"):
+        if wrap_mode not in ("dataset_max", "true_end"):
+            raise ValueError("wrap_mode must be 'dataset_max' or 'true_end'")
         self.net = net.eval()
         self.device = net._device()
+        self.sample_rate, self.wrap_mode = int(sample_rate), wrap_mode
         self.plan = CQTPlan(sample_rate, hop_for(sample_rate, frames), net.pitches, 36, device=self.device)
         self.streams = max(1, int(streams))
         self._slots = [{"ws": None, "stream": None} for _ in range(self.streams)]
@@ -38,15 +48,22 @@ class KeyEstimator:
                 cur.wait_stream(slot["stream"])
 
     @torch.no_grad()
-    def __call__(self, audio: torch.Tensor, lengths: torch.Tensor | None = None):
-        """audio (B, n) float32 on the GPU -> tuple of (B,12), (B,12)[, (B,11)] float32 tensors.
+    def __call__(self, audio: torch.Tensor, lengths: torch.Tensor | None = None, rate: int | None = None, channel: int = 0):
+        """audio (B, n) or (B, C, n) float32 on the GPU -> tuple of (B,12), (B,12)[, (B,11)] float32 tensors.
 
         ``lengths`` (B,) int64: ragged batch, row i holds ``lengths[i] <= n`` samples; every clip is pooled over its own frames
-        (``seq_length`` = ``1 + lengths[i] // hop``), as a ``KeyDataset`` batch of unequal clips is (KeyDataset.py:245-256)."""
+        (``seq_length`` = ``1 + lengths[i] // hop``), as a ``KeyDataset`` batch of unequal clips is (KeyDataset.py:245-256).
+        ``rate``: sample rate of ``audio`` when it is not the estimator's -- it is resampled on the device first
+        (``scipy.signal.resample_poly``'s filter); ``channel``: which channel of (B, C, n) audio to take (0 = the reference's
+        ``waveform[0]``, KeyDataset.py:480) or -1 for the mean of all."""
         self.net._sync_weights(self.device)
+        if audio.dim() == 3 or (rate is not None and int(rate) != self.sample_rate):
+            rs = get_resampler(self.sample_rate if rate is None else int(rate), self.sample_rate, self.device)
+            audio, len_out = rs(audio, channel=channel, lengths=lengths)
+            lengths = len_out if lengths is not None else None
         slot = self._slots[self._turn]
         if self.streams == 1:
-            return self._run(slot, audio, lengths)
+            return self._run_wrapped(slot, audio, lengths)
         self._turn = (self._turn + 1) % self.streams
         with torch.cuda.device(self.device):
             if slot["stream"] is None:
@@ -54,7 +71,7 @@ class KeyEstimator:
             slot["stream"].wait_stream(torch.cuda.current_stream(self.device))      # the inputs were produced on the caller's stream
             cur = torch.cuda.current_stream(self.device)
             with torch.cuda.stream(slot["stream"]):
-                out = self._run(slot, audio, lengths)
+                out = self._run_wrapped(slot, audio, lengths)
             # the outputs were allocated on the side stream and will be read on the caller's: tell the allocator now (nothing to
             # remember until join(), nothing to drop when a caller never joins)
             for t in out:
@@ -62,6 +79,27 @@ class KeyEstimator:
                     t.record_stream(cur)
             audio.record_stream(slot["stream"])
         return out
+
+    def _run_wrapped(self, slot, audio, lengths):
+        """wrap_mode "true_end": one unpadded call per distinct frame count (the clips of a group share T, so no frame is padding)."""
+        if self.wrap_mode != "true_end" or lengths is None:
+            return self._run(slot, audio, lengths)
+        lengths = torch.as_tensor(lengths).to(device=self.device, dtype=torch.int64)
+        lens = lengths.cpu()                                      # (opt-in mode: grouping needs the lengths on the host)
+        frames = 1 + lens // self.plan.hop_length
+        B = audio.shape[0]
+        outs = [torch.empty((B, w), dtype=torch.float32, device=self.device) for w in ((12, 12, 11) if self.net.genre else (12, 12))]
+        for t in torch.unique(frames).tolist():
+            idx = torch.nonzero(frames == t).flatten()
+            n_g = int(lens[idx].max())
+            # a group's clips have the same frame count but not the same sample count: lengths stay (the CQT zero-pads the tails)
+            sub = audio.index_select(0, idx.to(self.device))[:, :max(n_g, 1)].contiguous()
+            if self.plan.num_frames(sub.shape[1]) != t:            # n_g rounds into the next hop only if a clip does: cannot happen
+                raise _lib.AkeError("true_end grouping: frame count mismatch")
+            got = self._run(slot, sub, lengths[idx.to(self.device)])
+            for o, g in zip(outs, got):
+                o.index_copy_(0, idx.to(self.device), g)
+        return tuple(outs)
 
     def _run(self, slot, audio, lengths):
         net, L = self.net, _lib.lib()

@@ -220,6 +220,23 @@ int ake_pcnet_tap_copy(const ake_pcnet* net, const char* name, int batch, int fr
                        float* out_dev, ake_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Audio preparation in front of the CQT (not in the reference, which takes channel 0 at the file's own
+ * rate: KeyDataset.py:479-485 -- channel = 0 and rate_in == rate_out reproduce exactly that): channel selection or mono
+ * mix-down and polyphase resampling = scipy.signal.resample_poly(x, up, down) with its default Kaiser(5.0) filter, on the
+ * device, for ragged batches.
+ * in_dev[clip * clip_stride + c * channel_stride + i]; channel >= 0 selects one channel, -1 takes the mean of all;
+ * n_in_clip_dev (or null): samples of each clip (<= n_in); out_dev[clip * out_stride + k], k < ake_resampler_out_len(n_in),
+ * zero behind a shorter clip; n_out_clip_dev (or null) receives every clip's output length ceil(n * up / down).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ake_resampler ake_resampler;
+int ake_resampler_create(int rate_in, int rate_out, ake_resampler** out);
+void ake_resampler_destroy(ake_resampler* r);
+int64_t ake_resampler_out_len(const ake_resampler* r, int64_t n_in);
+int ake_resample_f32(const ake_resampler* r, const float* in_dev, int batch, int channels, int64_t n_in, int64_t clip_stride,
+                     int64_t channel_stride, int channel, const int64_t* n_in_clip_dev, float* out_dev, int64_t out_stride,
+                     int64_t* n_out_clip_dev, ake_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Whole hot path for a batch of equal-length clips: CQT then forward
  * (DatasetLoader.get_all -> __getitem__ -> general_step's forward; KeyDataset.py:469-509,
  * 242-256, models.py:846).  seq_length of every clip = num_frames(n_samples).

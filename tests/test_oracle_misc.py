@@ -79,3 +79,20 @@ def test_shift_helpers():
     assert (up[:6] == 0).all() and np.array_equal(up[6:], m[:-6])
     dn = mirex_oracle.mel_shifting_down(m, 12)
     assert (dn[-36:] == 0).all() and np.array_equal(dn[:-36], m[36:])
+
+
+def test_resample_restatement_equals_scipy():
+    """oracle/resample_oracle.py (the polyphase sum as csrc/audio.hip evaluates it) is pinned on scipy.signal.resample_poly itself."""
+    import scipy.signal as ss
+    from oracle import resample_oracle as R
+    rng = np.random.default_rng(0)
+    for rate_in, rate_out, n in ((44100, 22050, 1001), (48000, 22050, 777), (24000, 22050, 500), (11025, 22050, 300), (16000, 22050, 640),
+                                 (22050, 22050, 100)):
+        x = rng.normal(size=n)
+        g = np.gcd(rate_in, rate_out)
+        want = ss.resample_poly(x, rate_out // g, rate_in // g)
+        got = R.resample_poly(x, rate_in, rate_out)
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-13, (rate_in, rate_out)
+    st = rng.normal(size=(2, 400))
+    assert np.allclose(R.prepare(st, 44100, 22050, channel=-1), ss.resample_poly(st.mean(0), 1, 2), atol=1e-13)
+    assert np.allclose(R.prepare(st, 44100, 22050, channel=1), ss.resample_poly(st[1], 1, 2), atol=1e-13)
