@@ -726,7 +726,7 @@ struct Buffers {           // workspace carve
     std::vector<float*> hst[3], aff_hst[3];                            // [head][hidden conv]
     // backward
     double* stats2 = nullptr;          // [bn_channels][3]  (sum g1, sum g1*zhat, sum (z - mean))
-    float* gslots = nullptr;           // [kGradSlots][grad_floats] partial weight gradients (backward)
+    gfx_t* gslots = nullptr;           // [kGradSlots][grad_floats] partial weight gradients (backward), 64-bit fixed point
     unsigned short* feat_cl = nullptr; // [2 planes][B][12][Tf][16]
     float* coef = nullptr;             // [bn_channels][4]  (c0, c1, c2, mean)
     float* g_map[3] = {nullptr, nullptr, nullptr};
@@ -784,7 +784,7 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
     if (train) {
         b->stats = cv.take<double>(static_cast<size_t>(n->bn_channels) * 2 * kStatSlots);
         b->stats2 = cv.take<double>(static_cast<size_t>(n->bn_channels) * 3);
-        b->gslots = cv.take<float>(static_cast<size_t>(kGradSlots) * n->grad_floats);
+        b->gslots = cv.take<gfx_t>(static_cast<size_t>(kGradSlots) * n->grad_floats);
         b->bstats = cv.take<float>(static_cast<size_t>(n->bn_channels) * 3);
         b->coef = cv.take<float>(static_cast<size_t>(n->bn_channels) * 4);
         for (auto* v : {&b->semi_raw, &b->aff_semi, &b->aff_cat, &b->aff_p2pin, &b->g_pc, &b->g_cat, &b->g_semi, &b->g_p, &b->g_pin, &b->g_psix})
@@ -2225,7 +2225,7 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     if (rc) return rc;
     AKE_REQUIRE(workspace && ws_bytes >= b.bytes, AKE_ERR_WORKSPACE, "pcnet backward: workspace %zu < %zu bytes", ws_bytes, b.bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    AKE_HIP_CHECK(hipMemsetAsync(b.gslots, 0, sizeof(float) * n->grad_floats * kGradSlots, s));
+    AKE_HIP_CHECK(hipMemsetAsync(b.gslots, 0, sizeof(gfx_t) * n->grad_floats * kGradSlots, s));
     AKE_HIP_CHECK(hipMemsetAsync(b.stats2, 0, sizeof(double) * 3 * n->bn_channels, s));
     Bwd bw{n, b, s, b.gslots, batch};
     rc = bw.run(mel, seq_length, d_key, d_tonic, d_genre, key_out);

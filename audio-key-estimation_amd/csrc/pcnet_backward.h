@@ -12,10 +12,10 @@ struct Bwd {
     const ake_pcnet* n;
     Buffers& b;
     hipStream_t s;
-    float* grads;        // slot 0 of the workspace's gradient slots ([kGradSlots][grad_floats]); run() is followed by grad_reduce_kernel
+    gfx_t* grads;        // slot 0 of the workspace's gradient slots ([kGradSlots][grad_floats], fixed point); run() is followed by grad_reduce_kernel
     int B;
 
-    float* grad_of(const std::string& key) const { return grads + n->grad_off[n->spec_index.at(key)]; }
+    gfx_t* grad_of(const std::string& key) const { return grads + n->grad_off[n->spec_index.at(key)]; }
     const float* raw_of(const std::string& key) const { return n->blob_dev + n->raw_w_off[n->spec_index.at(key)]; }
     int bn_of(const std::string& name) const { return n->bn_index.at(name); }
 
@@ -45,7 +45,7 @@ struct Bwd {
 
     // weight gradient of one convolution: dW += corr(act(input), dz)
     int wgrad(const PackedConv& pc, int kind, Src src, const float* in_aff, int H, int T_in, bool same_time, const float* dz, int dz_ctot,
-              int dz_coff, float* dW, const char* name) {
+              int dz_coff, gfx_t* dW, const char* name) {
         static const bool wg_f32 = std::getenv("AKE_WGRAD_F32") != nullptr;
         if (!wg_f32 && kind == 0 && pc.kh == 7 && pc.kw == 7 && pc.cout == 8 && pc.cin <= 8 && T_in <= kWgMaxT && dz_ctot == 8 && dz_coff == 0) {
             WgradBfArgs w;
@@ -130,7 +130,7 @@ struct Bwd {
                         nullptr, nullptr, &g, accumulate);
     }
 
-    void bias_grad(const float* dz, int ctot, int coff, int C, int HT, float* db) {
+    void bias_grad(const float* dz, int ctot, int coff, int C, int HT, gfx_t* db) {
         ake::ProfScope ps("channel_sum_kernel", s);
         hipLaunchKernelGGL(channel_sum_kernel, dim3(C, B), dim3(256), 0, s, dz, db, static_cast<long long>(n->grad_floats), ctot, coff, HT);
     }

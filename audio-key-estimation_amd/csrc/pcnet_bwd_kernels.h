@@ -14,22 +14,26 @@
 
 namespace ake_k {
 
-// Weight gradients are reductions over (clip, position) finished with float atomics.  Thousands of workgroups adding into the
+// Weight gradients are reductions over (clip, position) finished with atomics.  Thousands of workgroups adding into the
 // same few cache lines serialise in L2 (measured: 1.6 ms for 2.4 M atomics on 18 lines), so every writer adds into one of
 // kGradSlots copies of the flat gradient buffer and grad_reduce_kernel sums the copies into the caller's buffer.
+// The copies hold 64-bit fixed point (kFxGrad, pcnet_kernels.h): the sums are independent of the arrival order, a training
+// step is bit-identical from run to run, and a data-parallel step equals its single-process emulation exactly.
 constexpr int kGradSlots = 16;
 
-__device__ __forceinline__ float* grad_slot(float* base, long long slot_stride) {
+__device__ __forceinline__ gfx_t* grad_slot(gfx_t* base, long long slot_stride) {
     return base + static_cast<long long>((blockIdx.x + 3 * blockIdx.y + 5 * blockIdx.z) & (kGradSlots - 1)) * slot_stride;
 }
+__device__ __forceinline__ void grad_add(gfx_t* cell, float v) { fx_add(cell, v, kFxGrad); }
 
-// out[i] (+)= sum over slots
-__global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restrict__ slots, float* __restrict__ out, long long n, int accumulate) {
+// out[i] (+)= sum over slots (exact integer sum, one rounding to float)
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const gfx_t* __restrict__ slots, float* __restrict__ out, long long n, int accumulate) {
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float s = 0.f;
+    long long si = 0;
 #pragma unroll
-    for (int k = 0; k < kGradSlots; ++k) s += slots[k * n + i];
+    for (int k = 0; k < kGradSlots; ++k) si += slots[k * n + i];
+    const float s = static_cast<float>(fx_checked(si, kFxGrad));
     out[i] = accumulate ? out[i] + s : s;
 }
 
@@ -111,21 +115,21 @@ __global__ __launch_bounds__(256) void act_bwd_stats_kernel(float* __restrict__ 
     if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; r3[threadIdx.x >> 6] = s3; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(stats2 + 3 * c, static_cast<double>(r1[0]) + r1[1] + r1[2] + r1[3]);
-        atomicAdd(stats2 + 3 * c + 1, static_cast<double>(r2[0]) + r2[1] + r2[2] + r2[3]);
-        atomicAdd(stats2 + 3 * c + 2, static_cast<double>(r3[0]) + r3[1] + r3[2] + r3[3]);
+        fx_add(stats2 + 3 * c, static_cast<double>(r1[0]) + r1[1] + r1[2] + r1[3], kFxGrad);
+        fx_add(stats2 + 3 * c + 1, static_cast<double>(r2[0]) + r2[1] + r2[2] + r2[3], kFxGrad);
+        fx_add(stats2 + 3 * c + 2, static_cast<double>(r3[0]) + r3[1] + r3[2] + r3[3], kFxStat);      // sum (z - mean): activation-sized
     }
 }
 
 // per channel: dz = c0 * g1 + c1 * (z - mean) + c2;  dgamma = S2, dbeta = S1.  coef[c] = (c0, c1, c2, mean)
 // c2 is solved in double from the ROUNDED c0, c1 so that sum(dz) vanishes for the values the apply kernel really uses.
 __global__ void bn_bwd_coef_kernel(const double* __restrict__ stats2, const float* __restrict__ bstats, const float* __restrict__ gamma,
-                                   float* __restrict__ coef, float* __restrict__ d_gamma, float* __restrict__ d_beta, int C) {
+                                   float* __restrict__ coef, gfx_t* __restrict__ d_gamma, gfx_t* __restrict__ d_beta, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const double N = bstats[3 * c + 2];
     const double rstd = 1.0 / sqrt(static_cast<double>(bstats[3 * c + 1]) + 1e-5);
-    const double S1 = stats2[3 * c], S2 = stats2[3 * c + 1], S3 = stats2[3 * c + 2];
+    const double S1 = fx_get(stats2 + 3 * c, kFxGrad), S2 = fx_get(stats2 + 3 * c + 1, kFxGrad), S3 = fx_get(stats2 + 3 * c + 2, kFxStat);
     const double k1 = gamma[c] * rstd;
     const float c0 = static_cast<float>(k1);
     const float c1 = static_cast<float>(-k1 * S2 / N * rstd);
@@ -133,8 +137,8 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ stats2, const floa
     coef[4 * c + 1] = c1;
     coef[4 * c + 2] = static_cast<float>(-(static_cast<double>(c0) * S1 + static_cast<double>(c1) * S3) / N);
     coef[4 * c + 3] = bstats[3 * c];
-    d_gamma[c] += static_cast<float>(S2);        // += : the flat gradient buffer may be accumulating (accumulate_grad_batches)
-    d_beta[c] += static_cast<float>(S1);
+    grad_add(d_gamma + c, static_cast<float>(S2));        // slot 0 of the gradient slots (the caller's buffer may be accumulating)
+    grad_add(d_beta + c, static_cast<float>(S1));
 }
 
 // dz = c0*g1 + c1*(z - mean) + c2 in place on g; same layout / grid as act_bwd_stats_kernel
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
 }
 
 // sum over (clip, positions) of one channel slice -> bias gradient of a convolution without BatchNorm
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, long long slot_stride, int ctot, int coff,
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, gfx_t* __restrict__ out, long long slot_stride, int ctot, int coff,
                                                           int HT) {
     const int c = blockIdx.x, clip = blockIdx.y;
     const long long base = (static_cast<long long>(clip) * ctot + coff + c) * HT;
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(grad_slot(out, slot_stride) + c, r[0] + r[1] + r[2] + r[3]);
+    if (threadIdx.x == 0) grad_add(grad_slot(out, slot_stride) + c, r[0] + r[1] + r[2] + r[3]);
 }
 
 // ---- pooling / fold / repeat routing -------------------------------------------------------------------------------
@@ -260,7 +264,7 @@ __global__ void semi_bwd_data_kernel(const float* __restrict__ dz, const float* 
 constexpr int kSemiRows = 48;
 
 __global__ __launch_bounds__(256) void semi_bwd_weight_kernel(const float* __restrict__ dz, const float* __restrict__ x,
-                                                              const float* __restrict__ x_aff, float* __restrict__ dW, long long slot_stride, int C,
+                                                              const float* __restrict__ x_aff, gfx_t* __restrict__ dW, long long slot_stride, int C,
                                                               int H, int T) {
     extern __shared__ float semi_lds[];
     const int clip = blockIdx.y;
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(256) void semi_bwd_weight_kernel(const float* __res
     if (wave == 0 && lane < pairs) {
 #pragma unroll
         for (int k = 0; k < 9; ++k)
-            atomicAdd(grad_slot(dW, slot_stride) + (co * C + ci) * 9 + k, (red[k * 64 + lane] + red[(9 + k) * 64 + lane]) + (red[(18 + k) * 64 + lane] + red[(27 + k) * 64 + lane]));
+            grad_add(grad_slot(dW, slot_stride) + (co * C + ci) * 9 + k, (red[k * 64 + lane] + red[(9 + k) * 64 + lane]) + (red[(18 + k) * 64 + lane] + red[(27 + k) * 64 + lane]));
     }
 }
 
@@ -338,7 +342,7 @@ __global__ void up_sixth_bwd_data_kernel(const float* __restrict__ dz, const flo
 
 // weight: dW[ci][co][j] += sum_{p,t} dz[co][3p+j][t] * act(x[ci][p][t])     grid (C*C*3, B)
 __global__ __launch_bounds__(64) void up_sixth_bwd_weight_kernel(const float* __restrict__ dz, const float* __restrict__ x, long long x_clip_stride,
-                                                                 const float* __restrict__ x_aff, float* __restrict__ dW, long long slot_stride, int C,
+                                                                 const float* __restrict__ x_aff, gfx_t* __restrict__ dW, long long slot_stride, int C,
                                                                  int T) {
     const int widx = blockIdx.x;                 // (ci, co, j)
     const int clip = blockIdx.y;
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(64) void up_sixth_bwd_weight_kernel(const float* __
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (threadIdx.x == 0) atomicAdd(grad_slot(dW, slot_stride) + widx, acc);
+    if (threadIdx.x == 0) grad_add(grad_slot(dW, slot_stride) + widx, acc);
 }
 
 // ---- convolution weight gradient on f32 MFMA --------------------------------------------------------------------------
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(64) void up_sixth_bwd_weight_kernel(const float* __
 // atomics once per (clip group, chunk).
 struct WgradArgs {
     ConvArgs c;               // forward geometry; c.dst = dz (read), c.dst_coff / dst_clip_stride address it; c.w unused
-    float* dW;                // [cout][cin][KH][KW] (+=), slot 0
+    gfx_t* dW;                // [cout][cin][KH][KW] (+=), slot 0
     long long slot_stride;    // floats between gradient slots
     int KH, KW;
     int rt_per_block;         // row tiles per workgroup
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs wa) {
             }
         }
         // ---- flush: D[row = co 4q+reg][col = tap c16] ----
-        float* const dWs = grad_slot(wa.dW, wa.slot_stride);
+        gfx_t* const dWs = grad_slot(wa.dW, wa.slot_stride);
         if (wave < cc) {
             const int ci = c_lo + wave;
 #pragma unroll
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs wa) {
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const int co = 16 * m + 4 * q + reg;
-                        if (co < a.cout && kk < KK) atomicAdd(dWs + (static_cast<long long>(co) * cin + ci) * KK + kk, acc[m][nt][reg]);
+                        if (co < a.cout && kk < KK) grad_add(dWs + (static_cast<long long>(co) * cin + ci) * KK + kk, acc[m][nt][reg]);
                     }
                 }
         }
@@ -511,7 +515,7 @@ struct WgradBfArgs {
     long long src0_clip_stride, src1_clip_stride;
     const float* in_affine;   // [cin][3] or null
     const float* dz;          // [clip][8][H][T]
-    float* dW;                // [8][cin][7][7], slot 0
+    gfx_t* dW;                // [8][cin][7][7], slot 0
     long long slot_stride;
     int c0, c1, h1, cin, H, T, rows_per_wg;
 };
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_p2p_bf16_kernel(WgradBfArgs a)
         __syncthreads();
     }
     // flush: D[row mm = 16 * wave + 4q + i][col n = 16 * ni + r16]
-    float* const dWs = grad_slot(a.dW, a.slot_stride);
+    gfx_t* const dWs = grad_slot(a.dW, a.slot_stride);
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         const int n = 16 * ni + r16;
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_p2p_bf16_kernel(WgradBfArgs a)
         for (int i = 0; i < 4; ++i) {
             const int mm = 16 * wave + 4 * q + i;
             const int dyy = mm >> 3, coo = mm & 7;
-            if (dyy < 7 && dx < 7 && ci < a.cin) atomicAdd(dWs + ((static_cast<long long>(coo) * a.cin + ci) * 7 + dyy) * 7 + dx, acc[ni][i]);
+            if (dyy < 7 && dx < 7 && ci < a.cin) grad_add(dWs + ((static_cast<long long>(coo) * a.cin + ci) * 7 + dyy) * 7 + dx, acc[ni][i]);
         }
     }
 }

@@ -62,6 +62,26 @@ struct ConvArgs {
 // serialise in one L2 channel, so every producer adds into one of kStatSlots copies and bn_finalize_kernel sums them.
 constexpr int kStatSlots = 64;
 
+// ---- order-independent reductions -------------------------------------------------------------------------------------
+// Every cross-workgroup sum of the training path (batch statistics, BatchNorm-backward sums, weight and bias gradients) is
+// accumulated in 64-bit FIXED POINT: integer addition is associative, so the result does not depend on the order in which
+// workgroups (or the threads of one) arrive, and two runs of a step are bit-identical.  (Float or double atomics give sums
+// that differ in the last bits from run to run; through Adam's normalisation that is a +-lr difference in single weights.)
+// The cells keep their old size: a `double` cell holds a long long.
+constexpr double kFxStat = 16777216.0;            // 2^24: sums of activations and their squares (|sum| < 5.5e11, i.e. an rms of 300 over
+                                                  // 5.6 M positions; resolution 6e-8 per partial sum = < 1e-9 of a variance; overflow -> NaN, below)
+constexpr double kFxGrad = 1099511627776.0;       // 2^40: gradient-side sums (|sum| < 8.4e6, resolution 9.1e-13)
+typedef long long gfx_t;                          // a gradient slot cell
+__device__ __forceinline__ void fx_add(long long* cell, double v, double scale) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(cell), static_cast<unsigned long long>(__double2ll_rn(v * scale)));
+}
+__device__ __forceinline__ void fx_add(double* cell, double v, double scale) { fx_add(reinterpret_cast<long long*>(cell), v, scale); }
+__device__ __forceinline__ double fx_get(const double* cell, double scale) { return static_cast<double>(*reinterpret_cast<const long long*>(cell)) / scale; }
+__device__ __forceinline__ double fx_checked(long long sum, double scale) {     // a sum that came near the range cannot be trusted: fail loudly
+    const long long lim = 1ll << 61;
+    return (sum > lim || sum < -lim) ? __longlong_as_double(0x7ff8000000000000ll) : static_cast<double>(sum) / scale;
+}
+
 // float -> bf16 bits, round to nearest even (finite inputs)
 __device__ __forceinline__ unsigned int bf16_bits(float v) {
     const unsigned int u = __float_as_uint(v);
@@ -582,8 +602,8 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
             const int co = n / TB;
             if (q == 0 && n - co * TB == 0 && co < a.cout) {
                 double* st = a.stats + static_cast<size_t>((blockIdx.x + 7 * blockIdx.z + wave) & (kStatSlots - 1)) * a.stats_stride;
-                atomicAdd(st + 2 * co, static_cast<double>(s1));
-                atomicAdd(st + 2 * co + 1, static_cast<double>(s2));
+                fx_add(st + 2 * co, s1, kFxStat);
+                fx_add(st + 2 * co + 1, s2, kFxStat);
             }
         }
     }
@@ -2163,8 +2183,8 @@ __device__ __forceinline__ void stats_commit(double* stats, int stats_stride, in
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     if ((threadIdx.x & 63) == 0) {
         double* st = stats + static_cast<size_t>((blockIdx.x + 7 * blockIdx.z + (threadIdx.x >> 6)) & (kStatSlots - 1)) * stats_stride;
-        atomicAdd(st + 2 * c, static_cast<double>(s1));
-        atomicAdd(st + 2 * c + 1, static_cast<double>(s2));
+        fx_add(st + 2 * c, s1, kFxStat);
+        fx_add(st + 2 * c + 1, s2, kFxStat);
     }
 }
 
@@ -2260,8 +2280,8 @@ __global__ void fold_affine_kernel(const float* __restrict__ src, const float* _
 __global__ void up_sixth_train_kernel(const float* __restrict__ src, long long src_clip_stride, const float* __restrict__ in_aff,
                                       const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ dst,
                                       double* __restrict__ stats, int stats_stride, int C, int T, long long total) {
-    __shared__ double sh[2 * 128];
-    for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) sh[k] = 0.0;
+    __shared__ long long sh[2 * 128];                              // fixed point: the order of the threads' adds does not matter
+    for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) sh[k] = 0;
     __syncthreads();
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < total) {
@@ -2276,12 +2296,13 @@ __global__ void up_sixth_train_kernel(const float* __restrict__ src, long long s
         float acc = bias[co];
         for (int ci = 0; ci < C; ++ci) acc = fmaf(affine_act(s[static_cast<long long>(ci) * 12 * T], in_aff, ci), w[(ci * C + co) * 3 + j], acc);
         dst[i] = acc;
-        atomicAdd(&sh[2 * co], static_cast<double>(acc));
-        atomicAdd(&sh[2 * co + 1], static_cast<double>(acc) * acc);
+        fx_add(&sh[2 * co], acc, kFxStat);
+        fx_add(&sh[2 * co + 1], static_cast<double>(acc) * acc, kFxStat);
     }
     __syncthreads();
     for (int k = threadIdx.x; k < 2 * C; k += blockDim.x)
-        if (sh[k] != 0.0) atomicAdd(stats + static_cast<size_t>(blockIdx.x & (kStatSlots - 1)) * stats_stride + k, sh[k]);
+        if (sh[k] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(stats + static_cast<size_t>(blockIdx.x & (kStatSlots - 1)) * stats_stride + k),
+                                  static_cast<unsigned long long>(sh[k]));
 }
 
 // time pooling with a pending affine on the input
@@ -2308,11 +2329,12 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int stats_s
                                    const float* __restrict__ beta, float* __restrict__ aff, float* __restrict__ batch_stats, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
+    long long i1 = 0, i2 = 0;                                      // the slots hold fixed-point sums (fx_add): exact integer adds
     for (int k = 0; k < kStatSlots; ++k) {
-        s1 += stats[static_cast<size_t>(k) * stats_stride + 2 * c];
-        s2 += stats[static_cast<size_t>(k) * stats_stride + 2 * c + 1];
+        i1 += reinterpret_cast<const long long*>(stats)[static_cast<size_t>(k) * stats_stride + 2 * c];
+        i2 += reinterpret_cast<const long long*>(stats)[static_cast<size_t>(k) * stats_stride + 2 * c + 1];
     }
+    const double s1 = fx_checked(i1, kFxStat), s2 = fx_checked(i2, kFxStat);
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0) var = 0;
