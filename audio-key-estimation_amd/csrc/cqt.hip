@@ -242,6 +242,7 @@ struct CascArgs {
     int g0;                    // full-rate frontier before tick 0 (multiple of 512, <= -512)
     int ticks_total, ticks_per_seg, warm;
     DecimTaps taps;
+    unsigned long long* stamps;   // diagnostic build: [4 waves][16] cycle sums per phase of a tick
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -335,7 +336,14 @@ __device__ __forceinline__ void cascade_level(const CascArgs& a, float* lds, int
     }
 }
 
-template <int NODD, int C, int NT, bool SPLIT>
+__device__ __forceinline__ unsigned long long casc_stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+
+// STAMP: diagnostic build (AKE_CQT_CASC_STAMP): s_memtime stamps around the phases of a tick, workgroup (0, 0); never timed
+template <int NODD, int C, int NT, bool SPLIT, bool STAMP = false>
 __global__ __launch_bounds__(NT) void cqt_cascade_kernel(CascArgs a) {
     static_assert(C % 512 == 0 && C >= 1024 && (C / 4) % NT == 0, "chunk");
     using Lay = CascLayout<C>;
@@ -381,7 +389,9 @@ __global__ __launch_bounds__(NT) void cqt_cascade_kernel(CascArgs a) {
     }
     const float hopf0 = static_cast<float>(a.hop), inv_hop0 = 1.f / hopf0;
     __syncthreads();
+    unsigned long long sm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts[10];
     for (int k = k_start; k < k_end; ++k) {
+        if (STAMP) ts[0] = casc_stamp();
         const bool owned = k >= k_own;
         if (S == 1 && k > k_start) {                                  // single stage: level 0 is also the deepest level
             float4 h = {0.f, 0.f, 0.f, 0.f};
@@ -426,14 +436,31 @@ __global__ __launch_bounds__(NT) void cqt_cascade_kernel(CascArgs a) {
         }
         if (k + 1 < k_end) fetch(k + 1);                              // next chunk in flight during the whole tick
         __syncthreads();
+        if (STAMP) ts[1] = casc_stamp();
         cascade_level<NODD, C, NT, 0, SPLIT>(a, lds, tid, clip, k, owned);
         __syncthreads();
+        if (STAMP) ts[2] = casc_stamp();
         if (S > 1) { cascade_level<NODD, C, NT, 1, SPLIT>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (STAMP) ts[3] = casc_stamp();
         if (S > 2) { cascade_level<NODD, C, NT, 2, SPLIT>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (STAMP) ts[4] = casc_stamp();
         if (S > 3) { cascade_level<NODD, C, NT, 3, SPLIT>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (STAMP) ts[5] = casc_stamp();
         if (S > 4) { cascade_level<NODD, C, NT, 4, SPLIT>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (STAMP) ts[6] = casc_stamp();
         if (S > 5) { cascade_level<NODD, C, NT, 5, SPLIT>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (STAMP) ts[7] = casc_stamp();
         if (S > 6) { cascade_level<NODD, C, NT, 6, SPLIT>(a, lds, tid, clip, k, owned); __syncthreads(); }
+        if (STAMP) {
+            ts[8] = casc_stamp();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sm[i] += ts[i + 1] - ts[i];
+            sm[8] += 1;
+        }
+    }
+    if (STAMP && blockIdx.x == 1 && blockIdx.y == 0 && (tid & 63) == 0 && a.stamps) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) a.stamps[(tid >> 6) * 16 + i] = sm[i];
     }
 }
 
@@ -1152,7 +1179,25 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
         const bool split = a.ph[0] != nullptr;
         if (p->half_len == 15 && split) hipLaunchKernelGGL((cqt_cascade_kernel<8, C, NT, true>), grid, dim3(NT), 0, stream, a);
         else if (p->half_len == 15) hipLaunchKernelGGL((cqt_cascade_kernel<8, C, NT, false>), grid, dim3(NT), 0, stream, a);
-        else if (split) hipLaunchKernelGGL((cqt_cascade_kernel<12, C, NT, true>), grid, dim3(NT), 0, stream, a);
+        else if (split) {
+            static const bool stamp_env = std::getenv("AKE_CQT_CASC_STAMP") != nullptr;
+            unsigned long long* sb = nullptr;
+            if (stamp_env && a.n_stage == 7 && hipMalloc(&sb, 64 * sizeof(unsigned long long)) == hipSuccess) {
+                CascArgs a2 = a;
+                a2.stamps = sb;
+                (void)hipMemsetAsync(sb, 0, 64 * sizeof(unsigned long long), stream);
+                hipLaunchKernelGGL((cqt_cascade_kernel<12, C, NT, true, true>), grid, dim3(NT), 0, stream, a2);
+                unsigned long long hb[64];
+                (void)hipMemcpyAsync(hb, sb, sizeof(hb), hipMemcpyDeviceToHost, stream);
+                (void)hipStreamSynchronize(stream);
+                (void)hipFree(sb);
+                for (int wv = 0; wv < 4; ++wv) {
+                    fprintf(stderr, "cascade stamps wave %d: ticks %llu  cycles/tick: level-0 write+barrier %.0f", wv, hb[wv * 16 + 8], hb[wv * 16] / double(hb[wv * 16 + 8]));
+                    for (int i = 1; i < 8; ++i) fprintf(stderr, "  stage %d: %.0f", i - 1, hb[wv * 16 + i] / double(hb[wv * 16 + 8]));
+                    fprintf(stderr, "\n");
+                }
+            } else hipLaunchKernelGGL((cqt_cascade_kernel<12, C, NT, true>), grid, dim3(NT), 0, stream, a);
+        }
         else hipLaunchKernelGGL((cqt_cascade_kernel<12, C, NT, false>), grid, dim3(NT), 0, stream, a);
     };
     if (p->engine == 4) {
