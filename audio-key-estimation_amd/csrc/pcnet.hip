@@ -2217,7 +2217,6 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     AKE_REQUIRE(n && mel && key_out && d_key && d_tonic && grads_out, AKE_ERR_INVALID, "pcnet backward: null argument");
     AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
     AKE_REQUIRE(!n->cfg.genre || d_genre, AKE_ERR_INVALID, "pcnet backward: genre head enabled but d_genre is null");
-    AKE_REQUIRE(n->cfg.local == 0, AKE_ERR_UNSUPPORTED, "pcnet: training a --local net is not built");
     AKE_REQUIRE(!(n->cfg.resblock || n->cfg.pc2p_mem || n->cfg.p2pc_conv || n->cfg.stay_sixth || n->cfg.denseblock), AKE_ERR_UNSUPPORTED,
                 "pcnet: training a --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth net is not built");
     Buffers b;
@@ -2265,7 +2264,6 @@ int ake_pcnet_forward_f32(const ake_pcnet* n, const float* mel, int batch, int f
 int ake_pcnet_forward_train_f32(const ake_pcnet* n, const float* mel, int batch, int frames, const int64_t* seq_length,
                                 float* key_out, float* tonic_out, float* genre_out, float* bn_stats_out, void* workspace,
                                 size_t ws_bytes, ake_stream_t stream) {
-    AKE_REQUIRE(!n || n->cfg.local == 0, AKE_ERR_UNSUPPORTED, "pcnet: training a --local net (per-frame losses, models.py:861-876) is not built");
     AKE_REQUIRE(!n || !(n->cfg.resblock || n->cfg.pc2p_mem || n->cfg.p2pc_conv || n->cfg.stay_sixth || n->cfg.denseblock), AKE_ERR_UNSUPPORTED,
                 "pcnet: training a --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth net is not built (inference only)");
     return forward_impl(n, true, mel, batch, frames, seq_length, key_out, tonic_out, genre_out, bn_stats_out, workspace, ws_bytes, stream);

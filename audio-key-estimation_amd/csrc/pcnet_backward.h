@@ -182,7 +182,16 @@ struct Bwd {
         pa.Tm = Tm; pa.seq = reinterpret_cast<const long long*>(seq);
         pa.n_pool_layers = L - 1; pa.tp = tp; pa.shrink = (c.kernel_size - 1) * c.head_layers; pa.batch = B;
         pa.maps[0] = b.map_k; pa.maps[1] = b.map_t; pa.maps[2] = c.genre ? b.map_g : nullptr; pa.max_pool = c.max_pool;
-        {
+        if (c.local > 0) {   // --local: sliding-window max, per-frame outputs (no seq_length, no time pooling in the layers)
+            AKE_REQUIRE(Tm >= c.local, AKE_ERR_INVALID, "pcnet --local backward: %d map frames are fewer than the pooling window %d", Tm, c.local);
+            LocalPoolBwdArgs la;
+            std::memset(&la, 0, sizeof(la));
+            for (int h = 0; h < 3; ++h) { la.d_out[h] = pa.d_out[h]; la.maps[h] = pa.maps[h]; la.d_map[h] = pa.d_map[h]; }
+            la.key_out = key_out;
+            la.Tm = Tm; la.Tq = Tm - c.local + 1; la.W = c.local; la.batch = B;
+            ake::ProfScope ps("local_pool_bwd_kernel", s);
+            hipLaunchKernelGGL(local_pool_bwd_kernel, dim3(static_cast<unsigned>((static_cast<long long>(B) * 12 * Tm + 255) / 256), 3), dim3(256), 0, s, la);
+        } else {
             ake::ProfScope ps("head_pool_bwd_kernel", s);
             hipLaunchKernelGGL(head_pool_bwd_kernel, dim3((B * 12 + 63) / 64, 3), dim3(64), 0, s, pa);
         }
@@ -310,7 +319,13 @@ struct Bwd {
         {
             ake::ProfScope ps("semi_bwd_weight_kernel", s);
             const size_t lds = std::max<size_t>(static_cast<size_t>(4) * (C * Tn + 3 * C * (Tn + 2)), 4 * 9 * 64) * sizeof(float);
-            AKE_REQUIRE(C <= 8 && lds <= kLdsBudget, AKE_ERR_UNSUPPORTED, "backward: pool_semi weight gradient handles <= 8 channels and %zu B of LDS (got %zu: too many frames)", kLdsBudget, lds);
+            const size_t cap = 160 * 1024;          // one workgroup per CU beyond 64 KB (--local clips: no time pooling, more frames)
+            AKE_REQUIRE(C <= 8 && lds <= cap, AKE_ERR_UNSUPPORTED, "backward: pool_semi weight gradient handles <= 8 channels and %zu B of LDS (got %zu: too many frames)", cap, lds);
+            static ake::DeviceOnce semi_attr;
+            if (lds > kLdsBudget && semi_attr.need()) {
+                AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(semi_bwd_weight_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(cap)));
+                semi_attr.mark();
+            }
             hipLaunchKernelGGL(semi_bwd_weight_kernel, dim3((P / 3 + kSemiRows - 1) / kSemiRows, B), dim3(256), lds, s, g, x, x_aff,
                                grad_of(m + "pool_semi.weight"), static_cast<long long>(n->grad_floats), C, P, Tn);
         }

@@ -85,6 +85,52 @@ __global__ void head_pool_bwd_kernel(PoolHeadBwdArgs a) {
     for (int t = 0; t < a.Tm; ++t) dm[t] = t < L ? gl : 0.f;
 }
 
+// ---- --local heads, backward (models.py:720-722, 805-810) ---------------------------------------------------------
+// Forward: out[(clip * 12 + p) * Tq + t] = max_{w < W} map[(clip * 12 + p) * Tm + t + w] (sigmoid on key), genre = the map.
+// One thread per map element (clip, p, tau) gathers the gradients of the windows whose (first) maximum sits at tau -- MaxPool2d's
+// backward -- in a fixed order, so the result does not depend on scheduling.  d_map is [B][12][Tm]; row 11 of the genre one is zero.
+struct LocalPoolBwdArgs {
+    const float* d_out[3];    // dL/d(key_out, tonic_out) in the maps' order [B][12][Tq]; dL/d(genre_out) [B][11][Tm]
+    const float* key_out;     // sigmoid output [B][12][Tq]
+    const float* maps[3];     // the forward's maps (key, tonic: [B][12][Tm])
+    float* d_map[3];
+    int Tm, Tq, W, batch;
+};
+
+__global__ void local_pool_bwd_kernel(LocalPoolBwdArgs a) {
+    const int which = blockIdx.y;
+    if (!a.d_map[which]) return;
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= static_cast<long long>(a.batch) * 12 * a.Tm) return;
+    const int tau = static_cast<int>(i % a.Tm);
+    const long long row = i / a.Tm;                       // clip * 12 + p
+    if (which == 2) {
+        const int p = static_cast<int>(row % 12);
+        const long long clip = row / 12;
+        a.d_map[2][i] = p < 11 ? a.d_out[2][(clip * 11 + p) * a.Tm + tau] : 0.f;
+        return;
+    }
+    const float* m = a.maps[which] + row * a.Tm;
+    const float mv = m[tau];
+    float acc = 0.f;
+    const int t0 = tau - a.W + 1 > 0 ? tau - a.W + 1 : 0;
+    const int t1 = tau < a.Tq - 1 ? tau : a.Tq - 1;
+    for (int t = t0; t <= t1; ++t) {
+        // tau is the arg-max of window t iff nothing before it in the window is >= and nothing after it is >
+        bool best = true;
+        for (int w = t; w < tau && best; ++w) best = m[w] < mv;
+        for (int w = tau + 1; w < t + a.W && best; ++w) best = m[w] <= mv;
+        if (!best) continue;
+        float g = a.d_out[which][row * a.Tq + t];
+        if (which == 0) {
+            const float y = a.key_out[row * a.Tq + t];
+            g *= y * (1.f - y);
+        }
+        acc += g;
+    }
+    a.d_map[which][i] = acc;
+}
+
 // ---- LeakyReLU' and the BatchNorm reductions -------------------------------------------------------------------------
 // g (in: ga, out: g1) and z share the layout [B][ctot][HT]; channels [coff, coff + C) are processed.
 // grid = (C, B); stats2[c] += (sum g1, sum g1 * zhat, sum (z - mean_f32))

@@ -512,10 +512,10 @@ class PitchClassNet(LightningModule):
         out_dtype = mel.dtype if mel.is_floating_point() else torch.float32
         x = mel.to(device=device, dtype=torch.float32).contiguous()
         B, _, _, Tn = x.shape
-        if self.local:
+        if self.local and not self.training:
             return self._forward_local(x, out_dtype)
         seq = None
-        if seq_length is not None:
+        if seq_length is not None and not self.local:          # --local: per-frame outputs, seq_length only enters the losses
             seq = torch.as_tensor(seq_length).to(device=device, dtype=torch.int64).reshape(-1)
             if seq.numel() == 1 and B > 1:
                 seq = seq.expand(B)
@@ -552,18 +552,10 @@ class PitchClassNet(LightningModule):
     def _forward_local(self, x, out_dtype):
         """--local (models.py:805-810): per-frame outputs key (B, T', 12) with sigmoid, tonic (B, T', 12), genre (B, Tm, 11); the
         shapes are the reference's ``reshape`` of the (B, 1, rows, frames) maps -- a reinterpretation, not a transpose."""
-        if self.training:
-            raise NotImplementedError("training a --local net (per-frame losses, models.py:861-876) is not built on the HIP path")
         device = x.device
         B, _, _, Tn = x.shape
         L = _lib.lib()
-        tq, tm = C.c_int(), C.c_int()
-        _lib.check(L.ake_pcnet_local_frames(self._h, Tn, C.byref(tq), C.byref(tm)), "ake_pcnet_local_frames")
-        if tq.value < 1:
-            raise _lib.AkeError(f"--local: {Tn} frames leave {tm.value} map frames, fewer than the pooling window {self.local_window}")
-        key = torch.empty((B, tq.value, 12), dtype=torch.float32, device=device)
-        tonic = torch.empty((B, tq.value, 12), dtype=torch.float32, device=device)
-        genre = torch.empty((B, tm.value, 11), dtype=torch.float32, device=device) if self.genre else None
+        key, tonic, genre = self._empty_outputs(B, Tn, device)
         with torch.cuda.device(device):
             ws = self._workspace(L.ake_pcnet_workspace_bytes(self._h, B, Tn), device)
             _lib.check(L.ake_pcnet_forward_local_f32(self._h, x.data_ptr(), B, Tn, key.data_ptr(), tonic.data_ptr(),
@@ -574,15 +566,26 @@ class PitchClassNet(LightningModule):
             return key.to(out_dtype), tonic.to(out_dtype), genre.to(out_dtype)
         return key.to(out_dtype), tonic.to(out_dtype)
 
+    def _empty_outputs(self, B, Tn, device):
+        """Output tensors of one forward: (B, 12) / (B, 11), or with --local the per-frame (B, T', 12) / (B, Tm, 11)."""
+        if not self.local:
+            return (torch.empty((B, 12), dtype=torch.float32, device=device), torch.empty((B, 12), dtype=torch.float32, device=device),
+                    torch.empty((B, 11), dtype=torch.float32, device=device) if self.genre else None)
+        tq, tm = C.c_int(), C.c_int()
+        _lib.check(_lib.lib().ake_pcnet_local_frames(self._h, Tn, C.byref(tq), C.byref(tm)), "ake_pcnet_local_frames")
+        if tq.value < 1:
+            raise _lib.AkeError(f"--local: {Tn} frames leave {tm.value} map frames, fewer than the pooling window {self.local_window}")
+        return (torch.empty((B, tq.value, 12), dtype=torch.float32, device=device),
+                torch.empty((B, tq.value, 12), dtype=torch.float32, device=device),
+                torch.empty((B, tm.value, 11), dtype=torch.float32, device=device) if self.genre else None)
+
     def _forward_train_raw(self, x, seq, ws=None):
         """x (B,1,P,T) float32 contiguous on the device -> float32 outputs; updates the BatchNorm running statistics.  ``ws``: the
         workspace the activations are left in (an autograd node's own, see _TrainStep); default: the module's shared one."""
         device = x.device
         B, _, _, Tn = x.shape
         L = _lib.lib()
-        key = torch.empty((B, 12), dtype=torch.float32, device=device)
-        tonic = torch.empty((B, 12), dtype=torch.float32, device=device)
-        genre = torch.empty((B, 11), dtype=torch.float32, device=device) if self.genre else None
+        key, tonic, genre = self._empty_outputs(B, Tn, device)
         ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(device):
             if ws is None:
@@ -639,7 +642,7 @@ class PitchClassNet(LightningModule):
         f32 = lambda t: None if t is None else t.to(device=device, dtype=torch.float32).contiguous()
         d_key, d_tonic, d_genre = f32(d_key), f32(d_tonic), f32(d_genre)
         if self.genre and d_genre is None:
-            d_genre = torch.zeros((B, 11), dtype=torch.float32, device=device)
+            d_genre = torch.zeros_like(self._empty_outputs(B, Tn, device)[2])
         flat = into if into is not None else torch.empty(int(L.ake_pcnet_grad_floats(self._h)), dtype=torch.float32, device=device)
         ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(device):
@@ -693,8 +696,50 @@ class PitchClassNet(LightningModule):
         return out
 
     # ------------------------------------------------------------------ steps (models.py:819-1027)
+    def _general_step_local(self, batch):
+        """--local branch of general_step (models.py:861-876, 898-909): per-frame labels (B, T', 12); for every clip the losses and
+        scores cover its first ``seq_length - loc_window_size * frames + 1`` frames and are averaged over the batch.  The tonic accuracy
+        covers two frames fewer (the reference's ``seq_length - (loc_window_size * frames + 1)``, :906 -- kept).  The reference's
+        --local --genre lines (:866-873, :907-911) index a (B, 11) "mask" into per-frame tensors and re-mask inside the clip loop;
+        they cannot run for any batch, so that combination is refused here rather than invented."""
+        opt = self.opt
+        if self.genre:
+            raise NotImplementedError("general_step with --local and --genre: the reference's lines (models.py:866-873) do not run; "
+                                      "forward / backward of such a net are available, the loss is the caller's")
+        mel = batch["mel"]
+        out = self.forward(mel, None)
+        key_out, tonic_out = out[0], out[1]
+        dev = key_out.device
+        key_labels = batch["key_labels"].to(device=dev, dtype=key_out.dtype)
+        tonic_labels = batch["tonic_labels"].long().to(dev)
+        tonic_idx = torch.argmax(tonic_labels, dim=2)
+        key_signature_id = batch["key_signature_id"].to(dev)
+        span = _opt_get(opt, "loc_window_size", 10) * _opt_get(opt, "frames", 5)
+        seq = [int(v) for v in torch.as_tensor(batch["seq_length"]).reshape(-1).tolist()]
+        B = mel.shape[0]
+        bce = tonic_loss = 0
+        sums = [0.0] * 7
+        acc_tonic = 0.0
+        for i in range(B):
+            n = seq[i] - span + 1
+            bce = bce + F.binary_cross_entropy(key_out[i, :n], key_labels[i, :n])
+            tonic_loss = tonic_loss + F.cross_entropy(tonic_out[i, :n], tonic_idx[i, :n])
+            with torch.no_grad():
+                sub = self.mirex_score(key_labels[i, :n], key_out[i, :n], tonic_labels[i, :n], tonic_out[i, :n], key_signature_id[i, :n])
+                sums = [a + b for a, b in zip(sums, sub)]
+                m = seq[i] - (span + 1)
+                acc_tonic = acc_tonic + (torch.argmax(tonic_out[i, :m], dim=1) == tonic_idx[i, :m]).float().mean()
+        loss = _opt_get(opt, "key_weight", 1.0) * bce / B + _opt_get(opt, "tonic_weight", 1.0) * tonic_loss / B
+        if _opt_get(opt, "use_cos", False):
+            loss = loss + (1 - F.cosine_similarity(key_out, key_labels, dim=1).sum() / key_out.shape[0])
+        mirex, correct, fifths, relative, parallel, other, accuracy = [torch.as_tensor(v / B).clone().float() for v in sums]
+        return (loss, accuracy, mirex, correct, fifths, relative, parallel, other, torch.as_tensor(acc_tonic / B).float(),
+                torch.tensor(0.0))
+
     def general_step(self, batch, batch_idx, mode):
         opt = self.opt
+        if self.local:
+            return self._general_step_local(batch)
         mel = batch["mel"]
         key_signature_id = batch["key_signature_id"]
         key_labels = batch["key_labels"].to(mel.dtype if mel.is_floating_point() else torch.float32)

@@ -177,7 +177,9 @@ int ake_pcnet_forward_local_f32(const ake_pcnet* net, const float* mel_dev, int 
  * outputs and per-channel sums; normalisation + LeakyReLU are applied by the next reader, never as a pass of their own.
  * bn_stats_out (optional, device): [sum of BN channels][3] = batch mean, biased batch variance, elements per channel, in
  * the layer order of ake_pcnet_bn_info -- what the caller needs for torch's running_mean / running_var update
- * (momentum 0.1, unbiased variance).  The whole batch is processed in one pass (no chunking). */
+ * (momentum 0.1, unbiased variance).  The whole batch is processed in one pass (no chunking).
+ * A net created with local > 0 (--local, models.py:805-810) takes seq_length_dev = NULL and writes the per-frame outputs of
+ * ake_pcnet_forward_local_f32: key / tonic (B, T', 12), genre (B, Tm, 11) with (T', Tm) from ake_pcnet_local_frames. */
 int ake_pcnet_num_bn(const ake_pcnet* net);
 int ake_pcnet_bn_info(const ake_pcnet* net, int index, const char** name, int* channels, int* channel_offset);
 size_t ake_pcnet_train_workspace_bytes(const ake_pcnet* net, int batch, int frames);
@@ -192,7 +194,9 @@ int ake_pcnet_forward_train_f32(const ake_pcnet* net, const float* mel_dev, int 
  * is the forward's key output (for the sigmoid derivative).  grads_out_dev receives dLoss/d(parameter) for every float entry of
  * the state_dict, flat, at ake_pcnet_grad_offset(name) (ake_pcnet_grad_floats() floats in total; running statistics get zeros).
  * accumulate != 0 adds to grads_out_dev instead of overwriting it (accumulate_grad_batches, train_model.py:118).
- * Built for num_layers <= 2 without --max_pool; otherwise AKE_ERR_UNSUPPORTED. */
+ * For a --local net d_* and key_out carry the per-frame shapes of the local forward (the sliding-window max routes each frame's
+ * gradient to the first maximum of its window, as nn.MaxPool2d does).
+ * Built for num_layers <= 2; --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth / --denseblock: AKE_ERR_UNSUPPORTED. */
 size_t ake_pcnet_grad_floats(const ake_pcnet* net);
 int64_t ake_pcnet_grad_offset(const ake_pcnet* net, const char* name);
 int ake_pcnet_backward_f32(const ake_pcnet* net, const float* mel_dev, int batch, int frames, const int64_t* seq_length_dev,

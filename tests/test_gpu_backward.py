@@ -88,7 +88,7 @@ def _run_default(gold_default, batch, frames, seed):
     loss_ref, ref = reference_grads(sd32, x, seq, labels)
     out = net(x.to(DEV), seq.to(DEV))
     loss = loss_fn(out[0], out[1], out[2], *(t.to(DEV) for t in labels))
-    assert abs(float(loss) - loss_ref) < 2e-5 * max(1.0, abs(loss_ref))
+    assert abs(float(loss.detach()) - loss_ref) < 2e-5 * max(1.0, abs(loss_ref))
     loss.backward()
     return grad_errors(net, ref)
 
@@ -229,3 +229,84 @@ def test_backward_after_other_forwards_uses_its_own_activations(gold_default):
     l2.backward(retain_graph=True)
     with pytest.raises(Exception):
         l2.backward()
+
+
+def _local_loss(key, tonic, genre, key_labels, tonic_idx, genre_idx, ns):
+    """Per-frame losses of general_step's --local branch (models.py:861-876): each clip over its first n frames, mean over clips;
+    a per-frame genre term on top so that the genre head's gradient path is exercised too."""
+    loss = 0
+    for i, n in enumerate(ns):
+        loss = loss + F.binary_cross_entropy(key[i, :n], key_labels[i, :n].to(key.dtype)) + F.cross_entropy(tonic[i, :n], tonic_idx[i, :n])
+        if genre is not None:
+            loss = loss + 0.1 * F.cross_entropy(genre[i], genre_idx[i])
+    return loss / len(ns)
+
+
+# flip-free (shape, seed) pairs picked with tests/tools/local_grad_scan.py (no time pooling: twice the pre-activations of the default
+# net per frame, so kink flips are more frequent); (1, 300) is past the 64 KB LDS form of the semitone weight-gradient kernel
+@pytest.mark.parametrize("batch,frames,seed", [(3, 120, 6), (2, 150, 3), (1, 300, 0)])
+def test_local_net_gradients(gold_default, batch, frames, seed):
+    """--local training: train-mode forward with per-frame outputs, backward through the sliding-window max
+    (gradient to the first maximum of each window, as nn.MaxPool2d), against float64 autograd through the oracle's --local forward
+    (pinned on the reference's own --local fixture in test_oracle_golden)."""
+    opt = Namespace(**json.loads(str(gold_default["opt"])))
+    opt.local = True
+    net = ake_amd.PitchClassNet(288, 12, 2, 7, opt)
+    sd32 = golden_state_dict(gold_default)
+    net.load_state_dict(sd32, strict=True)
+    net = net.to(DEV).train()
+    W = net.local_window
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand((batch, 1, 288, frames), generator=g) * 2.5
+    Tm = frames - 12
+    Tq = Tm - W + 1
+    ns = [Tq, Tq - 9, Tq - 20][:batch]
+    key_labels = (torch.rand((batch, Tq, 12), generator=g) > 0.5).float()
+    tonic_idx = torch.randint(0, 12, (batch, Tq), generator=g)
+    genre_idx = torch.randint(0, 11, (batch, Tm), generator=g)
+    sd = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.double() if v.is_floating_point() else v)
+          for k, v in sd32.items()}
+    out = pcnet_oracle.pcnet_forward(sd, x.double(), None, training=True, local_window=W)
+    assert out[0].shape == (batch, Tq, 12) and out[2].shape == (batch, Tm, 11)
+    lref = _local_loss(out[0], out[1], out[2], key_labels, tonic_idx, genre_idx, ns)
+    lref.backward()
+    ref = {k: v.grad for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad}
+    o = net(x.to(DEV), None)
+    assert o[0].shape == (batch, Tq, 12) and o[1].shape == (batch, Tq, 12) and o[2].shape == (batch, Tm, 11)
+    for a, r in zip(o, out):
+        assert float((a.detach().cpu().double() - r.detach()).abs().max()) < 2e-5 * max(1.0, float(r.detach().abs().max()))
+    loss = _local_loss(o[0], o[1], o[2], key_labels.to(DEV), tonic_idx.to(DEV), genre_idx.to(DEV), ns)
+    assert abs(float(loss.detach()) - float(lref.detach())) < 2e-5 * max(1.0, abs(float(lref.detach())))
+    loss.backward()
+    rows = grad_errors(net, ref)
+    bad = [(e, n) for e, n, _ in rows if e > ILL_CONDITIONED.get(n, 5e-5)]
+    assert not bad, bad[:6]
+
+
+def test_local_training_step_runs_and_learns(gold_default):
+    """general_step's --local branch through training_step + the fused Adam: per-frame labels, the loss falls on a fixed batch."""
+    opt = Namespace(**json.loads(str(gold_default["opt"])))
+    opt.local, opt.genre, opt.lr = True, False, 1e-3
+    torch.manual_seed(0)
+    net = ake_amd.PitchClassNet(288, 12, 2, 7, opt).to(DEV).train()
+    span = opt.frames * opt.loc_window_size
+    g = torch.Generator().manual_seed(4)
+    B, T = 2, 120
+    Tq = T - span + 1
+    tonic = F.one_hot(torch.randint(0, 12, (B, Tq), generator=g), 12)
+    batch = {"mel": torch.rand((B, 1, 288, T), generator=g).to(DEV) * 2.5, "seq_length": torch.tensor([T, T - 10]),
+             "key_labels": (torch.rand((B, Tq, 12), generator=g) > 0.5).float(), "tonic_labels": tonic,
+             "key_signature_id": F.one_hot(torch.randint(0, 24, (B, Tq), generator=g), 24)}
+    optim = net.configure_optimizers()[0][0]
+    losses = []
+    for _ in range(12):
+        optim.zero_grad()
+        d = net.training_step(batch, 0)
+        d["loss"].backward()
+        optim.step()
+        losses.append(float(d["loss"]))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.05, losses
+    with pytest.raises(NotImplementedError, match="--local and --genre"):
+        opt2 = Namespace(**json.loads(str(gold_default["opt"])))
+        opt2.local = True
+        ake_amd.PitchClassNet(288, 12, 2, 7, opt2).to(DEV).train().training_step(batch, 0)
