@@ -122,7 +122,7 @@ struct ake_pcnet {
     size_t dense_aff_floats = 0;
     float* dense_aff_dev = nullptr;
     int32_t* dense_aff_idx_dev = nullptr;
-    uint4* bf_frags_dev = nullptr;     // split-bf16 weight fragments of conv_p2p_bf16_kernel, rebuilt from the eval packs on the device
+    uint4* bf_frags_dev = nullptr;     // split-bf16 weight fragments of conv_p2p_f16_kernel, rebuilt from the eval packs on the device
     size_t bf_frags_count = 0;         // uint4 entries
 };
 
@@ -429,7 +429,7 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
 
 // does inference run layer i's Pitch2Pitch stack on the bf16 kernel (everything but its first conv)?
 // (the bf16 kernels keep all frames of their row tile in one LDS patch: long clips fall back to the time-tiled f32 kernel)
-bool p2p_uses_bf16(const ake_pcnet* n, int i, int T) {
+bool p2p_uses_f16(const ake_pcnet* n, int i, int T) {
     static const bool f32_only = std::getenv("AKE_P2P_F32") != nullptr;
     const auto& c = n->cfg;
     if (f32_only || c.resblock || i < 1 || c.conv_layers < 2 || n->dims[i].out_p != 8 || T > 146) return false;
@@ -448,36 +448,36 @@ bool pc2pc_uses_bf16(const ake_pcnet* n, int i, int T) {
     return true;
 }
 
-// 8 -> 8 channel 7x7 pitch convolution on bf16 MFMA (conv_p2p_bf16_kernel): channels-last split planes in, planes or NCHW f32 out
-int run_p2p_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const unsigned short* xl, const Src* nchw, int batch, int H, int T,
-                 float* dst_nchw, int dst_ctot, unsigned short* oh, unsigned short* ol, hipStream_t s, const char* name) {
+// 8 -> 8 channel 7x7 pitch convolution on bf16 MFMA (conv_p2p_f16_kernel): channels-last split planes in, planes or NCHW f32 out
+int run_p2p_f16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const Src* nchw, int batch, int H, int T,
+                 float* dst_nchw, int dst_ctot, unsigned short* oh, hipStream_t s, const char* name) {
     P2pBfArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.xh = xh; a.xl = xl;
+    a.xh = xh;
     if (nchw) { a.p = nchw->p0; a.c0 = nchw->c0; a.u = nchw->p1; a.c1 = nchw->c1; a.h1 = nchw->h1 > 0 ? nchw->h1 : 1; } a.bfrag = n->bf_frags_dev + pc.bf_off; a.bias = n->blob_dev + pc.b_off;
     a.dst = dst_nchw; a.dst_clip_stride = static_cast<long long>(dst_ctot) * H * T; a.dst_coff = 0;
-    a.oh = oh; a.ol = ol;
+    a.oh = oh;
     a.H = H; a.T = T;
     a.J = (T + 1) / 2;
     a.Tp = 2 * a.J + 6;
     a.R = std::max(1, std::min(H, 8 * kP2pMT * 16 / a.J));
-    auto lds_of = [&](int R) { return (static_cast<size_t>(2) * (R + 6) * a.Tp + (kP2pStreamB ? 0 : kBfFragsPerConv)) * sizeof(uint4); };
+    auto lds_of = [&](int R) { return (static_cast<size_t>(R + 6) * a.Tp + (kP2pStreamB ? 0 : kBfFragsPerConv)) * sizeof(uint4); };
     while (a.R > 1 && lds_of(a.R) > 76 * 1024) --a.R;
     AKE_REQUIRE(lds_of(a.R) <= 150 * 1024, AKE_ERR_UNSUPPORTED, "conv %s: %d frames do not fit the bf16 kernel's LDS patch", name, T);
     a.n_row_tiles = (H + a.R - 1) / a.R;
     static ake::DeviceOnce attr_set;
     if (attr_set.need()) {
-        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_bf16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_f16_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_f16_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_f16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set.mark();
     }
     dim3 grid(a.n_row_tiles, 1, batch), block(512);
     ake::ProfScope ps(name, s);
     AKE_REQUIRE(!nchw || oh, AKE_ERR_STATE, "conv %s: the assembling variant writes channels-last planes", name);
-    if (nchw) hipLaunchKernelGGL((conv_p2p_bf16_kernel<true, true>), grid, block, lds_of(a.R), s, a);
-    else if (oh) hipLaunchKernelGGL((conv_p2p_bf16_kernel<true, false>), grid, block, lds_of(a.R), s, a);
-    else hipLaunchKernelGGL((conv_p2p_bf16_kernel<false, false>), grid, block, lds_of(a.R), s, a);
+    if (nchw) hipLaunchKernelGGL((conv_p2p_f16_kernel<true, true>), grid, block, lds_of(a.R), s, a);
+    else if (oh) hipLaunchKernelGGL((conv_p2p_f16_kernel<true, false>), grid, block, lds_of(a.R), s, a);
+    else hipLaunchKernelGGL((conv_p2p_f16_kernel<false, false>), grid, block, lds_of(a.R), s, a);
     return AKE_OK;
 }
 
@@ -499,10 +499,10 @@ int p2p_ps_rows(int H, int T, bool semi, int* plane_pos, size_t* lds) {
     if (T < 2 || (T & 1) || device_cus() < 8) return 0;
     const int J = T / 2, Tp = 2 * J + 6;
     auto plane_of = [&](int R) { return ((R + 6) * Tp + 63) / 64 * 64; };
-    auto lds_of = [&](int R) { return (static_cast<size_t>(4) * plane_of(R) + (semi ? 4 * 8 * kP2pMT * 16 * 2 : 8 * kP2pMT * kP2pPsStage)) * sizeof(uint4); };
+    auto lds_of = [&](int R) { return (static_cast<size_t>(2) * plane_of(R) + (semi ? 2 * 8 * kP2pMT * 16 * 2 : 8 * kP2pMT * kP2pPsStage)) * sizeof(uint4); };
     int R = std::max(1, std::min(H, 8 * kP2pMT * 16 / J));
     if (semi) R = R / 3 * 3;
-    while (R >= (semi ? 3 : 1) && (lds_of(R) > 156 * 1024 || plane_of(R) / 64 > 24)) R -= semi ? 3 : 1;
+    while (R >= (semi ? 3 : 1) && (lds_of(R) > 156 * 1024 || plane_of(R) / 64 > 48)) R -= semi ? 3 : 1;     // the loader: 8 waves x 6 pieces
     if (R < (semi ? 3 : 1) || H < R + 6) return 0;
     if (semi && (H % 3 || (H / 3) % 12)) return 0;
     if (plane_pos) *plane_pos = plane_of(R);
@@ -514,16 +514,16 @@ int p2p_ps_rows(int H, int T, bool semi, int* plane_pos, size_t* lds) {
 // Only in the net's last layer: an inner layer's pitch tensor is also the next layer's pitch stream (time_pool_p, models.py:395).
 bool p2p_fuses_semi(const ake_pcnet* n, int i, int P, int T) {
     static const bool off = std::getenv("AKE_P2P_PS") != nullptr && std::atoi(std::getenv("AKE_P2P_PS")) == 0;
-    return !off && !g_keep_taps && !n->cfg.p2pc_conv && !n->cfg.stay_sixth && i == n->cfg.num_layers - 1 && p2p_uses_bf16(n, i, T) && static_cast<size_t>(i) < n->semi.size() && n->semi[i].bf_off >= 0 &&
+    return !off && !g_keep_taps && !n->cfg.p2pc_conv && !n->cfg.stay_sixth && i == n->cfg.num_layers - 1 && p2p_uses_f16(n, i, T) && static_cast<size_t>(i) < n->semi.size() && n->semi[i].bf_off >= 0 &&
            p2p_ps_rows(P, T, true, nullptr, nullptr) > 0;
 }
 
-// the same convolution as a persistent launch (conv_p2p_bf16_ps_kernel): one workgroup per CU walks the row tiles.  Taken for even
+// the same convolution as a persistent launch (conv_p2p_f16_ps_kernel): one workgroup per CU walks the row tiles.  Taken for even
 // frame counts and enough tiles to give every CU at least two (always when `semi_pc` asks for the fused semitone conv: `dst` then
 // receives the semitone maps [clip][8][H / 3][T]); returns false when the shape does not qualify (the caller then launches
-// conv_p2p_bf16_kernel)
-bool run_p2p_bf16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const unsigned short* xl, const Src* nchw, int batch, int H, int T, float* dst_nchw,
-                     int dst_ctot, unsigned short* oh, unsigned short* ol, const PackedConv* semi_pc, hipStream_t s, const char* name) {
+// conv_p2p_f16_kernel)
+bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const Src* nchw, int batch, int H, int T, float* dst_nchw,
+                     int dst_ctot, unsigned short* oh, const PackedConv* semi_pc, hipStream_t s, const char* name) {
     static const bool off = std::getenv("AKE_P2P_PS") != nullptr && std::atoi(std::getenv("AKE_P2P_PS")) == 0;
     if (off) return false;
     P2pPsArgs a;
@@ -532,12 +532,12 @@ bool run_p2p_bf16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sh
     a.R = p2p_ps_rows(H, T, semi_pc != nullptr, &a.plane_pos, &lds);
     if (a.R <= 0) return false;
     const int n_cus = device_cus();
-    a.xh = xh; a.xl = xl; a.bfrag = n->bf_frags_dev + pc.bf_off; a.bias = n->blob_dev + pc.b_off;
+    a.xh = xh; a.bfrag = n->bf_frags_dev + pc.bf_off; a.bias = n->blob_dev + pc.b_off;
     if (nchw) {
         if (dst_nchw || nchw->c0 < 1 || nchw->c0 + nchw->c1 > 8) return false;
         a.p = nchw->p0; a.c0 = nchw->c0; a.u = nchw->p1 ? nchw->p1 : nchw->p0; a.c1 = nchw->p1 ? nchw->c1 : 0; a.h1 = nchw->h1 > 0 ? nchw->h1 : 1;
     }
-    a.dst = dst_nchw; a.dst_clip_stride = static_cast<long long>(dst_ctot) * (semi_pc ? H / 3 : H) * T; a.oh = oh; a.ol = ol;
+    a.dst = dst_nchw; a.dst_clip_stride = static_cast<long long>(dst_ctot) * (semi_pc ? H / 3 : H) * T; a.oh = oh;
     if (semi_pc) {
         if (!dst_nchw || semi_pc->bf_off < 0) return false;
         a.sfrag = n->bf_frags_dev + semi_pc->bf_off; a.sbias = n->blob_dev + semi_pc->b_off;
@@ -551,19 +551,19 @@ bool run_p2p_bf16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sh
     }
     static ake::DeviceOnce attr_set;
     if (attr_set.need()) {
-        const void* fns[] = {reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<1, 0>), reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<1, 5>),
-                             reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<1, 8>), reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<0, 0>),
-                             reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<2, 0>), reinterpret_cast<const void*>(conv_p2p_bf16_ps_kernel<1, 0, true>)};
+        const void* fns[] = {reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<1, 0>), reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<1, 5>),
+                             reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<1, 8>), reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<0, 0>),
+                             reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<2, 0>), reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<1, 0, true>)};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
         attr_set.mark();
     }
     dim3 grid(std::min(n_cus / 8 * 8, (a.n_tiles + 7) / 8 * 8)), block(512);
     ake::ProfScope ps(name, s);
-    if (semi_pc) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<2, 0>), grid, block, lds, s, a);
-    else if (dst_nchw) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<0, 0>), grid, block, lds, s, a);
-    else if (nchw && a.c0 + a.c1 <= 5) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<1, 5>), grid, block, lds, s, a);
-    else if (nchw) hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<1, 8>), grid, block, lds, s, a);
+    if (semi_pc) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<2, 0>), grid, block, lds, s, a);
+    else if (dst_nchw) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<0, 0>), grid, block, lds, s, a);
+    else if (nchw && a.c0 + a.c1 <= 5) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<1, 5>), grid, block, lds, s, a);
+    else if (nchw) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<1, 8>), grid, block, lds, s, a);
     else {
         static const bool stamp_env = std::getenv("AKE_P2P_STAMP") != nullptr;
         unsigned long long* sb = nullptr;
@@ -571,7 +571,7 @@ bool run_p2p_bf16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sh
             // diagnostic build: in-kernel cycle stamps of the tile loop's sections (workgroup 0), printed to stderr; never timed
             (void)hipMemsetAsync(sb, 0, 64 * sizeof(unsigned long long), s);
             a.stamps = sb;
-            hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<1, 0, true>), grid, block, lds, s, a);
+            hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<1, 0, true>), grid, block, lds, s, a);
             unsigned long long hb[64];
             (void)hipMemcpyAsync(hb, sb, sizeof(hb), hipMemcpyDeviceToHost, s);
             (void)hipStreamSynchronize(s);
@@ -580,7 +580,7 @@ bool run_p2p_bf16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sh
                 fprintf(stderr, "p2p stamps wave %d: tiles %llu  cycles/tile: vmcnt-wait %.0f barrier %.0f late-epilogue %.0f multiply(+dma+stores) %.0f epilogue %.0f\n", wv,
                         hb[wv * 8 + 5], hb[wv * 8 + 0] / double(hb[wv * 8 + 5]), hb[wv * 8 + 1] / double(hb[wv * 8 + 5]), hb[wv * 8 + 2] / double(hb[wv * 8 + 5]),
                         hb[wv * 8 + 3] / double(hb[wv * 8 + 5]), hb[wv * 8 + 4] / double(hb[wv * 8 + 5]));
-        } else hipLaunchKernelGGL((conv_p2p_bf16_ps_kernel<1, 0>), grid, block, lds, s, a);
+        } else hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<1, 0>), grid, block, lds, s, a);
     }
     return true;
 }
@@ -1394,7 +1394,7 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
     for (const auto& layer : n->p2p)
         for (const PackedConv& pc : layer)
             if (pc.bf_off >= 0)
-                hipLaunchKernelGGL(pack_p2p_bf16_kernel, dim3((14 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc.w_off, n->bf_frags_dev + pc.bf_off, pc.cin);
+                hipLaunchKernelGGL(pack_p2p_f16_kernel, dim3((14 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc.w_off, n->bf_frags_dev + pc.bf_off, pc.cin);
     for (const PackedConv* pc : pcs)
         if (pc->bf_off >= 0) {
             const int NT = pc->cout / 16;
@@ -1407,7 +1407,7 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
                 hipLaunchKernelGGL(pack_l0_bf16_kernel, dim3(3), dim3(256), 0, s, n->blob_dev + pc.w_off, n->bf_frags_dev + pc.l0_off, pc.cin, pc.cout);
     for (size_t i = 1; i < n->semi.size(); ++i)
         if (n->semi[i].bf_off >= 0)
-            hipLaunchKernelGGL(pack_semi_bf16_kernel, dim3(1), dim3(192), 0, s, n->blob_dev + n->semi[i].w_off, n->bf_frags_dev + n->semi[i].bf_off);
+            hipLaunchKernelGGL(pack_semi_f16_kernel, dim3(1), dim3(192), 0, s, n->blob_dev + n->semi[i].w_off, n->bf_frags_dev + n->semi[i].bf_off);
     for (const PackedConv* pc : h1)
         if (pc->bf_off >= 0)
             hipLaunchKernelGGL(pack_head1_bf16_kernel, dim3((pc->kh * 22 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
@@ -1912,12 +1912,10 @@ struct Fwd {
             const float* in_aff = train ? b.aff_p2pin[i] : nullptr;
             float* out = nullptr;
             float* out_aff = nullptr;
-            // inference: every conv of the stack but the first is 8 -> 8 channels and runs on bf16 MFMA with split operands; the
-            // activations between them are channels-last split planes that live in the same ping-pong buffers (32 B per position
-            // either way: 8 f32 channels, or 8 bf16 hi + 8 bf16 lo)
-            const bool bf = !train && p2p_uses_bf16(n, i, Ti);
+            // inference: the stack runs on f16 MFMA (f16 activations x hi + lo f16 weights, see conv_p2p_f16_kernel); the activations
+            // between its convs are ONE channels-last f16 plane (16 B per position) in the same ping-pong buffers
+            const bool bf = !train && p2p_uses_f16(n, i, Ti);
             bool fused_semi = false;
-            const size_t plane = static_cast<size_t>(B) * P * Ti * 8;                 // bf16 elements per plane
             if (c.resblock) {
                 if ((rc = res_stack(n->p2p[i], 0, sdesc, B, P, Ti, b.pa[i], b.pb[i], nullptr, 0, "conv_mfma_kernel/p2p"))) return rc;
                 out = b.pa[i];
@@ -1929,21 +1927,21 @@ struct Fwd {
                     unsigned short* oh = reinterpret_cast<unsigned short*>(out);
                     const bool last_conv = j == c.conv_layers - 1;
                     if (j == 0) {   // the stack's input (pitch stream | repeated up_sixth output) is assembled by the kernel's own loader
-                        if (run_p2p_bf16_ps(n, n->p2p[i][0], nullptr, nullptr, &sdesc, B, P, Ti, nullptr, d.out_p, oh, oh + plane, nullptr, s, "conv_p2p_bf16_kernel")) continue;
-                        if ((rc = run_p2p_bf16(n, n->p2p[i][0], nullptr, nullptr, &sdesc, B, P, Ti, nullptr, d.out_p, oh, oh + plane, s, "conv_p2p_bf16_kernel")))
+                        if (run_p2p_f16_ps(n, n->p2p[i][0], nullptr, &sdesc, B, P, Ti, nullptr, d.out_p, oh, nullptr, s, "conv_p2p_f16_kernel")) continue;
+                        if ((rc = run_p2p_f16(n, n->p2p[i][0], nullptr, &sdesc, B, P, Ti, nullptr, d.out_p, oh, s, "conv_p2p_f16_kernel")))
                             return rc;
                     } else {
                         const unsigned short* xh = reinterpret_cast<const unsigned short*>(((j - 1) & 1) ? b.pb[i] : b.pa[i]);
                         if (last_conv && p2p_fuses_semi(n, i, P, Ti) &&
-                            run_p2p_bf16_ps(n, n->p2p[i][j], xh, xh + plane, nullptr, B, P, Ti, out, d.out_p, nullptr, nullptr, &n->semi[i], s, "conv_p2p_bf16_kernel")) {
+                            run_p2p_f16_ps(n, n->p2p[i][j], xh, nullptr, B, P, Ti, out, d.out_p, nullptr, &n->semi[i], s, "conv_p2p_f16_kernel")) {
                             fused_semi = true;    // `out` holds the semitone maps [clip][8][P / 3][T], not the pitch tensor
                             continue;
                         }
-                        if (run_p2p_bf16_ps(n, n->p2p[i][j], xh, xh + plane, nullptr, B, P, Ti, last_conv ? out : nullptr, d.out_p, last_conv ? nullptr : oh,
-                                            last_conv ? nullptr : oh + plane, nullptr, s, "conv_p2p_bf16_kernel"))
+                        if (run_p2p_f16_ps(n, n->p2p[i][j], xh, nullptr, B, P, Ti, last_conv ? out : nullptr, d.out_p, last_conv ? nullptr : oh, nullptr, s,
+                                            "conv_p2p_f16_kernel"))
                             continue;
-                        if ((rc = run_p2p_bf16(n, n->p2p[i][j], xh, xh + plane, nullptr, B, P, Ti, last_conv ? out : nullptr, d.out_p, last_conv ? nullptr : oh,
-                                               last_conv ? nullptr : oh + plane, s, "conv_p2p_bf16_kernel")))
+                        if ((rc = run_p2p_f16(n, n->p2p[i][j], xh, nullptr, B, P, Ti, last_conv ? out : nullptr, d.out_p, last_conv ? nullptr : oh, s,
+                                               "conv_p2p_f16_kernel")))
                             return rc;
                     }
                     continue;
@@ -2327,8 +2325,8 @@ static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frame
                     ake::set_error("tap: '%s' is fused with the semitone conv that follows it (never written); ake_debug_keep_taps(1) before the forward keeps it", name);
                     return AKE_ERR_INVALID;
                 }
-                // inference keeps the stack's intermediate activations as channels-last split-bf16 planes (conv_p2p_bf16_kernel)
-                if (j < last_j && p2p_uses_bf16(n, i, Ti) && channels_last) *channels_last = 1;
+                // inference keeps the stack's intermediate activations as channels-last split-bf16 planes (conv_p2p_f16_kernel)
+                if (j < last_j && p2p_uses_f16(n, i, Ti) && channels_last) *channels_last = 2;      // one f16 plane
                 return set((j & 1) ? b.pb[i] : b.pa[i], d.out_p, P, Ti);
             }
         }
@@ -2367,7 +2365,7 @@ int ake_pcnet_tap_copy(const ake_pcnet* n, const char* name, int batch, int fram
         const long long total = shape[0] * shape[1] * shape[2] * shape[3];
         const unsigned short* h = reinterpret_cast<const unsigned short*>(p);
         hipLaunchKernelGGL(cl_to_nchw_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), h,
-                           h + total, out_dev, static_cast<int>(shape[1]), static_cast<int>(shape[2]), static_cast<int>(shape[3]), total);
+                           cl == 2 ? nullptr : h + total, out_dev, static_cast<int>(shape[1]), static_cast<int>(shape[2]), static_cast<int>(shape[3]), total);
         AKE_HIP_CHECK(hipGetLastError());
         return AKE_OK;
     }

@@ -610,45 +610,56 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
 }
 
 // ==========================================================================================
-// 7x7 circular pitch convolution, 8 -> 8 channels, on v_mfma_f32_16x16x32_bf16 with split operands ("bf16x3").
+// 7x7 circular pitch convolution, 8 -> 8 channels, on v_mfma_f32_16x16x32_f16: f16 activations x (f16 hi + f16 lo) weights.
 //
-// The f32 MFMA above runs at the vector rate; this form does the same contraction with 5.3x fewer matrix-pipe cycles:
-// activations and weights are kept as bf16 pairs (hi, lo; value = hi + lo to 2^-17) and every product is
-// xh*wh + xl*wh + xh*wl with f32 accumulation (relative error ~1e-5, measured against the f32 kernel in the tests).
-// What makes it cheap is the layout: activations are CHANNELS-LAST, [clip][row][frame][8 ch] per plane, so the 8
+// The f32 MFMA above runs at the vector rate; this form does the same contraction with 8x fewer matrix-pipe cycles.
+//   * weights: w = wh + wl, both f16 (wl stored times 2^11 so that it stays a normal number; its products go to an accumulator
+//     of their own that is folded in with 2^-11 at the end): exact to 2^-22, better than f32's product rounding;
+//   * activations: ONE f16 value (11 significant bits, rounding 2^-12 relative, unbiased).  Rounding the operand of these three
+//     convolutions moves the network's outputs by 1.5e-6 of their range (tests/tools/split_precision_proto.py: float64 forward with
+//     the rounding applied, golden and sparse inputs) -- below what the split-bf16 pair it replaces cost (hi + lo to 2^-17 on BOTH
+//     operands, 3 products, 2.8e-6) -- because 392 products with independent rounding errors are summed per output and the result
+//     is max-pooled over octaves.  The same prototype shows that the layer-1 pitch-class stack and the heads are NOT that
+//     tolerant (3e-5 .. 5e-4): they keep the three-product split-bf16 form.
+//   The second activation plane was what bound the previous form: per tile and CU its A fragments were 672 ds_read_b128 = 5376
+//   LDS cycles against 4032 matrix-pipe cycles (in-kernel stamps: 4450-5270 cycles per tile in the multiply loop).  Now 336 reads
+//   (2688 cycles) feed 2 products (2688 cycles), and half as many bytes are staged and written back.
+// What makes it cheap is the layout: activations are CHANNELS-LAST, [clip][row][frame][8 ch], so the 8
 // consecutive k of one MFMA lane are the 8 input channels of one tap = one aligned 16-byte LDS read, with no Toeplitz
 // gather on the A side:
 //   m = (row r, frame pair j)            A[m][k = (tap q' of the k-step, ci)] = X[r + dy][2j + 4h + q'][ci]
 //   n = (tau, co) = 8*tau + co           B[k][n] = w[co][ci][dy][4h + q' - tau]   (zero outside the 7 taps)
-//   k-step = (dy, h):  7 x 2 = 14 steps of K = 32, three MFMAs each per M-tile.
-// One workgroup = R rows x all frames of one clip (8 waves x 3 M-tiles), patch and B fragments in LDS.
-// Output: NCHW f32 (for the semitone pooling that follows the stack) or channels-last split planes (next conv).
+//   k-step = (dy, h):  7 x 2 = 14 steps of K = 32, two MFMAs each per M-tile.
+// One workgroup = R rows x all frames of one clip (8 waves x 3 M-tiles), patch in LDS.
+// Output: NCHW f32 (for the semitone pooling that follows the stack) or the channels-last f16 plane (next conv).
 // ==========================================================================================
 struct P2pBfArgs {
-    const unsigned short* xh;     // [clip][H][T][8]   (IN_NCHW == false)
-    const unsigned short* xl;
+    const unsigned short* xh;     // [clip][H][T][8] f16   (IN_NCHW == false)
     // IN_NCHW == true (first convolution of a stack): the input is assembled while staging, channels [0, c0) from the pitch stream
     // p [clip][c0][H][T], channels [c0, c0 + c1) from the up_sixth output u [clip][c1][h1][T] repeated over the octaves (row % h1;
     // models.py:140-143, 378-383), the rest zero -- the concatenated tensor never exists in memory
     const float* p;
     const float* u;
     int c0, c1, h1;
-    const uint4* bfrag;           // [14 k-steps][hi|lo][64 lanes] x 8 bf16
+    const uint4* bfrag;           // [14 k-steps][hi|lo * 2^11][64 lanes] x 8 f16
     const float* bias;            // [8] (BatchNorm folded)
     float* dst;                   // NCHW f32 [clip][dst_ctot][H][T] (OUT_CL == false)
     long long dst_clip_stride;
     int dst_coff;
-    unsigned short* oh;           // channels-last planes (OUT_CL == true)
-    unsigned short* ol;
+    unsigned short* oh;           // channels-last f16 plane (OUT_CL == true)
     int H, T, R, J, Tp, n_row_tiles;
 };
 
 typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8c __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2c __attribute__((ext_vector_type(2)));
+constexpr float kP2pLoScale = 2048.f, kP2pLoInv = 1.f / 2048.f;     // the lo weight plane is stored times 2^11 (kept normal in f16)
+__device__ __forceinline__ unsigned int f16_bits(float v) { return __builtin_bit_cast(unsigned short, static_cast<_Float16>(v)); }
 constexpr bool kP2pStreamB = true;
 constexpr int kP2pMT = 3;            // M-tiles (16 positions) per wave
 
 template <bool OUT_CL, bool IN_NCHW>
-__global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
+__global__ __launch_bounds__(512) void conv_p2p_f16_kernel(P2pBfArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
     const int clip = blockIdx.z;
     const int y0 = blockIdx.x * a.R;
@@ -659,13 +670,11 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
     const int rows_here = a.H - y0 < a.R ? a.H - y0 : a.R;
     const int Mblk = rows_here * J;
     uint4* const pH = lds4;                                  // [R_in][Tp] positions, 16 B each
-    uint4* const pL = lds4 + R_in * Tp;
-    uint4* const pB = lds4 + 2 * R_in * Tp;                  // [14][2][64]
+    uint4* const pB = lds4 + R_in * Tp;                      // [14][2][64]
     // ---- stage: patch (both circular halos resolved) and the weight fragments ----
     {
         const long long cbase = static_cast<long long>(clip) * a.H * a.T;
         const uint4* gh = reinterpret_cast<const uint4*>(a.xh) + cbase;
-        const uint4* gl = reinterpret_cast<const uint4*>(a.xl) + cbase;
         const int npos = R_in * Tp;
         for (int i = threadIdx.x; i < npos; i += blockDim.x) {
             const int rj = i / Tp, f = i - rj * Tp;
@@ -674,24 +683,20 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
             row -= row >= a.H ? a.H : 0;
             const int t = wrap(f - 3, a.T);
             if (IN_NCHW) {
-                unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+                unsigned int hi[4] = {0, 0, 0, 0};
                 const int ru = row % a.h1;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     if (c < a.c0 + a.c1) {
                         const float v = c < a.c0 ? a.p[((static_cast<long long>(clip) * a.c0 + c) * a.H + row) * a.T + t]
                                                  : a.u[((static_cast<long long>(clip) * a.c1 + (c - a.c0)) * a.h1 + ru) * a.T + t];
-                        const unsigned int hb = bf16_bits(v);
-                        hi[c >> 1] |= hb << (16 * (c & 1));
-                        lo[c >> 1] |= bf16_bits(v - __uint_as_float(hb << 16)) << (16 * (c & 1));
+                        hi[c >> 1] |= f16_bits(v) << (16 * (c & 1));
                     }
                 }
                 pH[i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-                pL[i] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
             } else {
                 const long long g = static_cast<long long>(row) * a.T + t;
                 pH[i] = gh[g];
-                pL[i] = gl[g];
             }
         }
         if (!kP2pStreamB)
@@ -709,44 +714,35 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
         abase[mt] = r * Tp + 2 * j + q;
     }
     typedef float f32x4c __attribute__((ext_vector_type(4)));
-    f32x4c acc[MT];
+    f32x4c acc[MT], accl[MT];       // products with the hi / the (scaled) lo weight plane
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt) { acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f}; accl[mt] = f32x4c{0.f, 0.f, 0.f, 0.f}; }
     const uint4* __restrict__ bg = a.bfrag + lane;
     uint4 nbh = bg[0], nbl = bg[64];
 #pragma unroll 2
     for (int ks = 0; ks < 14; ++ks) {
         const int dy = ks >> 1, h = ks & 1;
-        bf16x8c bh, bl;
-        if (kP2pStreamB) {   // weight fragments straight from L2, one k-step ahead: 28 KB less LDS per workgroup -> 3 workgroups per CU
-            bh = __builtin_bit_cast(bf16x8c, nbh); bl = __builtin_bit_cast(bf16x8c, nbl);
+        f16x8c bh, bl;
+        if (kP2pStreamB) {   // weight fragments straight from L2, one k-step ahead: 28 KB less LDS per workgroup
+            bh = __builtin_bit_cast(f16x8c, nbh); bl = __builtin_bit_cast(f16x8c, nbl);
             const int kn = ks + 1 < 14 ? ks + 1 : ks;
             nbh = bg[(2 * kn + 0) * 64]; nbl = bg[(2 * kn + 1) * 64];
         } else {
-            bh = __builtin_bit_cast(bf16x8c, pB[(2 * ks + 0) * 64 + lane]);
-            bl = __builtin_bit_cast(bf16x8c, pB[(2 * ks + 1) * 64 + lane]);
+            bh = __builtin_bit_cast(f16x8c, pB[(2 * ks + 0) * 64 + lane]);
+            bl = __builtin_bit_cast(f16x8c, pB[(2 * ks + 1) * 64 + lane]);
         }
-        bf16x8c ah[MT], al[MT];
+        f16x8c ah[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int ad = abase[mt] + dy * Tp + 4 * h;
-            ah[mt] = __builtin_bit_cast(bf16x8c, pH[ad]);
-            al[mt] = __builtin_bit_cast(bf16x8c, pL[ad]);
-        }
+        for (int mt = 0; mt < MT; ++mt) ah[mt] = __builtin_bit_cast(f16x8c, pH[abase[mt] + dy * Tp + 4 * h]);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh, acc[mt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) accl[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, accl[mt], 0, 0, 0);
     }
-    // ---- epilogue: D[row m = 4q + i][col n = 8*tau + co]; 32-bit offsets inside the clip, hardware bf16 conversion (v_cvt_pk_bf16_f32) ----
+    // ---- epilogue: D[row m = 4q + i][col n = 8*tau + co]; 32-bit offsets inside the clip ----
     const int tau = r16 >> 3, co = r16 & 7;
     const float bias = a.bias[co];
-    typedef float f32x2e __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x2e __attribute__((ext_vector_type(2)));
     unsigned short* const oh = OUT_CL ? a.oh + static_cast<long long>(clip) * a.H * a.T * 8 + co : nullptr;
-    unsigned short* const ol = OUT_CL ? a.ol + static_cast<long long>(clip) * a.H * a.T * 8 + co : nullptr;
     float* const od = OUT_CL ? nullptr : a.dst + clip * a.dst_clip_stride + static_cast<long long>(a.dst_coff + co) * a.H * a.T;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -757,21 +753,15 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int t = 2 * j + tau;
-            const float x = acc[mt][i] + bias;
+            const float x = fmaf(accl[mt][i], kP2pLoInv, acc[mt][i]) + bias;
             v[i] = x > 0.f ? x : x * kSlope;
             pos[i] = (m0 + i < Mblk && t < a.T) ? (y0 + r) * a.T + t : -1;
             if (++j == J) { j = 0; ++r; }
         }
         if (OUT_CL) {
 #pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-                const f32x2e x = {v[i], v[i + 1]};
-                const bf16x2e h = __builtin_convertvector(x, bf16x2e);
-                const bf16x2e l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2e), bf16x2e);
-                const unsigned int hp = __builtin_bit_cast(unsigned int, h), lp = __builtin_bit_cast(unsigned int, l);
-                if (pos[i] >= 0) { oh[pos[i] * 8] = static_cast<unsigned short>(hp); ol[pos[i] * 8] = static_cast<unsigned short>(lp); }
-                if (pos[i + 1] >= 0) { oh[pos[i + 1] * 8] = static_cast<unsigned short>(hp >> 16); ol[pos[i + 1] * 8] = static_cast<unsigned short>(lp >> 16); }
-            }
+            for (int i = 0; i < 4; ++i)
+                if (pos[i] >= 0) oh[pos[i] * 8] = static_cast<unsigned short>(f16_bits(v[i]));
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -781,35 +771,33 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_kernel(P2pBfArgs a) {
 }
 
 // ==========================================================================================
-// Persistent form of conv_p2p_bf16_kernel (channels-last planes in; even frame counts).
+// Persistent form of conv_p2p_f16_kernel (channels-last f16 plane in; even frame counts).
 //
 // Measured on the kernel above (256 clips, by switching its phases off one at a time): skeleton 39 us + patch loads 40 us +
 // MFMA loop 63 us + stores 19 us = the 161 us of a launch -- the phases ADD, nothing overlaps.  All three memory phases go
 // through the CU's one vector-memory path: the weight fragments streamed from L2 (229 KB per workgroup, 5x the patch), the
 // patch, and 192 two-byte store instructions per workgroup; and a workgroup lives for 16 us, a third of it latency.
 // Here ONE workgroup per CU walks ~29 row tiles:
-//   * the 28 weight fragments (hi | lo, 14 k-steps) live in registers for the whole launch: no weight traffic in the loop;
+//   * the 28 weight fragments (hi | lo * 2^11, 14 k-steps) live in registers for the whole launch: no weight traffic in the loop;
 //   * the patch of tile k+1 is fetched by LDS-DMA (global_load_lds_dwordx4, circular halos resolved on the per-lane source
 //     address) into the other half of a double buffer while tile k is multiplied;
 //   * the epilogue transposes each 16 x 16 accumulator tile through a wave-private 1 KB LDS slab, so that a tile leaves as
-//     ONE 16-byte store per lane (32 positions x 8 channels x (hi | lo), or 8 channels x 32 consecutive frames of NCHW f32);
+//     ONE 16-byte store per lane (32 positions x 8 f16 channels, two tiles per instruction; or 8 channels x 32 consecutive frames of NCHW f32);
 //     the stores of tile k are issued after tile k+1's loads, under its MFMA loop;
 //   * tiles are dealt so that the workgroups of one XCD (blockIdx % 8) hold neighbouring row tiles: halo rows hit that L2.
 // One barrier per tile.
 // ==========================================================================================
 struct P2pPsArgs {
-    const unsigned short* xh;     // [clip][H][T][8]   (IN_NCHW == false)
-    const unsigned short* xl;
-    const float* p;               // IN_NCHW == true: the stack's input is assembled by the loader, as in conv_p2p_bf16_kernel
+    const unsigned short* xh;     // [clip][H][T][8] f16   (IN_NCHW == false)
+    const float* p;               // IN_NCHW == true: the stack's input is assembled by the loader, as in conv_p2p_f16_kernel
     const float* u;
     int c0, c1, h1;
-    const uint4* bfrag;           // [14 k-steps][hi|lo][64 lanes] x 8 bf16
+    const uint4* bfrag;           // [14 k-steps][hi|lo * 2^11][64 lanes] x 8 f16
     const float* bias;            // [8]
     float* dst;                   // OUT == 0: NCHW f32 [clip][dst_ctot][H][T];  OUT == 2: semitone maps [clip][8][H / 3][T]
     long long dst_clip_stride;
-    unsigned short* oh;           // OUT == 1: channels-last planes
-    unsigned short* ol;
-    const uint4* sfrag;           // OUT == 2: B fragments of the semitone conv [3 dy][hi|lo][64 lanes] x 8 bf16, and its bias [8]
+    unsigned short* oh;           // OUT == 1: channels-last f16 plane
+    const uint4* sfrag;           // OUT == 2: B fragments of the semitone conv [3 dy][hi|lo * 2^11][64 lanes] x 8 f16, and its bias [8]
     const float* sbias;
     int H, T, R, J, Tp, n_row_tiles, n_tiles, plane_pos;   // plane_pos: (R + 6) * Tp rounded up to 64 positions
     unsigned long long* stamps;   // diagnostic build (AKE_P2P_STAMP): [8 waves][8] cycle sums of the tile loop's sections, workgroup 0
@@ -823,15 +811,15 @@ __device__ __forceinline__ unsigned long long p2p_stamp() {
 
 constexpr int kP2pPsStage = 80;      // uint4 per M-tile of a wave's staging slab (NCHW form: 8 channels x 36 floats, padded)
 
-// OUT: 0 = NCHW f32, 1 = channels-last split planes (next conv of the stack), 2 = the stack's last conv FUSED with the semitone conv
+// OUT: 0 = NCHW f32, 1 = channels-last f16 plane (next conv of the stack), 2 = the stack's last conv FUSED with the semitone conv
 //   that follows it (3x3, stride (3,1), time circular + BN + LeakyReLU; models.py:337-339, 386-388): the activated tile (R = 3k rows)
-//   stays in LDS as split planes [plane][m][tau][8 ch] = position-major, the semitone conv runs over it on the same MFMA form
+//   stays in LDS as an f16 plane [m][tau][8 ch] = position-major, the semitone conv runs over it on the same MFMA form
 //   (m = (semitone row, frame pair), n = (tau, co), k-step = one of its 3 rows: 4 positions x 8 channels, the 4th tap zero), one
 //   M-tile per wave, and only the semitone maps [clip][8][H / 3][T] go to memory: the 8 x H x T pitch tensor is never written.
-// NIN: 0 = channels-last split planes in; else the number of f32 channels the loader assembles (5: default net, 8: any)
+// NIN: 0 = channels-last f16 plane in; else the number of f32 channels the loader assembles (5: default net, 8: any)
 // STAMP: diagnostic build with s_memtime stamps around the tile loop's sections (tools/p2p_stamp.py; shares, never timed)
 template <int OUT, int NIN, bool STAMP = false>
-__global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
+__global__ __launch_bounds__(512) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {
     constexpr bool OUT_CL = OUT == 1, OUT_SEMI = OUT == 2;
     constexpr bool IN_NCHW = NIN > 0;
     constexpr int NV = IN_NCHW ? NIN : 1;
@@ -846,13 +834,12 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
     // tiles of this workgroup: first, first + gridDim.x, ...; workgroups of one XCD take neighbouring tiles
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     const int first = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    // ---- loader: the pieces c = wave, wave + 8, ... of [plane][piece]; lane -> patch position -> (row offset, frame) ----
+    // ---- loader: the pieces c = wave, wave + 8, ... of the plane; lane -> patch position -> (row offset, frame) ----
     int pk[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const int c = wave + 8 * k;
-        const int ci = c >= nchunk ? c - nchunk : c;
-        int i = ci * 64 + lane;
+        int i = c * 64 + lane;
         i = i < npos ? i : npos - 1;
         const int rj = i / Tp, f = i - rj * Tp;
         pk[k] = (rj << 16) | wrap(f - 3, T);
@@ -864,13 +851,12 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const int c = wave + 8 * k;
-            if (c < 2 * nchunk) {
-                const bool lo = c >= nchunk;
+            if (c < nchunk) {
                 int row = y0 - 3 + (pk[k] >> 16);
                 row += row < 0 ? a.H : 0;
                 row -= row >= a.H ? a.H : 0;
-                const uint4* src = reinterpret_cast<const uint4*>(lo ? a.xl : a.xh) + cbase + static_cast<long long>(row) * T + (pk[k] & 0xffff);
-                uint4* dstl = lds4 + (buf * 2 + (lo ? 1 : 0)) * a.plane_pos + (lo ? c - nchunk : c) * 64;
+                const uint4* src = reinterpret_cast<const uint4*>(a.xh) + cbase + static_cast<long long>(row) * T + (pk[k] & 0xffff);
+                uint4* dstl = lds4 + buf * a.plane_pos + c * 64;
                 // inline asm: hipcc orders every later LDS access behind a builtin LDS-DMA with vmcnt(0) (it cannot tell the two buffer
                 // halves apart), which would serialise load and multiply; the wait is placed by hand before the barrier instead
                 const unsigned int lds_dst = static_cast<unsigned int>(reinterpret_cast<unsigned long long>(dstl));   // LDS aperture: low 32 bits = LDS byte address
@@ -880,7 +866,7 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
             }
         }
     };
-    // IN_NCHW: f32 planes -> registers (requested before the multiply loop) -> split-bf16 channels-last patch (written after it);
+    // IN_NCHW: f32 planes -> registers (requested before the multiply loop) -> f16 channels-last patch (written after it);
     // thread -> the patch positions threadIdx.x, + 512, + 1024
     float vin[3][NV];
     int pn[3];
@@ -914,27 +900,19 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
         }
     };
     auto write_lds = [&](int buf) {
-        uint4* const wH = lds4 + (buf * 2) * a.plane_pos;
-        uint4* const wL = wH + a.plane_pos;
+        uint4* const wH = lds4 + buf * a.plane_pos;
         const int ctot = a.c0 + a.c1;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+            unsigned int hi[4] = {0, 0, 0, 0};
             typedef float f32x2w __attribute__((ext_vector_type(2)));
-            typedef __bf16 bf16x2w __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int c = 0; c < NV; c += 2) {   // hardware conversion (v_cvt_pk_bf16_f32, round to nearest even as bf16_bits), two channels at a time
+            for (int c = 0; c < NV; c += 2) {   // round to nearest even, two channels at a time
                 const f32x2w v = {c < ctot ? vin[k][c] : 0.f, (c + 1 < NV && c + 1 < ctot) ? vin[k][c + 1 < NV ? c + 1 : c] : 0.f};
-                const bf16x2w h = __builtin_convertvector(v, bf16x2w);
-                const bf16x2w l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2w), bf16x2w);
-                hi[c >> 1] = __builtin_bit_cast(unsigned int, h);
-                lo[c >> 1] = __builtin_bit_cast(unsigned int, l);
+                hi[c >> 1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2c));
             }
             const int i = threadIdx.x + 512 * k;
-            if (i < npos) {
-                wH[i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-                wL[i] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-            }
+            if (i < npos) wH[i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
         }
     };
     if (first < a.n_tiles) {
@@ -955,28 +933,30 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
     }
     const int tau = r16 >> 3, co = r16 & 7;
     const float bias = a.bias[co];
-    uint4* const stage = lds4 + 4 * a.plane_pos + wave * (MT * kP2pPsStage);          // OUT 0 / 1: wave-private slabs
-    uint4* const opatch = lds4 + 4 * a.plane_pos;                                      // OUT 2: [2 buffers][hi|lo][384 m][2 tau] positions
-    constexpr int kOP = 8 * MT * 16 * 2;                                               // positions per plane of the output patch
+    uint4* const stage = lds4 + 2 * a.plane_pos + wave * (MT * kP2pPsStage);          // OUT 0 / 1: wave-private slabs
+    uint4* const opatch = lds4 + 2 * a.plane_pos;                                      // OUT 2: [2 buffers][384 m][2 tau] positions
+    constexpr int kOP = 8 * MT * 16 * 2;                                               // positions of one output patch
     typedef float f32x2e __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x2e __attribute__((ext_vector_type(2)));
     long long prev_base = 0;          // element offset of the pending tile's first position (channels-last: position index)
     int prev_mblk = 0;
     bool has_prev = false;
     auto store_pending = [&]() {      // the finished tile waits in the staging slab (not in registers: the multiply loop needs them all)
+        if (OUT_CL) {       // lane = (M-tile of a pair, m, tau): position 2 * (mbase + m) + tau of the tile, 8 channels = 16 bytes
+            static_assert(MT == 3, "the M-tiles leave as one pair and a single");
+            const uint4 o01 = stage[(lane >> 5) * kP2pPsStage + (lane & 31)], o2 = stage[2 * kP2pPsStage + (lane & 31)];
+            const int mb01 = (wave * MT + (lane >> 5)) * 16, mb2 = (wave * MT + 2) * 16, ml = (lane >> 1) & 15;
+            uint4* const o = reinterpret_cast<uint4*>(a.oh) + prev_base + (lane & 31);
+            if (mb01 + ml < prev_mblk) o[2 * mb01] = o01;
+            if (lane < 32 && mb2 + ml < prev_mblk) o[2 * mb2] = o2;
+            return;
+        }
         uint4 outv[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) outv[mt] = OUT_CL ? stage[mt * kP2pPsStage + lane] : stage[mt * kP2pPsStage + (lane >> 3) * 9 + (lane & 7)];
+        for (int mt = 0; mt < MT; ++mt) outv[mt] = stage[mt * kP2pPsStage + (lane >> 3) * 9 + (lane & 7)];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int mbase = (wave * MT + mt) * 16;
-            if (OUT_CL) {   // lane = (plane, m, tau): position 2 * (mbase + m) + tau of the tile, 8 channels = 16 bytes
-                const int m = mbase + ((lane >> 1) & 15);
-                if (m < prev_mblk) {
-                    uint4* o = reinterpret_cast<uint4*>(lane < 32 ? a.oh : a.ol) + prev_base + 2 * mbase + (lane & 31);
-                    *o = outv[mt];
-                }
-            } else {        // lane = (channel, group of 4 frames)
+            {               // lane = (channel, group of 4 frames)
                 const int m = mbase + 2 * (lane & 7);
                 float* o = a.dst + prev_base + static_cast<long long>(lane >> 3) * a.H * T + 2 * m;
                 if (m + 1 < prev_mblk) *reinterpret_cast<uint4*>(o) = outv[mt];
@@ -986,13 +966,13 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
     };
     // bias + LeakyReLU, transposed into the wave's staging slab
     typedef float f32x4c __attribute__((ext_vector_type(4)));
-    auto epilogue = [&](const f32x4c (&acc)[MT], int obuf) {
+    auto epilogue = [&](const f32x4c (&acc)[MT], const f32x4c (&accl)[MT], int obuf) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float x = acc[mt][i] + bias;
+                const float x = fmaf(accl[mt][i], kP2pLoInv, acc[mt][i]) + bias;
                 v[i] = x > 0.f ? x : x * kSlope;
             }
             if (OUT_CL || OUT_SEMI) {
@@ -1004,19 +984,13 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
                 const float m0 = odd ? v[2] : v[0], m1 = odd ? v[3] : v[1];
                 const f32x2e xa = {odd ? g0 : m0, odd ? m0 : g0};       // (even channel, odd channel) of row ma
                 const f32x2e xb = {odd ? g1 : m1, odd ? m1 : g1};       // ... of row ma + 1
-                const bf16x2e ha = __builtin_convertvector(xa, bf16x2e), hb = __builtin_convertvector(xb, bf16x2e);
-                const bf16x2e la = __builtin_convertvector(xa - __builtin_convertvector(ha, f32x2e), bf16x2e);
-                const bf16x2e lb = __builtin_convertvector(xb - __builtin_convertvector(hb, f32x2e), bf16x2e);
                 // OUT 1: the M-tile's own slab; OUT 2: the tile-wide patch, m counted over the tile (= position 2m + tau: T = 2J)
-                unsigned int* st = OUT_SEMI ? reinterpret_cast<unsigned int*>(opatch + obuf * 2 * kOP) + (wave * MT + mt) * 128
+                unsigned int* st = OUT_SEMI ? reinterpret_cast<unsigned int*>(opatch + obuf * kOP) + (wave * MT + mt) * 128
                                             : reinterpret_cast<unsigned int*>(stage + mt * kP2pPsStage);
-                constexpr int lo_plane = OUT_SEMI ? kOP * 4 : 128;       // dwords from the hi plane to the lo plane
                 const int ma = 4 * q + (odd ? 2 : 0);
-                const int d = ma * 8 + tau * 4 + (co >> 1);              // [plane][m][tau][co / 2] dwords
-                st[d] = __builtin_bit_cast(unsigned int, ha);
-                st[d + 8] = __builtin_bit_cast(unsigned int, hb);
-                st[lo_plane + d] = __builtin_bit_cast(unsigned int, la);
-                st[lo_plane + d + 8] = __builtin_bit_cast(unsigned int, lb);
+                const int d = ma * 8 + tau * 4 + (co >> 1);              // [m][tau][co / 2] dwords
+                st[d] = __builtin_bit_cast(unsigned int, __builtin_convertvector(xa, f16x2c));
+                st[d + 8] = __builtin_bit_cast(unsigned int, __builtin_convertvector(xb, f16x2c));
             } else {
                 float* st = reinterpret_cast<float*>(stage + mt * kP2pPsStage);
 #pragma unroll
@@ -1038,23 +1012,21 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
         sbase = 3 * srow * T + wrap(2 * sj - 1 + q, T);               // A[m][k = (position q, ci)] = X[3s + dy][2j - 1 + q][ci]
     }
     auto semi_stage = [&](int obuf, long long base, int mblk) {      // base: element offset of (clip, channel 0, first semitone row) in dst
-        const uint4* const oH = opatch + obuf * 2 * kOP;
-        const uint4* const oL = oH + kOP;
-        f32x4c sacc = {0.f, 0.f, 0.f, 0.f};
+        const uint4* const oH = opatch + obuf * kOP;
+        f32x4c sacc = {0.f, 0.f, 0.f, 0.f}, saccl = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-            const bf16x8c ah = __builtin_bit_cast(bf16x8c, oH[sbase + dy * T]), al = __builtin_bit_cast(bf16x8c, oL[sbase + dy * T]);
-            const bf16x8c bh = __builtin_bit_cast(bf16x8c, sreg[2 * dy]), bl = __builtin_bit_cast(bf16x8c, sreg[2 * dy + 1]);
-            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, sacc, 0, 0, 0);
+            const f16x8c ah = __builtin_bit_cast(f16x8c, oH[sbase + dy * T]);
+            const f16x8c bh = __builtin_bit_cast(f16x8c, sreg[2 * dy]), bl = __builtin_bit_cast(f16x8c, sreg[2 * dy + 1]);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, sacc, 0, 0, 0);
+            saccl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, saccl, 0, 0, 0);
         }
         const int S = a.H / 3;
         float* const o = a.dst + base + static_cast<long long>(co) * S * T + tau;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                                 // D[m = 4q + i][n = (tau, co)]: semitone position 2m + tau of the tile
             const int m = wave * 16 + 4 * q + i;
-            const float x = sacc[i] + sbias;
+            const float x = fmaf(saccl[i], kP2pLoInv, sacc[i]) + sbias;
             if (3 * m < mblk) o[2 * m] = x > 0.f ? x : x * kSlope;
         }
     };
@@ -1062,9 +1034,9 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
     // half, so one half's epilogue, loads and stores issue under the other half's MFMAs instead of all eight waves leaving the
     // matrix pipe idle together
     const bool late = !OUT_SEMI && wave >= 4;
-    f32x4c acc[MT];
+    f32x4c acc[MT], accl[MT];       // products with the hi / the (scaled) lo weight plane
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt) { acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f}; accl[mt] = f32x4c{0.f, 0.f, 0.f, 0.f}; }
     int cur = 0;
     unsigned long long sm[6] = {0, 0, 0, 0, 0, 0}, ts[6];
     for (int tile = first; tile < a.n_tiles; tile += nwg, cur ^= 1) {
@@ -1078,13 +1050,12 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
         const bool more = tile + nwg < a.n_tiles;
         if (has_prev) {
             if (OUT_SEMI) semi_stage(cur ^ 1, prev_base, prev_mblk);
-            else if (late) epilogue(acc, 0);
+            else if (late) epilogue(acc, accl, 0);
         }
-        const uint4* const pH = lds4 + (cur * 2) * a.plane_pos;
-        const uint4* const pL = pH + a.plane_pos;
+        const uint4* const pH = lds4 + cur * a.plane_pos;
         if (STAMP) ts[3] = p2p_stamp();
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt) { acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f}; accl[mt] = f32x4c{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < 14; ++ks) {
             // the next tile's loads and the previous tile's stores are issued from inside the multiply loop rather than in front of it,
@@ -1096,23 +1067,17 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
             }
             if (ks == 6 && !OUT_SEMI && has_prev) store_pending();
             const int dy = ks >> 1, h = ks & 1;
-            const bf16x8c bh = __builtin_bit_cast(bf16x8c, breg[2 * ks]), bl = __builtin_bit_cast(bf16x8c, breg[2 * ks + 1]);
-            bf16x8c ah[MT], al[MT];
+            const f16x8c bh = __builtin_bit_cast(f16x8c, breg[2 * ks]), bl = __builtin_bit_cast(f16x8c, breg[2 * ks + 1]);
+            f16x8c ah[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int ad = abase[mt] + dy * Tp + 4 * h;
-                ah[mt] = __builtin_bit_cast(bf16x8c, pH[ad]);
-                al[mt] = __builtin_bit_cast(bf16x8c, pL[ad]);
-            }
+            for (int mt = 0; mt < MT; ++mt) ah[mt] = __builtin_bit_cast(f16x8c, pH[abase[mt] + dy * Tp + 4 * h]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh, acc[mt], 0, 0, 0);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) accl[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, accl[mt], 0, 0, 0);
         }
         if (STAMP) ts[4] = p2p_stamp();
-        if (!late) epilogue(acc, cur);
+        if (!late) epilogue(acc, accl, cur);
         if (IN_NCHW && more) write_lds(cur ^ 1);
         {
             const int clip = tile / a.n_row_tiles;
@@ -1140,7 +1105,7 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
             __syncthreads();          // every wave's share of the last tile is in the output patch
             semi_stage(cur ^ 1, prev_base, prev_mblk);
         } else {
-            if (late) epilogue(acc, 0);
+            if (late) epilogue(acc, accl, 0);
             store_pending();
         }
     }
@@ -1149,7 +1114,7 @@ __global__ __launch_bounds__(512) void conv_p2p_bf16_ps_kernel(P2pPsArgs a) {
 // ==========================================================================================
 // Equivariant pitch-class convolution (12 x 7 kernel, rows circular over the 12 pitch classes, time zero-padded or valid;
 // models.py:36-47) on bf16 MFMA with split operands -- the PitchClass2PitchClass stacks and the first convolution of the
-// key / tonic heads.  Same idea as conv_p2p_bf16_kernel: channels-last activations [clip][12][T][16] as bf16 hi / lo planes,
+// key / tonic heads.  Same idea as conv_p2p_f16_kernel: channels-last activations [clip][12][T][16] as bf16 hi / lo planes,
 //   m = (pitch class y, frame t)       A[m][k] = X[(y + dy) mod 12][t + dx - pad][ci]
 //   n = output channel (NT tiles of 16)  B[k][n] = w[co][ci][dy][dx]
 //   k-step = (dy, tap pair p): lane q holds tap dx = 2p + (q >> 1), channels 8 (q & 1) .. +7   -> 12 x 4 = 48 k-steps (dx = 7 is
@@ -1701,7 +1666,7 @@ __global__ void nchw_to_cl16_kernel(const float* __restrict__ src, long long src
     ol[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]); ol[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
 }
 
-// debug taps: channels-last split planes [clip][H][T][C] -> NCHW f32 [clip][C][H][T]
+// debug taps: channels-last split-bf16 planes (xl != null) or one f16 plane (xl == null) [clip][H][T][C] -> NCHW f32 [clip][C][H][T]
 __global__ void cl_to_nchw_kernel(const unsigned short* __restrict__ xh, const unsigned short* __restrict__ xl, float* __restrict__ out, int C, int H,
                                   int T, long long total) {
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1713,13 +1678,14 @@ __global__ void cl_to_nchw_kernel(const unsigned short* __restrict__ xh, const u
     const int c = static_cast<int>(r % C);
     const long long clip = r / C;
     const long long src = ((clip * H + y) * T + t) * C + c;
-    out[i] = __uint_as_float(static_cast<unsigned int>(xh[src]) << 16) + __uint_as_float(static_cast<unsigned int>(xl[src]) << 16);
+    out[i] = xl ? __uint_as_float(static_cast<unsigned int>(xh[src]) << 16) + __uint_as_float(static_cast<unsigned int>(xl[src]) << 16)
+                : static_cast<float>(__builtin_bit_cast(_Float16, xh[src]));
 }
 
-// B fragments of conv_p2p_bf16_kernel from the VALU-layout eval pack [ci < cin][dy][dx][8 co] (BatchNorm already folded; input
-// channels >= cin get zero weights):
+// B fragments of conv_p2p_f16_kernel from the VALU-layout eval pack [ci < cin][dy][dx][8 co] (BatchNorm already folded; input
+// channels >= cin get zero weights): f16 hi = rn(w), f16 lo = rn((w - hi) * 2^11);
 // one thread per (k-step, lane, element).
-__global__ void pack_p2p_bf16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin) {
+__global__ void pack_p2p_f16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (ks, lane)
     if (i >= 14 * 64) return;
     const int ks = i / 64, lane = i - ks * 64;
@@ -1731,8 +1697,9 @@ __global__ void pack_p2p_bf16_kernel(const float* __restrict__ w, uint4* __restr
     for (int ci = 0; ci < 8; ++ci) {
         float v = 0.f;
         if (dx >= 0 && dx < 7 && ci < cin) v = w[((ci * 7 + dy) * 7 + dx) * 8 + co];
-        const unsigned int hb = bf16_bits(v);
-        const unsigned int lb = bf16_bits(v - __uint_as_float(hb << 16));
+        const _Float16 hv = static_cast<_Float16>(v);
+        const unsigned int hb = __builtin_bit_cast(unsigned short, hv);
+        const unsigned int lb = f16_bits((v - static_cast<float>(hv)) * kP2pLoScale);
         hi[ci >> 1] |= hb << (16 * (ci & 1));
         lo[ci >> 1] |= lb << (16 * (ci & 1));
     }
@@ -1740,9 +1707,9 @@ __global__ void pack_p2p_bf16_kernel(const float* __restrict__ w, uint4* __restr
     out[(2 * ks + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
-// B fragments of the semitone conv fused into conv_p2p_bf16_ps_kernel<2, ...>, from its eval pack [ci < 8][3 dy][3 dx][8 co]:
+// B fragments of the semitone conv fused into conv_p2p_f16_ps_kernel<2, ...>, from its eval pack [ci < 8][3 dy][3 dx][8 co]:
 // k-step = dy, k = (position qq, ci), n = (tau, co), tap dx = qq - tau (the 4th position of either frame carries zero weights)
-__global__ void pack_semi_bf16_kernel(const float* __restrict__ w, uint4* __restrict__ out) {
+__global__ void pack_semi_f16_kernel(const float* __restrict__ w, uint4* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (dy, lane)
     if (i >= 3 * 64) return;
     const int dy = i / 64, lane = i - dy * 64;
@@ -1753,8 +1720,9 @@ __global__ void pack_semi_bf16_kernel(const float* __restrict__ w, uint4* __rest
     for (int ci = 0; ci < 8; ++ci) {
         float v = 0.f;
         if (dx >= 0 && dx < 3) v = w[((ci * 3 + dy) * 3 + dx) * 8 + co];
-        const unsigned int hb = bf16_bits(v);
-        const unsigned int lb = bf16_bits(v - __uint_as_float(hb << 16));
+        const _Float16 hv = static_cast<_Float16>(v);
+        const unsigned int hb = __builtin_bit_cast(unsigned short, hv);
+        const unsigned int lb = f16_bits((v - static_cast<float>(hv)) * kP2pLoScale);
         hi[ci >> 1] |= hb << (16 * (ci & 1));
         lo[ci >> 1] |= lb << (16 * (ci & 1));
     }
@@ -1964,7 +1932,7 @@ __global__ void local_pool_kernel(LocalPoolArgs a) {
 // ---- the same launch with the convolution stack on bf16 MFMA (split operands) ------------------------------------------------
 // The VALU form above spends 2.9 M FMAs per clip at the vector rate (0.07 ms per 256 clips, the kernel is VALU-bound).  Here the
 // maps live in LDS as channels-last split planes [12 rows][T + 8 positions][4 ch] (8 bytes per position and plane, 3 zero positions
-// either side = the convs' zero padding), and a conv is the MFMA form of conv_p2p_bf16_kernel with 4 channels:
+// either side = the convs' zero padding), and a conv is the MFMA form of conv_p2p_f16_kernel with 4 channels:
 //   m = (pitch class p, frame pair j)     A[m][k = (position q', ci)] = X[(p + dy) mod 12][2j + q'][ci]    (8 positions x 4 channels = 32)
 //   n = (tau, co) = 4 * tau + co < 8      B[k][n] = w[co][ci][dy][q' - tau]                                  (columns 8..15 idle)
 //   k-step = dy: 12 steps x 3 MFMAs per 16 x 16 tile, ~29 tiles per clip.

@@ -10,7 +10,7 @@ owns 256 clips of its own (weak scaling, clips are independent, no data-path col
 step time is the max over ranks.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line (tier contract):
-  roofline      dominant kernel (conv_p2p_bf16_kernel: the 7x7 circular pitch convolutions, 65 % of
+  roofline      dominant kernel (conv_p2p_f16_kernel: the 7x7 circular pitch convolutions, 65 % of
                 the MACs): algorithmic FLOPs (2 x MACs) of its launches / their hipEvent-measured
                 duration, vs the 2.5 PFLOP/s dense bf16 MFMA peak of MI355X; the kernel multiplies
                 split-bf16 operands (3 MFMA products per MAC), so `frac_of_split_ceiling` = 3 x frac
@@ -348,7 +348,7 @@ def main():
     torch.cuda.synchronize()
     # timed region: hipEvents (on the launch stream) bracket only the dominant kernel -- 3 launches per step
     ake_amd._lib.lib().ake_prof_reset()
-    ake_amd._lib.prof_enable("conv_p2p_bf16_kernel", True)
+    ake_amd._lib.prof_enable("conv_p2p_f16_kernel", True)
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -391,7 +391,7 @@ def main():
     if args.sustained_seconds > 0:
         n_sus = max(args.steps, int(args.sustained_seconds / (dt / args.steps) * 1.1) + 1)
         ake_amd._lib.lib().ake_prof_reset()
-        ake_amd._lib.prof_enable("conv_p2p_bf16_kernel", True)
+        ake_amd._lib.prof_enable("conv_p2p_f16_kernel", True)
         D.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -402,7 +402,7 @@ def main():
         dt_sus = D.max_over_ranks(time.perf_counter() - t0, dev)
         prof_sus = ake_amd._lib.prof_results()
         ake_amd._lib.prof_enable("", False)
-        s_ms, s_n = prof_sus.get("conv_p2p_bf16_kernel", (0.0, 0))
+        s_ms, s_n = prof_sus.get("conv_p2p_f16_kernel", (0.0, 0))
         s_tf = 2.0 * P2P_MACS_PER_CLIP * B * n_sus / (s_ms * 1e-3) / 1e12 if s_ms > 0 else None
         sustained = {"seconds": round(dt_sus, 3), "steps": n_sus, "distinct_batches": R, "resident_audio_bytes": R * B * N_SAMPLES * 4,
                      "value": round(B * world * n_sus / dt_sus, 1), "unit": "clips/s", "ms_per_step": round(dt_sus / n_sus * 1e3, 4),
@@ -422,27 +422,28 @@ def main():
 
     clips = B * world * args.steps
     value = clips / dt
-    # dominant kernel: the three 7x7 pitch convolutions (65 % of the network's MACs), conv_p2p_bf16_kernel
-    p2p_ms, p2p_n = prof.get("conv_p2p_bf16_kernel", (0.0, 0))
+    # dominant kernel: the three 7x7 pitch convolutions (65 % of the network's MACs), conv_p2p_f16_kernel
+    p2p_ms, p2p_n = prof.get("conv_p2p_f16_kernel", (0.0, 0))
     launches_per_step = p2p_n / args.steps if args.steps else 0
     p2p_flops = 2.0 * P2P_MACS_PER_CLIP * B * args.steps              # algorithmic: (5*8 + 8*8 + 8*8) * 49 MACs per position
     achieved = p2p_flops / (p2p_ms * 1e-3) / 1e12 if p2p_ms > 0 else None
     cqt_ms = sum(prof_all.get(k, (0.0, 0))[0] for k in prof_all if k.startswith("cqt_"))
     cqt_gbs = CQT_BYTES_PER_CLIP * B * args.steps / (cqt_ms * 1e-3) / 1e9 if cqt_ms > 0 else None
     kernel_ms = {k: round(v[0] / args.steps, 4) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}
-    p2p1_ms, p2p1_n = prof_all.get("conv_p2p_bf16_kernel", (0.0, 0))
+    p2p1_ms, p2p1_n = prof_all.get("conv_p2p_f16_kernel", (0.0, 0))
     achieved1 = p2p_flops / (p2p1_ms * 1e-3) / 1e12 if p2p1_ms > 0 else None
     traffic_src, traffic, traffic_stale = pmc_traffic()
     p2p_traffic = cqt_traffic = None
     if B == 256 and traffic:
-        bf_rows = [v for k, v in traffic.items() if k.startswith("conv_p2p_bf16")]
+        bf_rows = [v for k, v in traffic.items() if k.startswith("conv_p2p_f16")]
         p2p_traffic = round(sum(v["hbm_bytes"] * v["dispatches"] for v in bf_rows) / max(1, sum(v["dispatches"] for v in bf_rows))) if bf_rows else None
         cqt_traffic = sum(v["hbm_bytes"] for k, v in traffic.items() if k.startswith("cqt_")) or None
     line = {
         "metric": "clips/s (15 s @ 22.05 kHz), HIP CQT + PitchClassNet forward",
         "value": round(value, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 storage and accumulation; the pitch / pitch-class convolutions and the CQT filter bank multiply as 3-term split-bf16 on MFMA (hi*hi + lo*hi + hi*lo, ~1e-5 relative to f32)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 accumulation everywhere; pitch convolutions: f16 activations x (f16 hi + f16 lo) weights on MFMA (2 products, weights exact to 2^-22); "
+                                     "pitch-class convolutions, heads and the CQT filter bank: 3-term split-bf16 on MFMA (hi*hi + lo*hi + hi*lo); outputs ~1e-5 of the float64 oracle", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: batch={B} synthetic 15 s sine-mix clips per GPU, HIP CQT (288 bins, hop 4410) "
                                f"+ default PitchClassNet inference (genre head on), audio resident in HBM",
                    "clips_per_gpu": B, "n_samples": N_SAMPLES, "frames": T_FRAMES, "weights": "tests/golden/pcnet_default.npz (seeded)",
@@ -452,13 +453,13 @@ def main():
                    "steps_in_flight": f"{args.streams}: every step is the whole path over one batch; consecutive steps go round-robin to "
                                       f"{args.streams} streams with a workspace each (KeyEstimator(streams=...))" if args.streams > 1 else "1"},
         "roofline": {"bound": "mfma",
-                     "kernel": "conv_p2p_bf16_ps_kernel (persistent 7x7 circular pitch convolution, 8 channels, split-bf16 operands on "
-                               "v_mfma_f32_16x16x32_bf16 with f32 accumulation: 3 MFMA products per algorithmic MAC), 3 launches per step; the third "
+                     "kernel": "conv_p2p_f16_ps_kernel (persistent 7x7 circular pitch convolution, 8 channels, f16 activations x (f16 hi + f16 lo) weights on "
+                               "v_mfma_f32_16x16x32_f16 with f32 accumulation: 2 MFMA products per algorithmic MAC), 3 launches per step; the third "
                                "also runs the semitone conv on its output tile and writes only the semitone maps",
                      "achieved": round(achieved, 2) if achieved else None, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_BF16_TFLOPS, 4) if achieved else None,
-                     "mfma_products_per_mac": 3,
-                     "frac_of_split_ceiling": round(3 * achieved / PEAK_BF16_TFLOPS, 4) if achieved else None,
+                     "mfma_products_per_mac": 2,
+                     "frac_of_split_ceiling": round(2 * achieved / PEAK_BF16_TFLOPS, 4) if achieved else None,
                      "traffic": p2p_traffic,
                      "traffic_source": f"profiles/{traffic_src}: mean HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE" if p2p_traffic else traffic_stale,
                      # mean over the three launches: (1 CQT + 4 x 36-row up_sixth channels -> 8 channels), (8 -> 8), (8 -> 8 semitone channels of P / 3 rows)

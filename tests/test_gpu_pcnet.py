@@ -71,7 +71,8 @@ def test_every_layer_against_reference_taps(gold_default, gold_taps):
     try:
         outs = net(x, torch.from_numpy(gold_taps["seq_length"]).to(DEV))
         _check_taps(net, outs, gold_taps)
-        assert rel_err(fused_cat.cpu(), net.tap("model.1.cat").cpu()) < 2e-5
+        # (the fused launch hands the semitone conv the last pitch conv's output as f16, the unfused one as f32: one more rounding unit)
+        assert rel_err(fused_cat.cpu(), net.tap("model.1.cat").cpu()) < 8e-4
     finally:
         net.keep_taps(was)
 
@@ -87,12 +88,19 @@ def _check_taps(net, outs, gold_taps):
         got = net.tap(name).cpu().numpy()
         ref = gold_taps["tap/" + name]
         assert got.shape == ref.shape, name
-        assert rel_err(got, ref) < TOL, name
+        # the pitch convs multiply ONE f16 value per activation (2^-11 = 4.9e-4 relative rounding at the worst element, unbiased; see
+        # conv_p2p_f16_kernel): inside the pitch stack single elements are off by that much; after the octave max and the
+        # pitch-class stack the taps are back under TOL, and the outputs are held to TOL like everything else
+        assert rel_err(got, ref) < (6e-4 if name.startswith("model.1.p2p.layer.") else TOL), name
     with pytest.raises(ake_amd._lib.AkeError, match="not a materialised"):
         net.tap("model.1.p2p.layer.2")
     cat = net.tap("model.1.cat").cpu().numpy()                    # [pc | pc2] concat, models.py:392
     assert rel_err(cat[:, :4], gold_taps["tap/model.0.pc2pc.layer.8"]) < TOL
-    assert rel_err(cat[:, 4:], gold_taps["tap/model.1.pool"]) < TOL
+    pool_ref = gold_taps["tap/model.1.pool"]                      # semitone conv + octave max of the f16 pitch stack: see above
+    assert rel_err(cat[:, 4:], pool_ref) < 6e-4
+    # (rms error / rms value = 2.5e-4 here: one f16 rounding unit, 2^-12 -- these sums cancel, they do not average; the averaging that
+    # brings the outputs to 1e-5 happens in the 1344-term pitch-class convolutions and the temporal mean behind this tap)
+    assert float(np.sqrt(np.mean((cat[:, 4:] - pool_ref) ** 2)) / np.sqrt(np.mean(pool_ref ** 2))) < 4e-4
 
 
 def test_guard_octave_equivariance_all_12_shifts(gold_guard):
@@ -206,8 +214,8 @@ def test_batch_larger_than_the_pitch_stream_chunk(gold_default):
 
 @pytest.mark.parametrize("B,T", [(24, 76), (40, 52), (64, 30), (20, 120)])
 def test_persistent_pitch_conv_equals_per_tile_kernel_and_oracle(gold_default, B, T):
-    """Batches with >= 2 row tiles per CU run the 8 -> 8 pitch convolutions as ONE persistent launch (conv_p2p_bf16_ps_kernel: LDS-DMA
-    double buffer, weights in registers, staged 16-byte stores); smaller batches take conv_p2p_bf16_kernel (one workgroup per tile).
+    """Batches with >= 2 row tiles per CU run the 8 -> 8 pitch convolutions as ONE persistent launch (conv_p2p_f16_ps_kernel: LDS-DMA
+    double buffer, weights in registers, staged 16-byte stores); smaller batches take conv_p2p_f16_kernel (one workgroup per tile).
     Same arithmetic in the same order => bit-identical outputs; partial last row tiles (288 = 20 x 14 + 8 at T = 52) and tile
     counts that do not divide by the grid are covered by the shapes.  Three clips are also held against the oracle."""
     net, _ = make_net(gold_default)
@@ -246,8 +254,11 @@ def test_local_heads_against_reference_fixture(gold_default, gold_local):
         assert a.shape == b.shape and rel_err(a.cpu(), b) < TOL
     with pytest.raises(ake_amd._lib.AkeError, match="pooling window"):
         net(torch.zeros(1, 1, 288, 40, device=DEV), None)
-    with pytest.raises(NotImplementedError):
-        net.train()(x, None)
+    # training mode: the same per-frame shapes, BatchNorm on the batch statistics (gradients: test_gpu_backward.test_local_net_gradients)
+    tr = net.train()(x, None)
+    ref_tr = pcnet_oracle.pcnet_forward(golden_state_dict(gold_default, torch.float64), x.cpu().double(), None, training=True, local_window=38)
+    for a, b in zip(tr, ref_tr):
+        assert a.shape == b.shape and rel_err(a.detach().cpu(), b) < TOL
 
 
 def test_resblock_against_reference_fixture(gold_resblock):
