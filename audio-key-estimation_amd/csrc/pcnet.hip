@@ -31,7 +31,7 @@ namespace {
 
 constexpr double kBnEps = 1e-5;          // nn.BatchNorm2d default
 constexpr size_t kLdsBudget = 64 * 1024; // dynamic LDS per workgroup we allow ourselves
-constexpr size_t kBfFragsPerConv = 14 * 2 * 64;   // uint4 entries of split-bf16 weight fragments per 8->8 pitch convolution
+constexpr size_t kBfFragsPerConv = 14 * 2 * 64 + 64;   // uint4 entries per 8->8 pitch convolution: f16 weight fragments [14 k-steps][hi|lo][64 lanes], then the 8 inverse channel scales
 
 struct TensorSpec {
     std::string name;
@@ -1381,7 +1381,7 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
         PackedConv& pc = n->semi[i];
         pc.bf_off = -1;
         if (pc.cin == 8 && pc.co == 8 && pc.groups == 1 && i < n->p2p.size() && !n->p2p[i].empty() && n->p2p[i].back().bf_off >= 0) {
-            pc.bf_off = static_cast<long long>(count); count += 6 * 64;
+            pc.bf_off = static_cast<long long>(count); count += 6 * 64 + 64;      // ... and the 8 inverse channel scales
         }
     }
     if (count == 0) return AKE_OK;

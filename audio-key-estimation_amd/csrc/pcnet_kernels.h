@@ -610,20 +610,28 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
 }
 
 // ==========================================================================================
-// 7x7 circular pitch convolution, 8 -> 8 channels, on v_mfma_f32_16x16x32_f16: f16 activations x (f16 hi + f16 lo) weights.
+// 7x7 circular pitch convolution, 8 -> 8 channels, on v_mfma_f32_16x16x32_f16: f16 activations x f16 weights, f32 accumulation.
 //
-// The f32 MFMA above runs at the vector rate; this form does the same contraction with 8x fewer matrix-pipe cycles.
-//   * weights: w = wh + wl, both f16 (wl stored times 2^11 so that it stays a normal number; its products go to an accumulator
-//     of their own that is folded in with 2^-11 at the end): exact to 2^-22, better than f32's product rounding;
-//   * activations: ONE f16 value (11 significant bits, rounding 2^-12 relative, unbiased).  Rounding the operand of these three
-//     convolutions moves the network's outputs by 1.5e-6 of their range (tests/tools/split_precision_proto.py: float64 forward with
-//     the rounding applied, golden and sparse inputs) -- below what the split-bf16 pair it replaces cost (hi + lo to 2^-17 on BOTH
-//     operands, 3 products, 2.8e-6) -- because 392 products with independent rounding errors are summed per output and the result
-//     is max-pooled over octaves.  The same prototype shows that the layer-1 pitch-class stack and the heads are NOT that
-//     tolerant (3e-5 .. 5e-4): they keep the three-product split-bf16 form.
-//   The second activation plane was what bound the previous form: per tile and CU its A fragments were 672 ds_read_b128 = 5376
-//   LDS cycles against 4032 matrix-pipe cycles (in-kernel stamps: 4450-5270 cycles per tile in the multiply loop).  Now 336 reads
-//   (2688 cycles) feed 2 products (2688 cycles), and half as many bytes are staged and written back.
+// The f32 MFMA above runs at the vector rate; this form does the same contraction with 16x fewer matrix-pipe cycles.
+//   * activations: ONE f16 value (11 significant bits, rounding 2^-12 relative, unbiased), channels-last;
+//   * weights: ONE f16 value each (kP2pProducts == 1), after scaling every output channel by a power of two so that its largest weight
+//     sits in [2^13, 2^14) -- whatever BatchNorm folded into it, nothing overflows or goes subnormal; the scale is undone by the
+//     epilogue's fma.  kP2pProducts == 2 adds the weights' second half (wl = rn((w - wh) * 2^11), products in an accumulator of their
+//     own): weights exact to 2^-22.
+//   What the roundings cost (tests/tools/split_precision_proto.py: the oracle's float64 forward with the rounding applied to these
+//   three convolutions, golden and sparse inputs; measured again end to end on the bench line): outputs move by 1.5e-6 of their range
+//   with exact weights and by 1.0e-5 .. 1.3e-5 with f16 weights (bench: max_rel_err 9.3e-6 -> 1.8e-5, budget 1e-3) -- the
+//   split-bf16 pair this replaces (hi + lo on BOTH operands, 3 products) cost 2.8e-6.  392 products with independent rounding errors
+//   are summed per output, and behind these convolutions sit an octave max, 1344-term pitch-class convolutions and a temporal mean.
+//   The same prototype shows that the layer-1 pitch-class stack and the heads are NOT that tolerant (3e-5 .. 5e-4 with f16
+//   activations): they keep the three-product split-bf16 form.
+//   Why it pays: on gfx950 a SIMD does not issue VALU work while its matrix pipe executes an MFMA, not even another wave's
+//   (tools/micro/mfma_valu_overlap.hip: 116 + 95 cycles alone, 210 together), so a tile costs MFMA cycles + VALU cycles + LDS waits.
+//   In-kernel stamps per tile (cycles): split-bf16 x3 ~7000 (A fragments of two planes: 5376 LDS cycles > 4032 MFMA cycles);
+//   f16 x (hi + lo) 4650 = 3260 MFMA + 1040 epilogue + 350 barrier; f16 x f16 3700 (now the A-fragment reads bound the loop: 336
+//   ds_read_b128 = 2688 LDS cycles against 1630 MFMA cycles).
+//   Range: activations beyond +-65504 saturate (MODE.FP16_OVFL is set, so nothing turns into inf); the net's activations sit behind
+//   BatchNorm + LeakyReLU and the log-magnitude CQT, orders of magnitude below that.
 // What makes it cheap is the layout: activations are CHANNELS-LAST, [clip][row][frame][8 ch], so the 8
 // consecutive k of one MFMA lane are the 8 input channels of one tap = one aligned 16-byte LDS read, with no Toeplitz
 // gather on the A side:
@@ -653,7 +661,11 @@ struct P2pBfArgs {
 typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8c __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2c __attribute__((ext_vector_type(2)));
+constexpr int kP2pProducts = 1;                                      // 1: f16 weights;  2: f16 hi + f16 lo weights (see above)
 constexpr float kP2pLoScale = 2048.f, kP2pLoInv = 1.f / 2048.f;     // the lo weight plane is stored times 2^11 (kept normal in f16)
+constexpr int kP2pFragScale = 14 * 2 * 64;                           // uint4 index of the 8 per-channel inverse scales behind a conv's fragments
+// v_cvt_f16_f32 saturates to +-65504 instead of producing inf (MODE.FP16_OVFL, bit 23)
+__device__ __forceinline__ void f16_saturate_mode() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
 __device__ __forceinline__ unsigned int f16_bits(float v) { return __builtin_bit_cast(unsigned short, static_cast<_Float16>(v)); }
 constexpr bool kP2pStreamB = true;
 constexpr int kP2pMT = 3;            // M-tiles (16 positions) per wave
@@ -669,6 +681,7 @@ __global__ __launch_bounds__(512) void conv_p2p_f16_kernel(P2pBfArgs a) {
     const int R_in = a.R + 6, Tp = a.Tp, J = a.J;
     const int rows_here = a.H - y0 < a.R ? a.H - y0 : a.R;
     const int Mblk = rows_here * J;
+    f16_saturate_mode();
     uint4* const pH = lds4;                                  // [R_in][Tp] positions, 16 B each
     uint4* const pB = lds4 + R_in * Tp;                      // [14][2][64]
     // ---- stage: patch (both circular halos resolved) and the weight fragments ----
@@ -737,11 +750,13 @@ __global__ __launch_bounds__(512) void conv_p2p_f16_kernel(P2pBfArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh, acc[mt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) accl[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, accl[mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt)
+            if (kP2pProducts == 2) accl[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, accl[mt], 0, 0, 0);
     }
     // ---- epilogue: D[row m = 4q + i][col n = 8*tau + co]; 32-bit offsets inside the clip ----
     const int tau = r16 >> 3, co = r16 & 7;
     const float bias = a.bias[co];
+    const float iscale = reinterpret_cast<const float*>(a.bfrag + kP2pFragScale)[co];
     unsigned short* const oh = OUT_CL ? a.oh + static_cast<long long>(clip) * a.H * a.T * 8 + co : nullptr;
     float* const od = OUT_CL ? nullptr : a.dst + clip * a.dst_clip_stride + static_cast<long long>(a.dst_coff + co) * a.H * a.T;
 #pragma unroll
@@ -753,7 +768,7 @@ __global__ __launch_bounds__(512) void conv_p2p_f16_kernel(P2pBfArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int t = 2 * j + tau;
-            const float x = fmaf(accl[mt][i], kP2pLoInv, acc[mt][i]) + bias;
+            const float x = fmaf(kP2pProducts == 2 ? fmaf(accl[mt][i], kP2pLoInv, acc[mt][i]) : acc[mt][i], iscale, bias);
             v[i] = x > 0.f ? x : x * kSlope;
             pos[i] = (m0 + i < Mblk && t < a.T) ? (y0 + r) * a.T + t : -1;
             if (++j == J) { j = 0; ++r; }
@@ -829,6 +844,7 @@ __global__ __launch_bounds__(512) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, q = lane >> 4;
     const int Tp = a.Tp, J = a.J, T = a.T;
+    f16_saturate_mode();
     const int nchunk = a.plane_pos >> 6;                        // 1 KB pieces per plane
     const int npos = (a.R + 6) * Tp;
     // tiles of this workgroup: first, first + gridDim.x, ...; workgroups of one XCD take neighbouring tiles
@@ -920,7 +936,7 @@ __global__ __launch_bounds__(512) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {
         else issue_loads(first, 0);
     }
     // ---- weight fragments: registers, for the whole launch ----
-    uint4 breg[28];
+    uint4 breg[28];                  // (kP2pProducts == 1: the lo halves are never used and never loaded)
 #pragma unroll
     for (int i = 0; i < 28; ++i) breg[i] = a.bfrag[i * 64 + lane];
     int abase[MT];
@@ -933,6 +949,7 @@ __global__ __launch_bounds__(512) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {
     }
     const int tau = r16 >> 3, co = r16 & 7;
     const float bias = a.bias[co];
+    const float iscale = reinterpret_cast<const float*>(a.bfrag + kP2pFragScale)[co];
     uint4* const stage = lds4 + 2 * a.plane_pos + wave * (MT * kP2pPsStage);          // OUT 0 / 1: wave-private slabs
     uint4* const opatch = lds4 + 2 * a.plane_pos;                                      // OUT 2: [2 buffers][384 m][2 tau] positions
     constexpr int kOP = 8 * MT * 16 * 2;                                               // positions of one output patch
@@ -972,8 +989,8 @@ __global__ __launch_bounds__(512) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float x = fmaf(accl[mt][i], kP2pLoInv, acc[mt][i]) + bias;
-                v[i] = x > 0.f ? x : x * kSlope;
+                const float x = fmaf(kP2pProducts == 2 ? fmaf(accl[mt][i], kP2pLoInv, acc[mt][i]) : acc[mt][i], iscale, bias);
+                v[i] = fmaxf(x, x * kSlope);            // LeakyReLU (slope < 1)
             }
             if (OUT_CL || OUT_SEMI) {
                 // lanes (co, co ^ 1) trade halves: the even lane keeps rows m = 4q, 4q + 1 of both channels, the odd lane rows 4q + 2, 4q + 3
@@ -1000,12 +1017,13 @@ __global__ __launch_bounds__(512) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {
     };
     // ---- OUT 2: semitone conv over the finished tile (one M-tile of 16 (semitone row, frame pair) positions per wave) ----
     uint4 sreg[6];
-    float sbias = 0.f;
+    float sbias = 0.f, siscale = 1.f;
     int sbase = 0;
     if (OUT_SEMI) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) sreg[i] = a.sfrag[i * 64 + lane];
         sbias = a.sbias[co];
+        siscale = reinterpret_cast<const float*>(a.sfrag + 6 * 64)[co];
         int ms = wave * 16 + r16;
         ms = ms < (a.R / 3) * J ? ms : (a.R / 3) * J - 1;
         const int srow = ms / J, sj = ms - srow * J;
@@ -1019,15 +1037,15 @@ __global__ __launch_bounds__(512) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {
             const f16x8c ah = __builtin_bit_cast(f16x8c, oH[sbase + dy * T]);
             const f16x8c bh = __builtin_bit_cast(f16x8c, sreg[2 * dy]), bl = __builtin_bit_cast(f16x8c, sreg[2 * dy + 1]);
             sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, sacc, 0, 0, 0);
-            saccl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, saccl, 0, 0, 0);
+            if (kP2pProducts == 2) saccl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, saccl, 0, 0, 0);
         }
         const int S = a.H / 3;
         float* const o = a.dst + base + static_cast<long long>(co) * S * T + tau;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                                 // D[m = 4q + i][n = (tau, co)]: semitone position 2m + tau of the tile
             const int m = wave * 16 + 4 * q + i;
-            const float x = fmaf(saccl[i], kP2pLoInv, sacc[i]) + sbias;
-            if (3 * m < mblk) o[2 * m] = x > 0.f ? x : x * kSlope;
+            const float x = fmaf(kP2pProducts == 2 ? fmaf(saccl[i], kP2pLoInv, sacc[i]) : sacc[i], siscale, sbias);
+            if (3 * m < mblk) o[2 * m] = fmaxf(x, x * kSlope);
         }
     };
     // The waves 4..7 run their epilogue one barrier late (the accumulators wait in registers): each SIMD holds one wave of either
@@ -1074,7 +1092,8 @@ __global__ __launch_bounds__(512) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh, acc[mt], 0, 0, 0);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) accl[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, accl[mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt)
+                if (kP2pProducts == 2) accl[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, accl[mt], 0, 0, 0);
         }
         if (STAMP) ts[4] = p2p_stamp();
         if (!late) epilogue(acc, accl, cur);
@@ -1685,6 +1704,15 @@ __global__ void cl_to_nchw_kernel(const unsigned short* __restrict__ xh, const u
 // B fragments of conv_p2p_f16_kernel from the VALU-layout eval pack [ci < cin][dy][dx][8 co] (BatchNorm already folded; input
 // channels >= cin get zero weights): f16 hi = rn(w), f16 lo = rn((w - hi) * 2^11);
 // one thread per (k-step, lane, element).
+// power of two s with s * wmax in [2^13, 2^14) (1 for an all-zero channel): the channel's weights use f16's normal range whatever
+// BatchNorm folded into them
+__device__ __forceinline__ float f16_weight_scale(float wmax) {
+    if (!(wmax > 0.f) || !(wmax < INFINITY)) return 1.f;
+    int e;
+    frexpf(wmax, &e);                                         // wmax = m * 2^e, m in [0.5, 1)
+    return ldexpf(1.f, 14 - e);
+}
+
 __global__ void pack_p2p_f16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (ks, lane)
     if (i >= 14 * 64) return;
@@ -1693,10 +1721,14 @@ __global__ void pack_p2p_f16_kernel(const float* __restrict__ w, uint4* __restri
     const int n = lane & 15, qq = lane >> 4;
     const int tau = n >> 3, co = n & 7;
     const int dx = 4 * h + qq - tau;
+    float wmax = 0.f;
+    for (int k = 0; k < cin * 49; ++k) wmax = fmaxf(wmax, fabsf(w[k * 8 + co]));
+    const float sc = f16_weight_scale(wmax);
+    if (ks == 0 && qq == 0 && tau == 0) reinterpret_cast<float*>(out + kP2pFragScale)[co] = 1.f / sc;
     unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
     for (int ci = 0; ci < 8; ++ci) {
         float v = 0.f;
-        if (dx >= 0 && dx < 7 && ci < cin) v = w[((ci * 7 + dy) * 7 + dx) * 8 + co];
+        if (dx >= 0 && dx < 7 && ci < cin) v = sc * w[((ci * 7 + dy) * 7 + dx) * 8 + co];
         const _Float16 hv = static_cast<_Float16>(v);
         const unsigned int hb = __builtin_bit_cast(unsigned short, hv);
         const unsigned int lb = f16_bits((v - static_cast<float>(hv)) * kP2pLoScale);
@@ -1716,10 +1748,14 @@ __global__ void pack_semi_f16_kernel(const float* __restrict__ w, uint4* __restr
     const int n = lane & 15, qq = lane >> 4;
     const int tau = n >> 3, co = n & 7;
     const int dx = qq - tau;
+    float wmax = 0.f;
+    for (int k = 0; k < 8 * 9; ++k) wmax = fmaxf(wmax, fabsf(w[k * 8 + co]));
+    const float sc = f16_weight_scale(wmax);
+    if (dy == 0 && qq == 0 && tau == 0) reinterpret_cast<float*>(out + 6 * 64)[co] = 1.f / sc;
     unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
     for (int ci = 0; ci < 8; ++ci) {
         float v = 0.f;
-        if (dx >= 0 && dx < 3) v = w[((ci * 3 + dy) * 3 + dx) * 8 + co];
+        if (dx >= 0 && dx < 3) v = sc * w[((ci * 3 + dy) * 3 + dx) * 8 + co];
         const _Float16 hv = static_cast<_Float16>(v);
         const unsigned int hb = __builtin_bit_cast(unsigned short, hv);
         const unsigned int lb = f16_bits((v - static_cast<float>(hv)) * kP2pLoScale);

@@ -442,8 +442,8 @@ def main():
         "metric": "clips/s (15 s @ 22.05 kHz), HIP CQT + PitchClassNet forward",
         "value": round(value, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 accumulation everywhere; pitch convolutions: f16 activations x (f16 hi + f16 lo) weights on MFMA (2 products, weights exact to 2^-22); "
-                                     "pitch-class convolutions, heads and the CQT filter bank: 3-term split-bf16 on MFMA (hi*hi + lo*hi + hi*lo); outputs ~1e-5 of the float64 oracle", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 accumulation everywhere; pitch convolutions: f16 activations x f16 weights (per-channel power-of-two scaled) on MFMA; "
+                                     "pitch-class convolutions, heads and the CQT filter bank: 3-term split-bf16 on MFMA (hi*hi + lo*hi + hi*lo); outputs ~2e-5 of the float64 oracle", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: batch={B} synthetic 15 s sine-mix clips per GPU, HIP CQT (288 bins, hop 4410) "
                                f"+ default PitchClassNet inference (genre head on), audio resident in HBM",
                    "clips_per_gpu": B, "n_samples": N_SAMPLES, "frames": T_FRAMES, "weights": "tests/golden/pcnet_default.npz (seeded)",
@@ -453,13 +453,12 @@ def main():
                    "steps_in_flight": f"{args.streams}: every step is the whole path over one batch; consecutive steps go round-robin to "
                                       f"{args.streams} streams with a workspace each (KeyEstimator(streams=...))" if args.streams > 1 else "1"},
         "roofline": {"bound": "mfma",
-                     "kernel": "conv_p2p_f16_ps_kernel (persistent 7x7 circular pitch convolution, 8 channels, f16 activations x (f16 hi + f16 lo) weights on "
-                               "v_mfma_f32_16x16x32_f16 with f32 accumulation: 2 MFMA products per algorithmic MAC), 3 launches per step; the third "
+                     "kernel": "conv_p2p_f16_ps_kernel (persistent 7x7 circular pitch convolution, 8 channels, f16 activations x f16 weights on "
+                               "v_mfma_f32_16x16x32_f16 with f32 accumulation: 1 MFMA product per algorithmic MAC), 3 launches per step; the third "
                                "also runs the semitone conv on its output tile and writes only the semitone maps",
                      "achieved": round(achieved, 2) if achieved else None, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_BF16_TFLOPS, 4) if achieved else None,
-                     "mfma_products_per_mac": 2,
-                     "frac_of_split_ceiling": round(2 * achieved / PEAK_BF16_TFLOPS, 4) if achieved else None,
+                     "mfma_products_per_mac": 1,
                      "traffic": p2p_traffic,
                      "traffic_source": f"profiles/{traffic_src}: mean HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE" if p2p_traffic else traffic_stale,
                      # mean over the three launches: (1 CQT + 4 x 36-row up_sixth channels -> 8 channels), (8 -> 8), (8 -> 8 semitone channels of P / 3 rows)
