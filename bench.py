@@ -12,9 +12,8 @@ step time is the max over ranks.  Rank 0 prints ONE JSON line.
 Extra objects on the line (tier contract):
   roofline      dominant kernel (conv_p2p_f16_kernel: the 7x7 circular pitch convolutions, 65 % of
                 the MACs): algorithmic FLOPs (2 x MACs) of its launches / their hipEvent-measured
-                duration, vs the 2.5 PFLOP/s dense bf16 MFMA peak of MI355X; the kernel multiplies
-                split-bf16 operands (3 MFMA products per MAC), so `frac_of_split_ceiling` = 3 x frac
-                is the fraction of what this formulation can reach.
+                duration, vs the 2.5 PFLOP/s dense f16 / bf16 MFMA peak of MI355X; the kernel multiplies
+                f16 activations with f16 weights, one MFMA product per MAC.
   roofline_cqt  the CQT stage against the 8 TB/s HBM peak (1 410 552 algorithmic bytes per clip).
   cpu_baseline  the CPU oracle (direct-form CQT as BLAS matmuls + the oracle network) timed on this
                 box's host cores on a bounded sample: BASELINE.md section 3's cases (fp32 / fp64, B = 1 /
