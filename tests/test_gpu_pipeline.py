@@ -149,7 +149,7 @@ def test_kernel_timer_reports_the_launched_kernels(net):
     assert {"cqt_bank_bf16_kernel", "cqt_cascade_kernel", "cqt_transpose_kernel", "conv_p2p_f16_kernel",
             "conv_pc_bf16_kernel/pc2pc", "conv_pc_bf16_kernel/head", "conv_head1_bf16_kernel"} <= set(res)
     assert "head_pool_kernel" not in res                                                   # the masked mean + sigmoid ride in conv_head1_bf16_kernel
-    # Pitch2Pitch stack: all three convs on the bf16x3 kernel (the 5-channel input is assembled channels-last, padded to 8)
+    # Pitch2Pitch stack: all three convs on the f16 MFMA kernel (the 5-channel input is assembled channels-last, padded to 8)
     assert "conv_mfma_kernel/p2p" not in res and res["conv_p2p_f16_kernel"][1] == 3
     assert res["cqt_cascade_kernel"][1] == 1                                               # 7 decimation stages, one launch
     assert all(ms > 0 for ms, _ in res.values())

@@ -70,8 +70,10 @@ groups = {
 for name, x, seq in cases:
     ref = run(x, seq, None, None)
     print(name)
-    for ak, wk in (("f16", "f16x2"), ("f16", "f16"), ("bf16x2", "bf16x2")):
+    import sys as _s
+    combos = (("f16", "f16x2"), ("f16", "f16"), ("bf16x2", "bf16x2")) if len(_s.argv) < 2 else tuple(tuple(None if v == "exact" else v for v in c.split(":")) for c in _s.argv[1:])
+    for ak, wk in combos:
         for gname, only in groups.items():
             out = run(x, seq, ak, wk, only)
             errs = [float((o - r).abs().max() / r.abs().max()) for o, r in zip(out, ref)]
-            print(f"   act {ak:7s} w {wk:7s} {gname:36s} key {errs[0]:.2e}  tonic {errs[1]:.2e}  genre {errs[2]:.2e}")
+            print(f"   act {str(ak):7s} w {str(wk):7s} {gname:36s} key {errs[0]:.2e}  tonic {errs[1]:.2e}  genre {errs[2]:.2e}")

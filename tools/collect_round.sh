@@ -8,8 +8,6 @@ mkdir -p $out
 export TMPDIR=/tmp
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $out/gpu_tests.log 2>&1; echo "gpu tests rc=$?" | tee -a $out/gpu_tests.log
 tail -3 $out/gpu_tests.log
-timeout -k 10 300 python3 bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"
-timeout -k 10 300 python3 bench.py --train > $out/train_bench.json 2> $out/train_bench.err; echo "train bench rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --sustained-seconds 0 --pipelined-streams 0 > $out/stats_bench.log 2>&1; echo "stats rc=$?"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --sustained-seconds 0 --pipelined-streams 0 > $out/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --sustained-seconds 0 --pipelined-streams 0 > $out/pmc_write.log 2>&1; echo "pmc write rc=$?"
@@ -20,4 +18,9 @@ write_csv=$(find $out/pmc_write -name "*_counter_collection.csv" | head -1)
 stats_csv=$(find $out/stats -name "*_kernel_stats.csv" | head -1)
 [ -n "$fetch_csv" ] && [ -n "$write_csv" ] && python3 tools/pmc_traffic.py "$fetch_csv" "$write_csv" $out/pmc_traffic.json > $out/pmc_traffic.txt
 [ -n "$stats_csv" ] && python3 tools/summarize_prof.py "$stats_csv" $out/stats_bench.log $out/kernel_stats.md
+# the bench lines last: the PMC summary of THIS build sits in profiles/ (box-local copy; copy it to the repo's profiles/ afterwards), so
+# the line's roofline.traffic is filled from counters taken with the same kernel sources
+[ -f $out/pmc_traffic.json ] && cp $out/pmc_traffic.json profiles/${tag}_pmc_traffic.json
+timeout -k 10 300 python3 bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"
+timeout -k 10 300 python3 bench.py --train > $out/train_bench.json 2> $out/train_bench.err; echo "train bench rc=$?"
 echo "collect_round done"
