@@ -558,7 +558,11 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
         attr_set.mark();
     }
-    dim3 grid(std::min(n_cus / 8 * 8, (a.n_tiles + 7) / 8 * 8)), block(512);
+    // two workgroups per CU when the LDS allows it (the kernel is built for 4 waves per SIMD): one's epilogue (vector work) and
+    // barrier waits run under the other's multiply loop (bound by its LDS reads)
+    static const int wg_per_cu_env = std::getenv("AKE_P2P_WG_PER_CU") ? std::atoi(std::getenv("AKE_P2P_WG_PER_CU")) : 2;
+    const int wg_per_cu = (wg_per_cu_env >= 2 && lds <= 80 * 1024 && a.n_tiles >= 4 * n_cus) ? 2 : 1;
+    dim3 grid(std::min(wg_per_cu * (n_cus / 8 * 8), (a.n_tiles + 7) / 8 * 8)), block(512);
     ake::ProfScope ps(name, s);
     if (semi_pc) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<2, 0>), grid, block, lds, s, a);
     else if (dst_nchw) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<0, 0>), grid, block, lds, s, a);

@@ -834,7 +834,7 @@ constexpr int kP2pPsStage = 80;      // uint4 per M-tile of a wave's staging sla
 // NIN: 0 = channels-last f16 plane in; else the number of f32 channels the loader assembles (5: default net, 8: any)
 // STAMP: diagnostic build with s_memtime stamps around the tile loop's sections (tools/p2p_stamp.py; shares, never timed)
 template <int OUT, int NIN, bool STAMP = false>
-__global__ __launch_bounds__(512) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {
+__global__ __launch_bounds__(512, 4) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {
     constexpr bool OUT_CL = OUT == 1, OUT_SEMI = OUT == 2;
     constexpr bool IN_NCHW = NIN > 0;
     constexpr int NV = IN_NCHW ? NIN : 1;
@@ -1713,7 +1713,17 @@ __device__ __forceinline__ float f16_weight_scale(float wmax) {
     return ldexpf(1.f, 14 - e);
 }
 
+// max |w| of each of the 8 output channels of a pack [n_k][8 co], by the whole block (bit patterns of non-negative floats order as ints)
+__device__ __forceinline__ void channel_absmax8(const float* __restrict__ w, int n_k, int* smax) {
+    if (threadIdx.x < 8) smax[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_k * 8; k += blockDim.x) atomicMax(&smax[k & 7], __float_as_int(fabsf(w[k])));
+    __syncthreads();
+}
+
 __global__ void pack_p2p_f16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin) {
+    __shared__ int smax[8];
+    channel_absmax8(w, cin * 49, smax);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (ks, lane)
     if (i >= 14 * 64) return;
     const int ks = i / 64, lane = i - ks * 64;
@@ -1721,9 +1731,7 @@ __global__ void pack_p2p_f16_kernel(const float* __restrict__ w, uint4* __restri
     const int n = lane & 15, qq = lane >> 4;
     const int tau = n >> 3, co = n & 7;
     const int dx = 4 * h + qq - tau;
-    float wmax = 0.f;
-    for (int k = 0; k < cin * 49; ++k) wmax = fmaxf(wmax, fabsf(w[k * 8 + co]));
-    const float sc = f16_weight_scale(wmax);
+    const float sc = f16_weight_scale(__int_as_float(smax[co]));
     if (ks == 0 && qq == 0 && tau == 0) reinterpret_cast<float*>(out + kP2pFragScale)[co] = 1.f / sc;
     unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
     for (int ci = 0; ci < 8; ++ci) {
@@ -1742,15 +1750,15 @@ __global__ void pack_p2p_f16_kernel(const float* __restrict__ w, uint4* __restri
 // B fragments of the semitone conv fused into conv_p2p_f16_ps_kernel<2, ...>, from its eval pack [ci < 8][3 dy][3 dx][8 co]:
 // k-step = dy, k = (position qq, ci), n = (tau, co), tap dx = qq - tau (the 4th position of either frame carries zero weights)
 __global__ void pack_semi_f16_kernel(const float* __restrict__ w, uint4* __restrict__ out) {
+    __shared__ int smax[8];
+    channel_absmax8(w, 8 * 9, smax);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (dy, lane)
     if (i >= 3 * 64) return;
     const int dy = i / 64, lane = i - dy * 64;
     const int n = lane & 15, qq = lane >> 4;
     const int tau = n >> 3, co = n & 7;
     const int dx = qq - tau;
-    float wmax = 0.f;
-    for (int k = 0; k < 8 * 9; ++k) wmax = fmaxf(wmax, fabsf(w[k * 8 + co]));
-    const float sc = f16_weight_scale(wmax);
+    const float sc = f16_weight_scale(__int_as_float(smax[co]));
     if (dy == 0 && qq == 0 && tau == 0) reinterpret_cast<float*>(out + 6 * 64)[co] = 1.f / sc;
     unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
     for (int ci = 0; ci < 8; ++ci) {
