@@ -502,7 +502,7 @@ int p2p_ps_rows(int H, int T, bool semi, int* plane_pos, size_t* lds) {
     auto lds_of = [&](int R) { return (static_cast<size_t>(2) * plane_of(R) + (semi ? 2 * 8 * kP2pMT * 16 * 2 : 8 * kP2pMT * kP2pPsStage)) * sizeof(uint4); };
     int R = std::max(1, std::min(H, 8 * kP2pMT * 16 / J));
     if (semi) R = R / 3 * 3;
-    while (R >= (semi ? 3 : 1) && (lds_of(R) > 156 * 1024 || plane_of(R) / 64 > 48)) R -= semi ? 3 : 1;     // the loader: 8 waves x 6 pieces
+    while (R >= (semi ? 3 : 1) && (lds_of(R) > 156 * 1024 || plane_of(R) / 64 > 8 * kP2pPieces)) R -= semi ? 3 : 1;     // the loader: 8 waves x kP2pPieces pieces
     if (R < (semi ? 3 : 1) || H < R + 6) return 0;
     if (semi && (H % 3 || (H / 3) % 12)) return 0;
     if (plane_pos) *plane_pos = plane_of(R);
@@ -561,7 +561,7 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
     // two workgroups per CU when the LDS allows it (the kernel is built for 4 waves per SIMD): one's epilogue (vector work) and
     // barrier waits run under the other's multiply loop (bound by its LDS reads)
     static const int wg_per_cu_env = std::getenv("AKE_P2P_WG_PER_CU") ? std::atoi(std::getenv("AKE_P2P_WG_PER_CU")) : 2;
-    const int wg_per_cu = (wg_per_cu_env >= 2 && lds <= 80 * 1024 && a.n_tiles >= 4 * n_cus) ? 2 : 1;
+    const int wg_per_cu = (wg_per_cu_env >= 2 && !nchw && lds <= 80 * 1024 && a.n_tiles >= 4 * n_cus) ? 2 : 1;
     dim3 grid(std::min(wg_per_cu * (n_cus / 8 * 8), (a.n_tiles + 7) / 8 * 8)), block(512);
     ake::ProfScope ps(name, s);
     if (semi_pc) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<2, 0>), grid, block, lds, s, a);

@@ -824,6 +824,7 @@ __device__ __forceinline__ unsigned long long p2p_stamp() {
     return t;
 }
 
+constexpr int kP2pPieces = 3;        // 1 KB pieces of the patch a wave requests per tile (8 waves: planes of up to 24 pieces)
 constexpr int kP2pPsStage = 80;      // uint4 per M-tile of a wave's staging slab (NCHW form: 8 channels x 36 floats, padded)
 
 // OUT: 0 = NCHW f32, 1 = channels-last f16 plane (next conv of the stack), 2 = the stack's last conv FUSED with the semitone conv
@@ -834,7 +835,7 @@ constexpr int kP2pPsStage = 80;      // uint4 per M-tile of a wave's staging sla
 // NIN: 0 = channels-last f16 plane in; else the number of f32 channels the loader assembles (5: default net, 8: any)
 // STAMP: diagnostic build with s_memtime stamps around the tile loop's sections (tools/p2p_stamp.py; shares, never timed)
 template <int OUT, int NIN, bool STAMP = false>
-__global__ __launch_bounds__(512, 4) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {
+__global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {   // (the assembling loader's 15 input registers do not fit 128)
     constexpr bool OUT_CL = OUT == 1, OUT_SEMI = OUT == 2;
     constexpr bool IN_NCHW = NIN > 0;
     constexpr int NV = IN_NCHW ? NIN : 1;
@@ -851,9 +852,9 @@ __global__ __launch_bounds__(512, 4) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     const int first = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     // ---- loader: the pieces c = wave, wave + 8, ... of the plane; lane -> patch position -> (row offset, frame) ----
-    int pk[6];
+    int pk[kP2pPieces];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < kP2pPieces; ++k) {
         const int c = wave + 8 * k;
         int i = c * 64 + lane;
         i = i < npos ? i : npos - 1;
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(512, 4) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {
         const int y0 = (tile - clip * a.n_row_tiles) * a.R;
         const long long cbase = static_cast<long long>(clip) * a.H * T;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < kP2pPieces; ++k) {
             const int c = wave + 8 * k;
             if (c < nchunk) {
                 int row = y0 - 3 + (pk[k] >> 16);
