@@ -235,6 +235,34 @@ def test_persistent_pitch_conv_equals_per_tile_kernel_and_oracle(gold_default, B
         assert rel_err(a.cpu(), b) < TOL
 
 
+def test_f16_pitch_convs_with_wide_batchnorm_scales(gold_default):
+    """The pitch convolutions multiply f16 activations and f16 weights (conv_p2p_f16_kernel).  LeakyReLU is positively homogeneous, so
+    scaling a BatchNorm's (gamma, beta) per channel and dividing the next convolution's weights of that input channel leaves the
+    network's function unchanged -- while activations and folded weights now span 1e-3 .. 1e3 across channels.  Every output
+    channel's weights are scaled into f16's normal range by their own power of two before rounding (the epilogue undoes it), so the
+    outputs must still agree with the oracle; without that scaling the small weights would be f16 subnormals."""
+    sd32 = golden_state_dict(gold_default)
+    scale = torch.tensor([300.0, 1 / 300.0, 1.0, 30.0, 1 / 30.0, 1000.0, 1e-3, 1.0])
+    for bn, nxt in (("model.1.p2p.layer.1", "model.1.p2p.layer.3.weight"), ("model.1.p2p.layer.4", "model.1.p2p.layer.6.weight"),
+                    ("model.1.p2p.layer.7", "model.1.pool_semi.weight")):
+        sd32[bn + ".weight"] = sd32[bn + ".weight"] * scale
+        sd32[bn + ".bias"] = sd32[bn + ".bias"] * scale
+        sd32[nxt] = sd32[nxt] / scale.reshape(1, 8, 1, 1)
+        scale = scale.flip(0)
+    opt = Namespace(**json.loads(str(gold_default["opt"])))
+    net = ake_amd.PitchClassNet(288, 12, 2, 7, opt)
+    net.load_state_dict(sd32, strict=True)
+    net = net.to(DEV).eval()
+    x = torch.from_numpy(gold_default["x"])
+    seq = torch.from_numpy(gold_default["seq_length"])
+    ref = pcnet_oracle.pcnet_forward({k: v.double() if v.is_floating_point() else v for k, v in sd32.items()}, x.double(), seq)
+    for n, r in zip(("key", "tonic", "genre"), ref):                     # the function did not change
+        assert rel_err(r, gold_default[n]) < 1e-6
+    got = net(x.to(DEV), seq.to(DEV))
+    for a, b in zip(got, ref):
+        assert torch.isfinite(a).all() and rel_err(a.cpu(), b) < TOL, rel_err(a.cpu(), b)
+
+
 def test_local_heads_against_reference_fixture(gold_default, gold_local):
     """--local (models.py:720-722, 805-810): same state_dict, per-frame key / tonic / genre; the fixture is the
     reference's own output with opt.local.  A long song (T = 1500, time-tiled kernels) is checked against the oracle."""
