@@ -8,9 +8,9 @@ mkdir -p $out
 export TMPDIR=/tmp
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $out/gpu_tests.log 2>&1; echo "gpu tests rc=$?" | tee -a $out/gpu_tests.log
 tail -3 $out/gpu_tests.log
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --sustained-seconds 0 --pipelined-streams 0 > $out/stats_bench.log 2>&1; echo "stats rc=$?"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --sustained-seconds 0 --pipelined-streams 0 > $out/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --sustained-seconds 0 --pipelined-streams 0 > $out/pmc_write.log 2>&1; echo "pmc write rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --sustained-seconds 0 --pipelined-streams 0 --spinup-seconds 0 > $out/stats_bench.log 2>&1; echo "stats rc=$?"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --sustained-seconds 0 --pipelined-streams 0 --spinup-seconds 0 > $out/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --sustained-seconds 0 --pipelined-streams 0 --spinup-seconds 0 > $out/pmc_write.log 2>&1; echo "pmc write rc=$?"
 find $out -name "*.csv" | head -20
 # summaries written on the box, from the kernel sources that actually ran (the PMC json carries their hash)
 fetch_csv=$(find $out/pmc_fetch -name "*_counter_collection.csv" | head -1)

@@ -21,7 +21,7 @@ def main(stats_csv, bench_log, out_md):
     bench = [l for l in open(bench_log) if l.startswith("{")]
     with open(out_md, "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats summary ({stats_csv.split('/')[-1]})\n\n")
-        f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --sustained-seconds 0 --pipelined-streams 0`\n")
+        f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --sustained-seconds 0 --pipelined-streams 0 --spinup-seconds 0`\n")
         f.write("(library kernels only; torch kernels that synthesise the input clips are omitted; 12 forward passes = 5 timed + 5 all-kernel-events + 2 warm-up)\n\n")
         f.write("| kernel | calls | total ms | avg us | min us | max us | % of library time |\n|---|---|---|---|---|---|---|\n")
         for r in sorted(rows, key=lambda r: -r[2]):
