@@ -134,7 +134,8 @@ def cqt_features(waveforms: torch.Tensor, rate: int, opt, lengths=None) -> torch
         raise NotImplementedError("opt.frames == 0 (fixed 592-frame windows, KeyDataset.py:490,501-503) is not built")
     if getattr(opt, "only_semitones", False) or getattr(opt, "multi_scale", False):
         raise NotImplementedError("--only_semitones / --multi_scale CQTs are not built (SURVEY.md section 2.1)")
-    plan = get_plan(rate, hop_for(rate, frames), 36 * getattr(opt, "octaves", 8), 36)
+    # opt.cqt_q_mode (not a reference option): 1 selects librosa <= 0.9's filter Q, see ake_amd.cqt.get_plan
+    plan = get_plan(rate, hop_for(rate, frames), 36 * getattr(opt, "octaves", 8), 36, q_mode=int(getattr(opt, "cqt_q_mode", 0)))
     return plan.logmag(waveforms, lengths=lengths)
 
 

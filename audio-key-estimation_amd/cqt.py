@@ -95,16 +95,21 @@ class CQTPlan:
 _plans = {}
 
 
-def get_plan(sr, hop_length, n_bins=288, bins_per_octave=36, device=None) -> CQTPlan:
+def get_plan(sr, hop_length, n_bins=288, bins_per_octave=36, device=None, q_mode: int = 0) -> CQTPlan:
+    """Cached plan.  ``q_mode``: 0 = the filter Q of librosa >= 0.10, (r^2 + 1) / (r^2 - 1) with r = 2^(1 / bins_per_octave) -- the
+    build's default, because librosa <= 0.9 rejects the reference's default hop 4410; 1 = librosa <= 0.9's Q = 1 / (r - 1)
+    (requirements.txt:250 pins 0.9.2: a checkpoint trained on features from that version saw this Q; its reflect padding of the
+    clip edges is NOT built -- frames whose windows reach past the clip see zeros).  ADVICE r1: the choice is the caller's."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    key = (int(sr), int(hop_length), int(n_bins), int(bins_per_octave), str(dev))
+    key = (int(sr), int(hop_length), int(n_bins), int(bins_per_octave), str(dev), int(q_mode))
     if key not in _plans:
-        _plans[key] = CQTPlan(sr, hop_length, n_bins, bins_per_octave, device=dev)
+        _plans[key] = CQTPlan(sr, hop_length, n_bins, bins_per_octave, q_mode=q_mode, device=dev)
     return _plans[key]
 
 
-def cqt_logmag(y, sr=22050, hop_length=512, n_bins=84, bins_per_octave=12, device=None) -> torch.Tensor:
-    """``log(1 + |librosa.cqt(y, sr, hop_length, n_bins=..., bins_per_octave=...)|)`` on the GPU (defaults as librosa's)."""
+def cqt_logmag(y, sr=22050, hop_length=512, n_bins=84, bins_per_octave=12, device=None, q_mode: int = 0) -> torch.Tensor:
+    """``log(1 + |librosa.cqt(y, sr, hop_length, n_bins=..., bins_per_octave=...)|)`` on the GPU (defaults as librosa's); ``q_mode``
+    as in get_plan."""
     y = torch.as_tensor(y)
-    plan = get_plan(sr, hop_length, n_bins, bins_per_octave, device if device is not None else (y.device if y.is_cuda else None))
+    plan = get_plan(sr, hop_length, n_bins, bins_per_octave, device if device is not None else (y.device if y.is_cuda else None), q_mode)
     return plan.logmag(y)

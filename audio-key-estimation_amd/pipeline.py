@@ -27,13 +27,14 @@ class KeyEstimator:
     behaviour, bit for bit.  ``"true_end"`` (opt-in) wraps every clip at its OWN last frame: clips are
     grouped by frame count and each group runs unpadded, so a clip's outputs are those of the clip alone."""
 
-    def __init__(self, net: PitchClassNet, sample_rate: int = 22050, frames: int = 5, streams: int = 1, wrap_mode: str = "dataset_max"):
+    def __init__(self, net: PitchClassNet, sample_rate: int = 22050, frames: int = 5, streams: int = 1, wrap_mode: str = "dataset_max",
+                 q_mode: int = 0):
         if wrap_mode not in ("dataset_max", "true_end"):
             raise ValueError("wrap_mode must be 'dataset_max' or 'true_end'")
         self.net = net.eval()
         self.device = net._device()
         self.sample_rate, self.wrap_mode = int(sample_rate), wrap_mode
-        self.plan = CQTPlan(sample_rate, hop_for(sample_rate, frames), net.pitches, 36, device=self.device)
+        self.plan = CQTPlan(sample_rate, hop_for(sample_rate, frames), net.pitches, 36, q_mode=q_mode, device=self.device)   # q_mode: ake_amd.cqt.get_plan
         self.streams = max(1, int(streams))
         self._slots = [{"ws": None, "stream": None} for _ in range(self.streams)]
         self._turn = 0

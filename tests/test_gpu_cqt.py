@@ -34,6 +34,24 @@ def test_short_clips_against_direct_form(plan):
         assert rel_err(got[b], ref) < TOL, b
 
 
+def test_librosa09_filter_q_is_selectable():
+    """requirements.txt:250 pins librosa 0.9.2, whose filter Q is 1 / (2^(1/36) - 1) instead of >= 0.10's; the choice is
+    exposed through the Python layer (CQTPlan / get_plan / cqt_logmag / opt.cqt_q_mode / KeyEstimator) and checked against the
+    direct-form oracle with the same constant.  The two Qs give measurably different features."""
+    ys, _ = synthetic.make_batch(range(2), SR * 3)
+    x = torch.from_numpy(ys).to(DEV)
+    got09 = ake_amd.cqt.cqt_logmag(x, SR, HOP, 288, 36, q_mode=1).cpu().numpy()
+    got10 = ake_amd.cqt.cqt_logmag(x, SR, HOP, 288, 36).cpu().numpy()
+    for b in range(2):
+        assert rel_err(got09[b], O.cqt_logmag(ys[b], SR, HOP, q_mode="librosa09")) < TOL
+        assert rel_err(got10[b], O.cqt_logmag(ys[b], SR, HOP)) < TOL
+    assert rel_err(got09, got10) > 5 * TOL
+    from argparse import Namespace
+    from ake_amd.KeyDataset import cqt_features
+    mel = cqt_features(x, SR, Namespace(frames=5, octaves=8, cqt_q_mode=1))
+    assert torch.equal(mel.cpu(), torch.from_numpy(got09))
+
+
 def test_full_length_clip_against_direct_form(plan):
     """One BASELINE-size clip: 15 s @ 22.05 kHz -> (288, 76)."""
     y, _ = synthetic.make_clip(7)
