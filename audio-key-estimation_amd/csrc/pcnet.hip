@@ -448,6 +448,13 @@ bool pc2pc_uses_bf16(const ake_pcnet* n, int i, int T) {
     return true;
 }
 
+// Row pitch of the pitch convs' LDS patch, in positions (16 B each): >= 2J + 6 (three halo frames either side), and 2J + 16 so that
+// an M-tile that runs over a row end (m = r * J + j: its lanes then sit in two patch rows) still reads 16 distinct 16-byte slots per
+// ds_read_b128 lane group -- the A-fragment address is r * Tp + 2j + q, a row change adds Tp - 2J, and the LDS has 16 slots per clock.
+// With 2J + 6 the straddling tiles (40 % of them at J = 38) paid two-way conflicts: SQ_LDS_BANK_CONFLICT was 26-28 % of the LDS cycles
+// of the three launches (profiles/r02_c_pmc_lds.md) in a multiply loop that is bound by exactly those reads.
+inline int p2p_pitch(int J) { return 2 * J + 16; }
+
 // 8 -> 8 channel 7x7 pitch convolution on bf16 MFMA (conv_p2p_f16_kernel): channels-last split planes in, planes or NCHW f32 out
 int run_p2p_f16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const Src* nchw, int batch, int H, int T,
                  float* dst_nchw, int dst_ctot, unsigned short* oh, hipStream_t s, const char* name) {
@@ -459,7 +466,7 @@ int run_p2p_f16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
     a.oh = oh;
     a.H = H; a.T = T;
     a.J = (T + 1) / 2;
-    a.Tp = 2 * a.J + 6;
+    a.Tp = p2p_pitch(a.J);
     a.R = std::max(1, std::min(H, 8 * kP2pMT * 16 / a.J));
     auto lds_of = [&](int R) { return (static_cast<size_t>(R + 6) * a.Tp + (kP2pStreamB ? 0 : kBfFragsPerConv)) * sizeof(uint4); };
     while (a.R > 1 && lds_of(a.R) > 76 * 1024) --a.R;
@@ -497,7 +504,7 @@ int device_cus() {
 // semitone conv (tiles of 3k rows, no staging slabs but a double-buffered output patch)
 int p2p_ps_rows(int H, int T, bool semi, int* plane_pos, size_t* lds) {
     if (T < 2 || (T & 1) || device_cus() < 8) return 0;
-    const int J = T / 2, Tp = 2 * J + 6;
+    const int J = T / 2, Tp = p2p_pitch(J);
     auto plane_of = [&](int R) { return ((R + 6) * Tp + 63) / 64 * 64; };
     auto lds_of = [&](int R) { return (static_cast<size_t>(2) * plane_of(R) + (semi ? 2 * 8 * kP2pMT * 16 * 2 : 8 * kP2pMT * kP2pPsStage)) * sizeof(uint4); };
     int R = std::max(1, std::min(H, 8 * kP2pMT * 16 / J));
@@ -542,7 +549,7 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
         if (!dst_nchw || semi_pc->bf_off < 0) return false;
         a.sfrag = n->bf_frags_dev + semi_pc->bf_off; a.sbias = n->blob_dev + semi_pc->b_off;
     }
-    a.H = H; a.T = T; a.J = T / 2; a.Tp = 2 * a.J + 6;
+    a.H = H; a.T = T; a.J = T / 2; a.Tp = p2p_pitch(a.J);
     a.n_row_tiles = (H + a.R - 1) / a.R;
     a.n_tiles = a.n_row_tiles * batch;
     if (!semi_pc && a.n_tiles < 2 * n_cus) return false;
