@@ -42,6 +42,8 @@ SYMBOLS = {
     "ake_cqt_workspace_bytes": (_SZ, [_P, _I, _I64]),
     "ake_cqt_logmag_f32": (_I, [_P, _P, _I, _I64, _I64, _P, _I64, _P, _SZ, _P]),
     "ake_cqt_logmag_ragged_f32": (_I, [_P, _P, _I, _I64, _I64, _P, _P, _I64, _P, _SZ, _P]),
+    "ake_cqt_frames_major_supported": (_I, [_P]),
+    "ake_cqt_logmag_frames_major_f32": (_I, [_P, _P, _I, _I64, _I64, _P, _P, _SZ, _P]),
     "ake_pcnet_default_config": (_I, [C.POINTER(PcnetConfig), _I, _I]),
     "ake_pcnet_create": (_I, [C.POINTER(PcnetConfig), C.POINTER(_P)]),
     "ake_pcnet_destroy": (None, [_P]),
@@ -54,6 +56,8 @@ SYMBOLS = {
     "ake_pcnet_forward_f32": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "ake_pcnet_local_frames": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I)]),
     "ake_pcnet_forward_local_f32": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
+    "ake_pcnet_accepts_frames_major": (_I, [_P, _I, _I]),
+    "ake_pcnet_forward_frames_major_f32": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "ake_pcnet_num_bn": (_I, [_P]),
     "ake_pcnet_bn_info": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_I), C.POINTER(_I)]),
     "ake_pcnet_train_workspace_bytes": (_SZ, [_P, _I, _I]),

@@ -1123,7 +1123,7 @@ size_t ake_cqt_workspace_bytes(const ake_cqt_plan* p, int batch, int64_t n_sampl
 
 namespace {
 int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_t n, int64_t audio_stride, const int64_t* n_clip,
-                    float* out, int64_t out_frames, void* workspace, size_t ws_bytes, ake_stream_t stream_);
+                    float* out, int64_t out_frames, void* workspace, size_t ws_bytes, ake_stream_t stream_, bool frames_major = false);
 }
 
 extern "C" {
@@ -1131,6 +1131,14 @@ extern "C" {
 int ake_cqt_logmag_f32(const ake_cqt_plan* p, const float* audio, int batch, int64_t n, int64_t audio_stride,
                        float* out, int64_t out_frames, void* workspace, size_t ws_bytes, ake_stream_t stream_) {
     return cqt_logmag_impl(p, audio, batch, n, audio_stride, nullptr, out, out_frames, workspace, ws_bytes, stream_);
+}
+
+int ake_cqt_frames_major_supported(const ake_cqt_plan* p) { return p && p->engine == 3 ? 1 : 0; }
+
+int ake_cqt_logmag_frames_major_f32(const ake_cqt_plan* p, const float* audio, int batch, int64_t n, int64_t audio_stride, float* out,
+                                    void* workspace, size_t ws_bytes, ake_stream_t stream_) {
+    AKE_REQUIRE(p, AKE_ERR_INVALID, "ake_cqt_logmag_frames_major_f32: null plan");
+    return cqt_logmag_impl(p, audio, batch, n, audio_stride, nullptr, out, ake_cqt_num_frames(p, n), workspace, ws_bytes, stream_, true);
 }
 
 int ake_cqt_logmag_ragged_f32(const ake_cqt_plan* p, const float* audio, int batch, int64_t n_max, int64_t audio_stride,
@@ -1146,8 +1154,10 @@ int ake_cqt_logmag_ragged_f32(const ake_cqt_plan* p, const float* audio, int bat
 namespace {
 
 int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_t n, int64_t audio_stride, const int64_t* n_clip,
-                    float* out, int64_t out_frames, void* workspace, size_t ws_bytes, ake_stream_t stream_) {
+                    float* out, int64_t out_frames, void* workspace, size_t ws_bytes, ake_stream_t stream_, bool frames_major) {
     AKE_REQUIRE(p && audio && out, AKE_ERR_INVALID, "ake_cqt_logmag_f32: null argument");
+    // frames_major: leave the result as the filter bank writes it, [clip][frame][bin] (no transpose pass); engine 3, equal-length clips
+    AKE_REQUIRE(!frames_major || (p->engine == 3 && !n_clip), AKE_ERR_UNSUPPORTED, "cqt: the frames-major output needs engine 3 and equal-length clips");
     AKE_REQUIRE(batch > 0 && n > 0 && audio_stride >= n, AKE_ERR_INVALID, "cqt: bad batch/n_samples/stride");
     AKE_REQUIRE(n < (1ll << 30), AKE_ERR_INVALID, "cqt: clip too long (%lld samples)", static_cast<long long>(n));
     const int64_t T = ake_cqt_num_frames(p, n);
@@ -1325,7 +1335,7 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
             a.need[l] = 2 * need >= a.hop ? -1 : static_cast<int>(need);
         }
         launch_cascade(a);
-        scratch = c.take<float>(static_cast<size_t>(batch) * T * p->cfg.n_bins);
+        scratch = frames_major ? out : c.take<float>(static_cast<size_t>(batch) * T * p->cfg.n_bins);
         dim3 grid(static_cast<unsigned>((T + 7) / 8 * 8), p->n_oct, (batch + 255) / 256);
         ake::ProfScope ps("cqt_bank_bf16_kernel", stream);
         hipLaunchKernelGGL(cqt_bank_bf16_kernel, grid, dim3(1024), p->bank2_lds, stream, call2, p->octs2_dev, p->table2_dev, batch,
@@ -1376,6 +1386,10 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
         ake::ProfScope ps("cqt_bank_kernel", stream);
         hipLaunchKernelGGL(cqt_bank_kernel, grid, dim3(256), 0, stream, call, p->octs_dev, p->table_dev, batch,
                            p->cfg.hop_length, p->hop_twos, scratch, static_cast<long long>(T) * p->cfg.n_bins, p->cfg.n_bins);
+    }
+    if (frames_major) {
+        AKE_HIP_CHECK(hipGetLastError());
+        return AKE_OK;
     }
     {
         dim3 grid((p->cfg.n_bins + 31) / 32, static_cast<unsigned>((out_frames + 31) / 32), batch);

@@ -529,8 +529,10 @@ bool p2p_fuses_semi(const ake_pcnet* n, int i, int P, int T) {
 // frame counts and enough tiles to give every CU at least two (always when `semi_pc` asks for the fused semitone conv: `dst` then
 // receives the semitone maps [clip][8][H / 3][T]); returns false when the shape does not qualify (the caller then launches
 // conv_p2p_f16_kernel)
+// p_frames_major: the one pitch-stream channel of `nchw` is stored [clip][T][H] (ake_pcnet_forward_frames_major_f32)
 bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const Src* nchw, int batch, int H, int T, float* dst_nchw,
-                     int dst_ctot, unsigned short* oh, const PackedConv* semi_pc, hipStream_t s, const char* name) {
+                     int dst_ctot, unsigned short* oh, const PackedConv* semi_pc, hipStream_t s, const char* name, bool p_frames_major = false,
+                     bool dry_run = false) {
     static const bool off = std::getenv("AKE_P2P_PS") != nullptr && std::atoi(std::getenv("AKE_P2P_PS")) == 0;
     if (off) return false;
     P2pPsArgs a;
@@ -543,7 +545,9 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
     if (nchw) {
         if (dst_nchw || nchw->c0 < 1 || nchw->c0 + nchw->c1 > 8) return false;
         a.p = nchw->p0; a.c0 = nchw->c0; a.u = nchw->p1 ? nchw->p1 : nchw->p0; a.c1 = nchw->p1 ? nchw->c1 : 0; a.h1 = nchw->h1 > 0 ? nchw->h1 : 1;
-    }
+        if (p_frames_major && nchw->c0 != 1) return false;
+        a.p_fm = p_frames_major ? 1 : 0;
+    } else if (p_frames_major) return false;
     a.dst = dst_nchw; a.dst_clip_stride = static_cast<long long>(dst_ctot) * (semi_pc ? H / 3 : H) * T; a.oh = oh;
     if (semi_pc) {
         if (!dst_nchw || semi_pc->bf_off < 0) return false;
@@ -567,6 +571,7 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
     }
     // two workgroups per CU when the LDS allows it (the kernel is built for 4 waves per SIMD): one's epilogue (vector work) and
     // barrier waits run under the other's multiply loop (bound by its LDS reads)
+    if (dry_run) return true;                          // (the eligibility question of ake_pcnet_accepts_frames_major)
     static const int wg_per_cu_env = std::getenv("AKE_P2P_WG_PER_CU") ? std::atoi(std::getenv("AKE_P2P_WG_PER_CU")) : 2;
     const int wg_per_cu = (wg_per_cu_env >= 2 && !nchw && lds <= 80 * 1024 && a.n_tiles >= 4 * n_cus) ? 2 : 1;
     dim3 grid(std::min(wg_per_cu * (n_cus / 8 * 8), (a.n_tiles + 7) / 8 * 8)), block(512);
@@ -1546,6 +1551,7 @@ struct Fwd {
     Buffers& b;
     hipStream_t s;
     bool train;
+    bool mel_fm = false;             // mel is frames-major [clip][T][P] (ake_pcnet_forward_frames_major_f32): only the fused default path can read it
 
     int bn_of(const std::string& name) const { return n->bn_index.at(name); }
 
@@ -1753,7 +1759,7 @@ struct Fwd {
     }
 
     // inference, default family: the whole of phase A as one launch, one workgroup per clip (layer0_fused_kernel)
-    bool layer0_fused(const float* mel, int B) {
+    bool layer0_fused(const float* mel, int B, bool dry_run = false) {
         static const bool off = std::getenv("AKE_L0_FUSED") != nullptr && std::atoi(std::getenv("AKE_L0_FUSED")) == 0;
         const auto& c = n->cfg;
         const int P = c.pitches, T0 = b.Tl[0], NF = c.n_filters;
@@ -1798,8 +1804,12 @@ struct Fwd {
         }
         a.RPp = (T0 + 8 + 1) / 2 * 2;
         const size_t lds_m = (static_cast<size_t>(4) * 12 * a.RP + static_cast<size_t>(2) * 12 * a.RPp * 4 + static_cast<size_t>(P) * T0) * sizeof(float);
+        const bool take_mfma = mfma && lds_m <= 150 * 1024;
+        if (mel_fm && (!take_mfma || P % 4)) return false;        // only the MFMA form's loader transposes
+        if (dry_run) return true;
+        a.mel_fm = mel_fm ? 1 : 0;
         ake::ProfScope ps("layer0_fused_kernel", s);
-        if (mfma && lds_m <= 150 * 1024) hipLaunchKernelGGL(layer0_mfma_kernel, dim3(B), dim3(512), lds_m, s, a);
+        if (take_mfma) hipLaunchKernelGGL(layer0_mfma_kernel, dim3(B), dim3(512), lds_m, s, a);
         else hipLaunchKernelGGL(layer0_fused_kernel, dim3(B), dim3(512), lds, s, a);
         return true;
     }
@@ -1810,6 +1820,7 @@ struct Fwd {
         const int L = c.num_layers, P = c.pitches, T0 = b.Tl[0];
         int rc;
         if (!train && L > 1 && layer0_fused(mel, B)) return AKE_OK;
+        AKE_REQUIRE(!mel_fm, AKE_ERR_UNSUPPORTED, "pcnet: this configuration does not take the frames-major input (ake_pcnet_accepts_frames_major)");
         if (c.stay_sixth && L > 1) {   // models.py:366-367: the activated semitone map is the pitch stream from here on; its fold feeds pc2pc
             if ((rc = semi_map(0, mel, B, P, T0, b.p0, false))) return rc;
             if ((rc = fold_maps(0, b.p0, 1, P / 3, B, T0, b.fold0, 1, 0))) return rc;
@@ -1926,6 +1937,8 @@ struct Fwd {
             // inference: the stack runs on f16 MFMA (f16 activations x hi + lo f16 weights, see conv_p2p_f16_kernel); the activations
             // between its convs are ONE channels-last f16 plane (16 B per position) in the same ping-pong buffers
             const bool bf = !train && p2p_uses_f16(n, i, Ti);
+            AKE_REQUIRE(!mel_fm || (bf && i == 1 && L == 2 && !c.resblock && !c.pc2p_mem && !c.stay_sixth), AKE_ERR_UNSUPPORTED,
+                        "pcnet: this configuration does not take the frames-major input (ake_pcnet_accepts_frames_major)");
             bool fused_semi = false;
             if (c.resblock) {
                 if ((rc = res_stack(n->p2p[i], 0, sdesc, B, P, Ti, b.pa[i], b.pb[i], nullptr, 0, "conv_mfma_kernel/p2p"))) return rc;
@@ -1938,7 +1951,8 @@ struct Fwd {
                     unsigned short* oh = reinterpret_cast<unsigned short*>(out);
                     const bool last_conv = j == c.conv_layers - 1;
                     if (j == 0) {   // the stack's input (pitch stream | repeated up_sixth output) is assembled by the kernel's own loader
-                        if (run_p2p_f16_ps(n, n->p2p[i][0], nullptr, &sdesc, B, P, Ti, nullptr, d.out_p, oh, nullptr, s, "conv_p2p_f16_kernel")) continue;
+                        if (run_p2p_f16_ps(n, n->p2p[i][0], nullptr, &sdesc, B, P, Ti, nullptr, d.out_p, oh, nullptr, s, "conv_p2p_f16_kernel", mel_fm && i == 1)) continue;
+                        AKE_REQUIRE(!mel_fm, AKE_ERR_UNSUPPORTED, "pcnet: this shape does not take the frames-major input (ake_pcnet_accepts_frames_major)");
                         if ((rc = run_p2p_f16(n, n->p2p[i][0], nullptr, &sdesc, B, P, Ti, nullptr, d.out_p, oh, s, "conv_p2p_f16_kernel")))
                             return rc;
                     } else {
@@ -2182,7 +2196,8 @@ struct Fwd {
 };
 
 int forward_impl(const ake_pcnet* n, bool train, const float* mel, int batch, int frames, const int64_t* seq_length, float* key_out,
-                 float* tonic_out, float* genre_out, float* bn_stats_out, void* workspace, size_t ws_bytes, ake_stream_t stream) {
+                 float* tonic_out, float* genre_out, float* bn_stats_out, void* workspace, size_t ws_bytes, ake_stream_t stream,
+                 bool mel_frames_major = false, bool dry_run = false) {
     AKE_REQUIRE(n && mel && key_out && tonic_out, AKE_ERR_INVALID, "pcnet forward: null argument");
     AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
     AKE_REQUIRE(batch > 0 && frames > 0, AKE_ERR_INVALID, "pcnet: bad batch/frames");
@@ -2195,6 +2210,18 @@ int forward_impl(const ake_pcnet* n, bool train, const float* mel, int batch, in
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (train) AKE_HIP_CHECK(hipMemsetAsync(b.stats, 0, sizeof(double) * 2 * n->bn_channels * kStatSlots, s));
     Fwd f{n, b, s, train};
+    f.mel_fm = mel_frames_major;
+    if (dry_run) {   // ake_pcnet_accepts_frames_major: would the two readers of mel take that layout for this shape?  (no launch)
+        const auto& c = n->cfg;
+        if (train || c.num_layers != 2 || c.resblock || c.denseblock || c.pc2p_mem || c.p2pc_conv || c.stay_sixth || c.local ||
+            batch > chunk || !p2p_uses_f16(n, 1, b.Tl[1]))
+            return AKE_ERR_UNSUPPORTED;
+        if (!f.layer0_fused(mel, batch, true)) return AKE_ERR_UNSUPPORTED;
+        const LayerDims& d = n->dims[1];
+        Src sdesc{mel, 1, b.psix[1], d.prev_pc, 36};
+        return run_p2p_f16_ps(n, n->p2p[1][0], nullptr, &sdesc, batch, c.pitches, b.Tl[1], nullptr, d.out_p, reinterpret_cast<unsigned short*>(b.pa[1]), nullptr, s,
+                              "conv_p2p_f16_kernel", true, true) ? AKE_OK : AKE_ERR_UNSUPPORTED;
+    }
     if ((rc = f.entry(mel, batch))) return rc;
     for (int c0 = 0; c0 < batch && n->cfg.num_layers > 1; c0 += chunk) {
         const int B = std::min(chunk, batch - c0);
@@ -2268,6 +2295,27 @@ int ake_pcnet_forward_f32(const ake_pcnet* n, const float* mel, int batch, int f
                           ake_stream_t stream) {
     AKE_REQUIRE(!n || n->cfg.local == 0, AKE_ERR_STATE, "pcnet: a --local net returns per-frame outputs: call ake_pcnet_forward_local_f32");
     return forward_impl(n, false, mel, batch, frames, seq_length, key_out, tonic_out, genre_out, nullptr, workspace, ws_bytes, stream);
+}
+
+// mel as the CQT filter bank writes it, [batch][frames][pitches] (ake_cqt_logmag_frames_major_f32): the two kernels that read the CQT
+// (layer 0 and the first pitch convolution) transpose while they stage it, so the [batch][pitches][frames] tensor of the
+// reference's interface -- a 48 MB round trip per 256 clips -- is never written.  Taken by the default architecture on the fused
+// inference path only: ask ake_pcnet_accepts_frames_major first (other configurations return AKE_ERR_UNSUPPORTED).
+int ake_pcnet_accepts_frames_major(const ake_pcnet* n, int batch, int frames) {
+    if (!n || !n->finalized || batch <= 0 || frames <= 0) return 0;
+    float dummy = 0.f;           // never dereferenced: the dry run stops before any launch
+    Buffers b;
+    if (plan_buffers(n, batch, std::min(batch, n->chunk_clips), frames, nullptr, &b, false) != AKE_OK) return 0;
+    const int rc = forward_impl(n, false, reinterpret_cast<const float*>(16), batch, frames, nullptr, &dummy, &dummy, &dummy, nullptr,
+                                reinterpret_cast<void*>(16), b.bytes, nullptr, true, true);
+    return rc == AKE_OK ? 1 : 0;
+}
+
+int ake_pcnet_forward_frames_major_f32(const ake_pcnet* n, const float* mel_fm, int batch, int frames, const int64_t* seq_length,
+                                       float* key_out, float* tonic_out, float* genre_out, void* workspace, size_t ws_bytes,
+                                       ake_stream_t stream) {
+    AKE_REQUIRE(!n || n->cfg.local == 0, AKE_ERR_UNSUPPORTED, "pcnet: a --local net does not take the frames-major input");
+    return forward_impl(n, false, mel_fm, batch, frames, seq_length, key_out, tonic_out, genre_out, nullptr, workspace, ws_bytes, stream, true);
 }
 
 int ake_pcnet_forward_train_f32(const ake_pcnet* n, const float* mel, int batch, int frames, const int64_t* seq_length,

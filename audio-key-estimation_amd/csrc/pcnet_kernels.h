@@ -807,6 +807,7 @@ struct P2pPsArgs {
     const float* p;               // IN_NCHW == true: the stack's input is assembled by the loader, as in conv_p2p_f16_kernel
     const float* u;
     int c0, c1, h1;
+    int p_fm;                     // p is ONE channel stored frames-major, [clip][T][H] (the CQT filter bank's own output order)
     const uint4* bfrag;           // [14 k-steps][hi|lo * 2^11][64 lanes] x 8 f16
     const float* bias;            // [8]
     float* dst;                   // OUT == 0: NCHW f32 [clip][dst_ctot][H][T];  OUT == 2: semitone maps [clip][8][H / 3][T]
@@ -906,7 +907,10 @@ __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel
             row += row < 0 ? a.H : 0;
             row -= row >= a.H ? a.H : 0;
             const int t = pn[k] & 0xffff;
-            const float* pp = a.p + (static_cast<long long>(clip) * a.c0 * a.H + row) * T + t;
+            // (frames-major p: one 64-byte line holds 16 bins of a frame = this tile's rows; the lanes of a request walk the frames, so
+            // it costs a cache line per lane in the texture addresser, but every line is read 16 times from the L1)
+            const float* pp = a.p_fm ? a.p + (static_cast<long long>(clip) * T + t) * a.H + row
+                                     : a.p + (static_cast<long long>(clip) * a.c0 * a.H + row) * T + t;
             const float* pu = a.u + (static_cast<long long>(clip) * a.c1 * a.h1 + row % a.h1) * T + t;
 #pragma unroll
             for (int c = 0; c < NV; ++c) {
@@ -1814,6 +1818,7 @@ struct Layer0Args {
     int H, T, RP, NF, n_conv;    // RP: LDS row pitch in floats (T + 6 rounded up to 4)
     const uint4* frag[4];        // layer0_mfma_kernel: B fragments of the convs [12 dy][hi|lo][64 lanes] x 8 bf16 (pack_l0_bf16_kernel)
     int RPp;                     // layer0_mfma_kernel: row pitch of the channels-last maps, in positions (even, >= T + 8)
+    int mel_fm;                  // layer0_mfma_kernel: mel is frames-major, [clip][T][H] (the CQT filter bank's own output order)
 };
 
 __global__ __launch_bounds__(512) void layer0_fused_kernel(Layer0Args a) {
@@ -2021,7 +2026,15 @@ __global__ __launch_bounds__(512) void layer0_mfma_kernel(Layer0Args a) {
     {
         const float4* mel4 = reinterpret_cast<const float4*>(a.mel + static_cast<long long>(clip) * a.H * T);
         const int n4 = a.H * T / 4;
-        for (int i = tid; i < n4; i += 512) reinterpret_cast<float4*>(ml)[i] = mel4[i];
+        if (a.mel_fm) {          // [T][H] -> the [H][T] image: 16-byte reads along the bins, transposed on the way into the LDS
+            const int h4 = a.H / 4;
+            for (int i = tid; i < n4; i += 512) {
+                const int t = i / h4, r4 = (i - t * h4) * 4;
+                const float4 v = mel4[i];
+                ml[(r4 + 0) * T + t] = v.x; ml[(r4 + 1) * T + t] = v.y; ml[(r4 + 2) * T + t] = v.z; ml[(r4 + 3) * T + t] = v.w;
+            }
+        } else
+            for (int i = tid; i < n4; i += 512) reinterpret_cast<float4*>(ml)[i] = mel4[i];
         __syncthreads();
         float w9[9];
 #pragma unroll

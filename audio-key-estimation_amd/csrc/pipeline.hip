@@ -88,7 +88,12 @@ static int pipeline_impl(const ake_cqt_plan* plan, const ake_pcnet* net, const f
     AKE_REQUIRE(workspace && workspace_bytes >= pc.total, AKE_ERR_WORKSPACE, "pipeline: workspace %zu < %zu bytes", workspace_bytes, pc.total);
     const int64_t T = ake_cqt_num_frames(plan, n_samples);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // equal-length clips through the default net: the CQT stays in the filter bank's own [clip][frame][bin] order and the net's two
+    // readers transpose while they stage it -- no transpose pass, same results bit for bit (AKE_PIPE_FRAMES_MAJOR=0 switches it off)
+    static const bool fm_off = std::getenv("AKE_PIPE_FRAMES_MAJOR") != nullptr && std::atoi(std::getenv("AKE_PIPE_FRAMES_MAJOR")) == 0;
+    const bool fm = !fm_off && !n_clip_dev && ake_cqt_frames_major_supported(plan) && ake_pcnet_accepts_frames_major(net, batch, static_cast<int>(T));
     rc = n_clip_dev ? ake_cqt_logmag_ragged_f32(plan, audio_dev, batch, n_samples, audio_stride, n_clip_dev, pc.mel, T, pc.cqt_ws, pc.cqt_bytes, stream)
+         : fm       ? ake_cqt_logmag_frames_major_f32(plan, audio_dev, batch, n_samples, audio_stride, pc.mel, pc.cqt_ws, pc.cqt_bytes, stream)
                     : ake_cqt_logmag_f32(plan, audio_dev, batch, n_samples, audio_stride, pc.mel, T, pc.cqt_ws, pc.cqt_bytes, stream);
     if (rc) return rc;
     if (n_clip_dev)   // seq_length of every clip = its own frame count (KeyDataset.py:248: mel.shape[2] before padding)
@@ -96,6 +101,9 @@ static int pipeline_impl(const ake_cqt_plan* plan, const ake_pcnet* net, const f
                            static_cast<long long>(T), batch);
     else
         hipLaunchKernelGGL(fill_i64_kernel, dim3((batch + 255) / 256), dim3(256), 0, s, pc.seq, static_cast<long long>(T), batch);
+    if (fm)
+        return ake_pcnet_forward_frames_major_f32(net, pc.mel, batch, static_cast<int>(T), reinterpret_cast<const int64_t*>(pc.seq), key_out_dev,
+                                                  tonic_out_dev, genre_out_dev, pc.net_ws, pc.net_bytes, stream);
     return ake_pcnet_forward_f32(net, pc.mel, batch, static_cast<int>(T), reinterpret_cast<const int64_t*>(pc.seq), key_out_dev,
                                  tonic_out_dev, genre_out_dev, pc.net_ws, pc.net_bytes, stream);
 }

@@ -92,6 +92,14 @@ int ake_cqt_logmag_ragged_f32(const ake_cqt_plan* plan, const float* audio_dev, 
                               int64_t audio_stride, const int64_t* n_samples_dev, float* out_dev, int64_t out_frames,
                               void* workspace, size_t workspace_bytes, ake_stream_t stream);
 
+/* Frames-major output: the same transform left as the filter bank writes it, out_dev = [batch][num_frames][n_bins] -- no transpose
+ * pass (a 48 MB round trip per 256 clips).  For consumers that can read that order: ake_pcnet_forward_frames_major_f32, and
+ * ake_pipeline_forward_f32 uses the pair internally.  Engine 3, equal-length clips (ake_cqt_frames_major_supported). */
+int ake_cqt_frames_major_supported(const ake_cqt_plan* plan);
+int ake_cqt_logmag_frames_major_f32(const ake_cqt_plan* plan, const float* audio_dev, int batch, int64_t n_samples,
+                                    int64_t audio_stride, float* out_dev, void* workspace, size_t workspace_bytes,
+                                    ake_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * PitchClassNet forward (inference: eval-mode BatchNorm folded into the convolutions).
  * Replaces  PitchClassNet.forward(mel, seq_length)   models.py:747-817
@@ -168,6 +176,15 @@ int ake_pcnet_forward_f32(const ake_pcnet* net, const float* mel_dev, int batch,
  *   key_out_dev, tonic_out_dev : [batch][12 * Tq]   sliding max over W frames of the head maps; sigmoid on key
  *   genre_out_dev              : [batch][11 * Tm]   the genre head's map */
 int ake_pcnet_local_frames(const ake_pcnet* net, int frames, int* pooled_frames, int* map_frames);
+/* The forward with mel as ake_cqt_logmag_frames_major_f32 leaves it, [batch][frames][pitches]: the two kernels that read the CQT (layer 0
+ * and the first pitch convolution) transpose while staging.  Only the default architecture on the fused inference path takes it:
+ * ake_pcnet_accepts_frames_major(net, batch, frames) != 0; otherwise AKE_ERR_UNSUPPORTED.  Same results as ake_pcnet_forward_f32 on the
+ * transposed tensor, bit for bit. */
+int ake_pcnet_accepts_frames_major(const ake_pcnet* net, int batch, int frames);
+int ake_pcnet_forward_frames_major_f32(const ake_pcnet* net, const float* mel_frames_major_dev, int batch, int frames,
+                                       const int64_t* seq_length_dev, float* key_out_dev, float* tonic_out_dev, float* genre_out_dev,
+                                       void* workspace, size_t workspace_bytes, ake_stream_t stream);
+
 int ake_pcnet_forward_local_f32(const ake_pcnet* net, const float* mel_dev, int batch, int frames, float* key_out_dev,
                                 float* tonic_out_dev, float* genre_out_dev, void* workspace, size_t workspace_bytes,
                                 ake_stream_t stream);

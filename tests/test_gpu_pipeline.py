@@ -46,6 +46,47 @@ def test_pipeline_equals_cqt_then_forward_and_oracle(net, gold_default):
         assert rel_err(a.cpu(), b) < 1e-3
 
 
+def test_frames_major_path_is_bit_identical_and_skips_the_transpose(net):
+    """for equal-length clips through the default net, ake_pipeline_forward_f32 leaves the CQT in the filter
+    bank's [clip][frame][bin] order (ake_cqt_logmag_frames_major_f32) and the net's two readers transpose while staging
+    (ake_pcnet_forward_frames_major_f32): no cqt_transpose_kernel, results equal to transpose + ake_pcnet_forward_f32 bit for bit."""
+    import ctypes as C
+    L = ake_amd._lib.lib()
+    B, T = 64, 76
+    audio = synthetic.make_batch_device(range(B), torch.device(DEV))[0]
+    est = ake_amd.KeyEstimator(net, 22050, 5)
+    mel = est.plan.logmag(audio)                                          # [B][288][T], through the transpose
+    k2, t2, g2 = net(mel[:, None], torch.full((B,), T, device=DEV))
+    assert L.ake_cqt_frames_major_supported(est.plan.handle) == 1
+    assert L.ake_pcnet_accepts_frames_major(net._h, B, T) == 1
+    assert L.ake_pcnet_accepts_frames_major(net._h, 2, T) == 0            # too few tiles for the persistent pitch conv: the plain route
+    assert L.ake_pcnet_accepts_frames_major(net._h, B, T + 1) == 0        # odd frame count
+    ake_amd._lib.prof_enable("", True)
+    key, tonic, genre = est(audio)
+    res = ake_amd._lib.prof_results()
+    ake_amd._lib.prof_enable("", False)
+    assert "cqt_transpose_kernel" not in res and "cqt_bank_bf16_kernel" in res
+    assert torch.equal(key, k2) and torch.equal(tonic, t2) and torch.equal(genre, g2)
+    # the two halves on their own
+    mel_fm = torch.empty((B, T, 288), dtype=torch.float32, device=DEV)
+    nbytes = L.ake_cqt_workspace_bytes(est.plan.handle, B, audio.shape[1])
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    ake_amd._lib.check(L.ake_cqt_logmag_frames_major_f32(est.plan.handle, audio.data_ptr(), B, audio.shape[1], audio.stride(0), mel_fm.data_ptr(),
+                                                         ws.data_ptr(), ws.numel(), stream), "ake_cqt_logmag_frames_major_f32")
+    assert torch.equal(mel_fm.transpose(1, 2), mel)
+    seq = torch.full((B,), T, dtype=torch.int64, device=DEV)
+    outs = [torch.empty((B, n), dtype=torch.float32, device=DEV) for n in (12, 12, 11)]
+    ws2 = torch.empty(L.ake_pcnet_workspace_bytes(net._h, B, T), dtype=torch.uint8, device=DEV)
+    ake_amd._lib.check(L.ake_pcnet_forward_frames_major_f32(net._h, mel_fm.data_ptr(), B, T, seq.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(),
+                                                            outs[2].data_ptr(), ws2.data_ptr(), ws2.numel(), stream), "ake_pcnet_forward_frames_major_f32")
+    assert torch.equal(outs[0], k2) and torch.equal(outs[1], t2) and torch.equal(outs[2], g2)
+    # a shape that cannot take the layout is refused instead of being read wrongly (2 clips: the per-tile pitch conv would run)
+    assert L.ake_pcnet_forward_frames_major_f32(net._h, mel_fm.data_ptr(), 2, T, seq.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(),
+                                                outs[2].data_ptr(), ws2.data_ptr(), ws2.numel(), stream) != 0
+    assert b"frames-major" in L.ake_last_error()
+
+
 def test_ragged_pipeline_equals_per_clip_pipeline(net):
     """ake_pipeline_forward_ragged_f32: every clip of a ragged batch is transformed on its own samples and pooled over its own frames
     (seq_length = 1 + n_i // hop, on the device): the same answer as the KeyDataset route -- per-clip CQT, zero padding to the longest
