@@ -1715,7 +1715,7 @@ __device__ __forceinline__ float f16_weight_scale(float wmax) {
     if (!(wmax > 0.f) || !(wmax < INFINITY)) return 1.f;
     int e;
     frexpf(wmax, &e);                                         // wmax = m * 2^e, m in [0.5, 1)
-    return ldexpf(1.f, 14 - e);
+    return ldexpf(1.f, 14 - e < 100 ? 14 - e : 100);          // (a channel of f32 denormals: the scale itself must stay finite)
 }
 
 // max |w| of each of the 8 output channels of a pack [n_k][8 co], by the whole block (bit patterns of non-negative floats order as ints)
