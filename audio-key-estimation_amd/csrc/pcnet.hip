@@ -530,9 +530,11 @@ bool p2p_fuses_semi(const ake_pcnet* n, int i, int P, int T) {
 // receives the semitone maps [clip][8][H / 3][T]); returns false when the shape does not qualify (the caller then launches
 // conv_p2p_f16_kernel)
 // p_frames_major: the one pitch-stream channel of `nchw` is stored [clip][T][H] (ake_pcnet_forward_frames_major_f32)
+// fold_coff >= 0 (with semi_pc): the fused semitone launch also takes the maximum over the octaves and writes channels
+// [fold_coff, fold_coff + 8) of the concat buffer dst_nchw [clip][dst_ctot][12][T] (OUT = 3); false when the shape does not allow it
 bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const Src* nchw, int batch, int H, int T, float* dst_nchw,
                      int dst_ctot, unsigned short* oh, const PackedConv* semi_pc, hipStream_t s, const char* name, bool p_frames_major = false,
-                     bool dry_run = false) {
+                     bool dry_run = false, int fold_coff = -1) {
     static const bool off = std::getenv("AKE_P2P_PS") != nullptr && std::atoi(std::getenv("AKE_P2P_PS")) == 0;
     if (off) return false;
     P2pPsArgs a;
@@ -556,13 +558,24 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
     a.H = H; a.T = T; a.J = T / 2; a.Tp = p2p_pitch(a.J);
     a.n_row_tiles = (H + a.R - 1) / a.R;
     a.n_tiles = a.n_row_tiles * batch;
+    static const bool fold_off = std::getenv("AKE_P2P_FOLD") != nullptr && std::atoi(std::getenv("AKE_P2P_FOLD")) == 0;
+    const bool fold = fold_coff >= 0;
+    if (fold && fold_off) return false;
+    if (fold) {
+        if (!semi_pc || H % 36 || 36 % a.R) return false;
+        a.n_oct = H / 36; a.n_units = batch * (36 / a.R);
+        if (a.n_units < 4 * n_cus) return false;                      // a unit is n_oct tiles in a row: small batches keep the tile-parallel form
+        a.dst = dst_nchw + static_cast<long long>(fold_coff) * 12 * T;
+        a.dst_clip_stride = static_cast<long long>(dst_ctot) * 12 * T;
+    }
     if (!semi_pc && a.n_tiles < 2 * n_cus) return false;
     if (dst_nchw && !semi_pc) {   // 16-byte stores of 4 consecutive frames
         if ((a.R * T) % 4 || (static_cast<long long>(H) * T) % 4 || a.dst_clip_stride % 4 || (reinterpret_cast<uintptr_t>(dst_nchw) & 15)) return false;
     }
     static ake::DeviceOnce attr_set;
     if (attr_set.need()) {
-        const void* fns[] = {reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<1, 0>), reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<1, 5>),
+        const void* fns[] = {reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<3, 0>),
+                             reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<1, 0>), reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<1, 5>),
                              reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<1, 8>), reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<0, 0>),
                              reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<2, 0>), reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<1, 0, true>)};
         for (const void* f : fns)
@@ -576,7 +589,8 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
     const int wg_per_cu = (wg_per_cu_env >= 2 && !nchw && lds <= 80 * 1024 && a.n_tiles >= 4 * n_cus) ? 2 : 1;
     dim3 grid(std::min(wg_per_cu * (n_cus / 8 * 8), (a.n_tiles + 7) / 8 * 8)), block(512);
     ake::ProfScope ps(name, s);
-    if (semi_pc) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<2, 0>), grid, block, lds, s, a);
+    if (fold) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<3, 0>), grid, block, lds, s, a);
+    else if (semi_pc) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<2, 0>), grid, block, lds, s, a);
     else if (dst_nchw) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<0, 0>), grid, block, lds, s, a);
     else if (nchw && a.c0 + a.c1 <= 5) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<1, 5>), grid, block, lds, s, a);
     else if (nchw) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<1, 8>), grid, block, lds, s, a);
@@ -1939,7 +1953,7 @@ struct Fwd {
             const bool bf = !train && p2p_uses_f16(n, i, Ti);
             AKE_REQUIRE(!mel_fm || (bf && i == 1 && L == 2 && !c.resblock && !c.pc2p_mem && !c.stay_sixth), AKE_ERR_UNSUPPORTED,
                         "pcnet: this configuration does not take the frames-major input (ake_pcnet_accepts_frames_major)");
-            bool fused_semi = false;
+            bool fused_semi = false, fused_fold = false;
             if (c.resblock) {
                 if ((rc = res_stack(n->p2p[i], 0, sdesc, B, P, Ti, b.pa[i], b.pb[i], nullptr, 0, "conv_mfma_kernel/p2p"))) return rc;
                 out = b.pa[i];
@@ -1957,6 +1971,12 @@ struct Fwd {
                             return rc;
                     } else {
                         const unsigned short* xh = reinterpret_cast<const unsigned short*>(((j - 1) & 1) ? b.pb[i] : b.pa[i]);
+                        if (last_conv && p2p_fuses_semi(n, i, P, Ti) &&
+                            run_p2p_f16_ps(n, n->p2p[i][j], xh, nullptr, B, P, Ti, cat, ctot, nullptr, &n->semi[i], s, "conv_p2p_f16_kernel", false, false,
+                                           d.prev_pc)) {
+                            fused_semi = fused_fold = true;    // semitone conv AND octave fold inside the launch: the folded maps are in `cat`
+                            continue;
+                        }
                         if (last_conv && p2p_fuses_semi(n, i, P, Ti) &&
                             run_p2p_f16_ps(n, n->p2p[i][j], xh, nullptr, B, P, Ti, out, d.out_p, nullptr, &n->semi[i], s, "conv_p2p_f16_kernel")) {
                             fused_semi = true;    // `out` holds the semitone maps [clip][8][P / 3][T], not the pitch tensor
@@ -1978,7 +1998,8 @@ struct Fwd {
                 in_aff = out_aff;
             }
             // models.py:386-392  pool_semi -> fold, written next to pc in the concat buffer
-            if (fused_semi) {
+            if (fused_fold) {
+            } else if (fused_semi) {
                 if ((rc = run_fold_max(out, d.out_p, P / 3, B, Ti, cat, ctot, d.prev_pc, s))) return rc;
             } else if (c.stay_sixth) {   // models.py:391: the stack's output is folded as it is (no semitone conv)
                 if ((rc = fold_maps(i, out, d.out_p, P, B, Ti, cat, ctot, d.prev_pc))) return rc;

@@ -816,6 +816,7 @@ struct P2pPsArgs {
     const uint4* sfrag;           // OUT == 2: B fragments of the semitone conv [3 dy][hi|lo * 2^11][64 lanes] x 8 f16, and its bias [8]
     const float* sbias;
     int H, T, R, J, Tp, n_row_tiles, n_tiles, plane_pos;   // plane_pos: (R + 6) * Tp rounded up to 64 positions
+    int n_oct, n_units;           // OUT == 3: octaves (H / 36) and work units (clip, group of R rows within an octave) = batch * 36 / R
     unsigned long long* stamps;   // diagnostic build (AKE_P2P_STAMP): [8 waves][8] cycle sums of the tile loop's sections, workgroup 0
 };
 
@@ -833,11 +834,15 @@ constexpr int kP2pPsStage = 80;      // uint4 per M-tile of a wave's staging sla
 //   stays in LDS as an f16 plane [m][tau][8 ch] = position-major, the semitone conv runs over it on the same MFMA form
 //   (m = (semitone row, frame pair), n = (tau, co), k-step = one of its 3 rows: 4 positions x 8 channels, the 4th tap zero), one
 //   M-tile per wave, and only the semitone maps [clip][8][H / 3][T] go to memory: the 8 x H x T pitch tensor is never written.
+//   OUT 3 = OUT 2 + Pitch2PitchClassPool (models.py:95-106): a workgroup walks the SAME rows of all octaves one after the other (its work
+//   unit = (clip, group of R rows within an octave), tiles 36 rows apart), keeps the running maximum of the semitone outputs in
+//   registers and writes the folded maps [clip][dst channel][12][T] once per unit: neither the semitone maps (60 MB per 256 clips) nor
+//   a fold launch exist.
 // NIN: 0 = channels-last f16 plane in; else the number of f32 channels the loader assembles (5: default net, 8: any)
 // STAMP: diagnostic build with s_memtime stamps around the tile loop's sections (tools/p2p_stamp.py; shares, never timed)
 template <int OUT, int NIN, bool STAMP = false>
 __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {   // (the assembling loader's 15 input registers do not fit 128)
-    constexpr bool OUT_CL = OUT == 1, OUT_SEMI = OUT == 2;
+    constexpr bool OUT_CL = OUT == 1, OUT_SEMI = OUT == 2 || OUT == 3, OUT_FOLD = OUT == 3;
     constexpr bool IN_NCHW = NIN > 0;
     constexpr int NV = IN_NCHW ? NIN : 1;
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
@@ -936,9 +941,13 @@ __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel
             if (i < npos) wH[i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
         }
     };
-    if (first < a.n_tiles) {
-        if (IN_NCHW) { load_regs(first); write_lds(0); }
-        else issue_loads(first, 0);
+    // tile sequence: first, first + nwg, ...; OUT 3: units first, first + nwg, ..., each the n_oct tiles (clip, octave o, group g)
+    const int G = OUT_FOLD ? a.n_row_tiles / a.n_oct : 1;
+    auto fold_tile = [&](int u, int o) { const int clip = u / G; return clip * a.n_row_tiles + o * G + (u - clip * G); };
+    const int tile0 = OUT_FOLD ? (first < a.n_units ? fold_tile(first, 0) : -1) : (first < a.n_tiles ? first : -1);
+    if (tile0 >= 0) {
+        if (IN_NCHW) { load_regs(tile0); write_lds(0); }
+        else issue_loads(tile0, 0);
     }
     // ---- weight fragments: registers, for the whole launch ----
     uint4 breg[28];                  // (kP2pProducts == 1: the lo halves are never used and never loaded)
@@ -1034,7 +1043,8 @@ __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel
         const int srow = ms / J, sj = ms - srow * J;
         sbase = 3 * srow * T + wrap(2 * sj - 1 + q, T);               // A[m][k = (position q, ci)] = X[3s + dy][2j - 1 + q][ci]
     }
-    auto semi_stage = [&](int obuf, long long base, int mblk) {      // base: element offset of (clip, channel 0, first semitone row) in dst
+    float smax[4] = {0.f, 0.f, 0.f, 0.f};                             // OUT 3: running maximum over the octaves of a unit
+    auto semi_stage = [&](int obuf, long long base, int mblk, int oct) {   // base: element offset of (clip, channel 0, first semitone row) in dst
         const uint4* const oH = opatch + obuf * kOP;
         f32x4c sacc = {0.f, 0.f, 0.f, 0.f}, saccl = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1044,13 +1054,19 @@ __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel
             sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, sacc, 0, 0, 0);
             if (kP2pProducts == 2) saccl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, saccl, 0, 0, 0);
         }
-        const int S = a.H / 3;
+        const int S = OUT_FOLD ? 12 : a.H / 3;
         float* const o = a.dst + base + static_cast<long long>(co) * S * T + tau;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                                 // D[m = 4q + i][n = (tau, co)]: semitone position 2m + tau of the tile
             const int m = wave * 16 + 4 * q + i;
             const float x = fmaf(kP2pProducts == 2 ? fmaf(saccl[i], kP2pLoInv, sacc[i]) : sacc[i], siscale, sbias);
-            if (3 * m < mblk) o[2 * m] = fmaxf(x, x * kSlope);
+            const float v = fmaxf(x, x * kSlope);
+            if (!OUT_FOLD) {
+                if (3 * m < mblk) o[2 * m] = v;
+            } else {
+                smax[i] = oct == 0 ? v : fmaxf(smax[i], v);
+                if (oct == a.n_oct - 1 && 3 * m < mblk) o[2 * m] = smax[i];
+            }
         }
     };
     // The waves 4..7 run their epilogue one barrier late (the accumulators wait in registers): each SIMD holds one wave of either
@@ -1062,7 +1078,13 @@ __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel
     for (int mt = 0; mt < MT; ++mt) { acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f}; accl[mt] = f32x4c{0.f, 0.f, 0.f, 0.f}; }
     int cur = 0;
     unsigned long long sm[6] = {0, 0, 0, 0, 0, 0}, ts[6];
-    for (int tile = first; tile < a.n_tiles; tile += nwg, cur ^= 1) {
+    int unit = first, oct = 0, prev_oct = 0;
+    for (int tile = tile0; tile >= 0; cur ^= 1) {
+        int next, n_unit = unit, n_oct_i = oct;
+        if (OUT_FOLD) {
+            if (++n_oct_i == a.n_oct) { n_oct_i = 0; n_unit += nwg; }
+            next = n_unit < a.n_units ? fold_tile(n_unit, n_oct_i) : -1;
+        } else next = tile + nwg < a.n_tiles ? tile + nwg : -1;
         if (STAMP) ts[0] = p2p_stamp();
         // this wave's share of the tile's patch has landed (and its stores have left).  The builtin, not asm: hipcc then knows that
         // nothing of its own is pending at the loop top and places no vmcnt wait inside the loop that would also drain the LDS-DMA
@@ -1070,9 +1092,9 @@ __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel
         if (STAMP) ts[1] = p2p_stamp();
         __syncthreads();              // ... every wave's; and every wave is done with the other half
         if (STAMP) ts[2] = p2p_stamp();
-        const bool more = tile + nwg < a.n_tiles;
+        const bool more = next >= 0;
         if (has_prev) {
-            if (OUT_SEMI) semi_stage(cur ^ 1, prev_base, prev_mblk);
+            if (OUT_SEMI) semi_stage(cur ^ 1, prev_base, prev_mblk, prev_oct);
             else if (late) epilogue(acc, accl, 0);
         }
         const uint4* const pH = lds4 + cur * a.plane_pos;
@@ -1085,8 +1107,8 @@ __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel
             // where both waves of a SIMD sit right after the barrier with the matrix pipe idle (-2 % per launch; switched off
             // altogether, loads and stores account for 11 + 15 us of a 128 us launch wherever they are placed -- see DESIGN.md)
             if (ks == 2 && more) {
-                if (IN_NCHW) load_regs(tile + nwg);
-                else issue_loads(tile + nwg, cur ^ 1);
+                if (IN_NCHW) load_regs(next);
+                else issue_loads(next, cur ^ 1);
             }
             if (ks == 6 && !OUT_SEMI && has_prev) store_pending();
             const int dy = ks >> 1, h = ks & 1;
@@ -1109,10 +1131,13 @@ __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel
             const int rows_here = a.H - y0 < a.R ? a.H - y0 : a.R;
             prev_mblk = rows_here * J;
             prev_base = OUT_CL ? static_cast<long long>(clip) * a.H * T + static_cast<long long>(y0) * T
+                      : OUT_FOLD ? clip * a.dst_clip_stride + static_cast<long long>((y0 % 36) / 3) * T
                       : OUT_SEMI ? clip * a.dst_clip_stride + static_cast<long long>(y0 / 3) * T
                                  : clip * a.dst_clip_stride + static_cast<long long>(y0) * T;
+            prev_oct = oct;
         }
         has_prev = true;
+        tile = next; unit = n_unit; oct = n_oct_i;
         if (STAMP) {
             ts[5] = p2p_stamp();
 #pragma unroll
@@ -1127,7 +1152,7 @@ __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel
     if (has_prev) {
         if (OUT_SEMI) {
             __syncthreads();          // every wave's share of the last tile is in the output patch
-            semi_stage(cur ^ 1, prev_base, prev_mblk);
+            semi_stage(cur ^ 1, prev_base, prev_mblk, prev_oct);
         } else {
             if (late) epilogue(acc, accl, 0);
             store_pending();
