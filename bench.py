@@ -466,15 +466,16 @@ def main():
         "roofline": {"bound": "mfma",
                      "kernel": "conv_p2p_f16_ps_kernel (persistent 7x7 circular pitch convolution, 8 channels, f16 activations x f16 weights on "
                                "v_mfma_f32_16x16x32_f16 with f32 accumulation: 1 MFMA product per algorithmic MAC), 3 launches per step; the third "
-                               "also runs the semitone conv on its output tile and writes only the semitone maps",
+                               "also runs the semitone conv and the octave maximum on its output tiles and writes only the folded maps",
                      "achieved": round(achieved, 2) if achieved else None, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_BF16_TFLOPS, 4) if achieved else None,
                      "mfma_products_per_mac": 1,
                      "traffic": p2p_traffic,
                      "traffic_source": f"profiles/{traffic_src}: mean HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE" if p2p_traffic else traffic_stale,
                      # mean over the three launches: (1 CQT + 4 x 36-row up_sixth channels, f32 -> 8 channels, f16), (8 -> 8, f16 both), (8 f16 -> 8
-                     # semitone channels of P / 3 rows, f32): the bytes this formulation has to move
-                     "algorithmic_bytes_per_launch": B * T_FRAMES * ((4 * (P + 4 * 36) + 2 * 8 * P) + (2 * 8 * P + 2 * 8 * P) + (2 * 8 * P + 4 * 8 * P // 3)) // 3,
+                     # folded semitone channels of 12 rows, f32: the semitone conv and the octave max run inside the launch): the bytes this
+                     # formulation has to move
+                     "algorithmic_bytes_per_launch": B * T_FRAMES * ((4 * (P + 4 * 36) + 2 * 8 * P) + (2 * 8 * P + 2 * 8 * P) + (2 * 8 * P + 4 * 8 * 12)) // 3,
                      "avg_launch_ms": round(p2p_ms / p2p_n, 4) if p2p_n else None, "launches_per_step": launches_per_step,
                      "note": "measured in the timed region: with streams > 1 another step's kernels share the GPU with these launches" if args.streams > 1 else None,
                      "single_stream": {"achieved": round(achieved1, 2) if achieved1 else None,
