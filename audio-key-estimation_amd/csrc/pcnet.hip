@@ -1404,7 +1404,7 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
         for (PackedConv& pc : n->pc2pc[0]) {
             pc.l0_off = -1;
             if (n->cfg.num_layers > 1 && pc.kh == 12 && pc.kw == 7 && pc.co == 4 && pc.groups == 1 && pc.cout <= 4 && pc.cin <= 4) {
-                pc.l0_off = static_cast<long long>(count); count += 24 * 64;
+                pc.l0_off = static_cast<long long>(count); count += 24 * 64 + 64;     // ... and the 4 inverse channel scales
             }
         }
     for (size_t i = 1; i < n->semi.size(); ++i) {            // semitone convs that follow an 8-channel pitch stack: fused into its last conv
@@ -1434,7 +1434,7 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
     if (!n->pc2pc.empty())
         for (const PackedConv& pc : n->pc2pc[0])
             if (pc.l0_off >= 0)
-                hipLaunchKernelGGL(pack_l0_bf16_kernel, dim3(3), dim3(256), 0, s, n->blob_dev + pc.w_off, n->bf_frags_dev + pc.l0_off, pc.cin, pc.cout);
+                hipLaunchKernelGGL(pack_l0_f16_kernel, dim3(3), dim3(256), 0, s, n->blob_dev + pc.w_off, n->bf_frags_dev + pc.l0_off, pc.cin, pc.cout);
     for (size_t i = 1; i < n->semi.size(); ++i)
         if (n->semi[i].bf_off >= 0)
             hipLaunchKernelGGL(pack_semi_f16_kernel, dim3(1), dim3(192), 0, s, n->blob_dev + n->semi[i].w_off, n->bf_frags_dev + n->semi[i].bf_off);
@@ -1822,6 +1822,10 @@ struct Fwd {
         if (mel_fm && (!take_mfma || P % 4)) return false;        // only the MFMA form's loader transposes
         if (dry_run) return true;
         a.mel_fm = mel_fm ? 1 : 0;
+        a.taps = g_keep_taps ? 1 : 0;
+        static const int dbg_skip = std::getenv("AKE_L0_SKIP") ? std::atoi(std::getenv("AKE_L0_SKIP")) : 0;   // timing experiments only (wrong results)
+        if (dbg_skip & 1) a.n_conv = 0;
+        if (dbg_skip & 2) a.psix = nullptr;
         ake::ProfScope ps("layer0_fused_kernel", s);
         if (take_mfma) hipLaunchKernelGGL(layer0_mfma_kernel, dim3(B), dim3(512), lds_m, s, a);
         else hipLaunchKernelGGL(layer0_fused_kernel, dim3(B), dim3(512), lds, s, a);
@@ -2397,6 +2401,11 @@ static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frame
                     return AKE_ERR_INVALID;
                 }
                 if (j < last_j && i == L - 1 && pc2pc_uses_bf16(n, i, Ti) && channels_last) *channels_last = 1;
+                if (i == 0 && L > 1 && !g_keep_taps && !g_pc_f32_only && !c.resblock && !c.denseblock && !c.p2pc_conv && !c.stay_sixth && c.n_filters >= 2 &&
+                    c.n_filters <= 4) {
+                    ake::set_error("tap: '%s' stays in LDS (layer 0 runs as one launch); ake_debug_keep_taps(1) before the forward writes it", name);
+                    return AKE_ERR_INVALID;
+                }
                 return set((j & 1) ? b.pcb[i] : b.pca[i], i == 0 ? c.n_filters : d.out_pc, 12, Ti);
             }
             if (i >= 1 && nm == m + "p2p.layer." + std::to_string(3 * j + 2)) {

@@ -1750,6 +1750,13 @@ __device__ __forceinline__ void channel_absmax8(const float* __restrict__ w, int
     for (int k = threadIdx.x; k < n_k * 8; k += blockDim.x) atomicMax(&smax[k & 7], __float_as_int(fabsf(w[k])));
     __syncthreads();
 }
+// ... of a pack [n_k][4 co]
+__device__ __forceinline__ void channel_absmax4(const float* __restrict__ w, int n_k, int* smax) {
+    if (threadIdx.x < 4) smax[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_k * 4; k += blockDim.x) atomicMax(&smax[k & 3], __float_as_int(fabsf(w[k])));
+    __syncthreads();
+}
 
 __global__ void pack_p2p_f16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin) {
     __shared__ int smax[8];
@@ -1841,7 +1848,8 @@ struct Layer0Args {
     float* fold0;                // [clip][1][12][T]
     float* psix;                 // [clip][NF][36][T]
     int H, T, RP, NF, n_conv;    // RP: LDS row pitch in floats (T + 6 rounded up to 4)
-    const uint4* frag[4];        // layer0_mfma_kernel: B fragments of the convs [12 dy][hi|lo][64 lanes] x 8 bf16 (pack_l0_bf16_kernel)
+    const uint4* frag[4];        // layer0_mfma_kernel: B fragments of the convs [12 dy][hi|lo][64 lanes] x 8 f16, then the 4 inverse channel scales (pack_l0_f16_kernel)
+    int taps;                    // layer0_mfma_kernel: also write the intermediate conv outputs dst[0 .. n_conv - 2] (debug taps; ake_debug_keep_taps)
     int RPp;                     // layer0_mfma_kernel: row pitch of the channels-last maps, in positions (even, >= T + 8)
     int mel_fm;                  // layer0_mfma_kernel: mel is frames-major, [clip][T][H] (the CQT filter bank's own output order)
 };
@@ -2006,26 +2014,34 @@ __global__ void local_pool_kernel(LocalPoolArgs a) {
 
 // ---- the same launch with the convolution stack on bf16 MFMA (split operands) ------------------------------------------------
 // The VALU form above spends 2.9 M FMAs per clip at the vector rate (0.07 ms per 256 clips, the kernel is VALU-bound).  Here the
-// maps live in LDS as channels-last split planes [12 rows][T + 8 positions][4 ch] (8 bytes per position and plane, 3 zero positions
-// either side = the convs' zero padding), and a conv is the MFMA form of conv_p2p_f16_kernel with 4 channels:
+// maps live in LDS channels-last, [12 rows][T + 8 positions][4 ch] f16 (8 bytes per position, 3 zero positions
+// either side = the convs' zero padding; ONE f16 value per activation and per weight, as in the pitch convs: this stack's operand
+// rounding moves the outputs by 2e-6, tests/tools/split_precision_proto.py), and a conv is the MFMA form of conv_p2p_f16_kernel with 4 channels:
 //   m = (pitch class p, frame pair j)     A[m][k = (position q', ci)] = X[(p + dy) mod 12][2j + q'][ci]    (8 positions x 4 channels = 32)
 //   n = (tau, co) = 4 * tau + co < 8      B[k][n] = w[co][ci][dy][q' - tau]                                  (columns 8..15 idle)
-//   k-step = dy: 12 steps x 3 MFMAs per 16 x 16 tile, ~29 tiles per clip.
-// One A fragment = one aligned 16-byte LDS read (2 positions x 4 channels); the 24 weight fragments of a layer sit in registers.
-__global__ void pack_l0_bf16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin, int cout) {
+//   k-step = dy: 12 MFMAs per 16 x 16 tile in two independent accumulator chains, ~29 tiles per clip.
+// One A fragment = one aligned 16-byte LDS read (2 positions x 4 channels); the 12 weight fragments of a layer sit in registers and the
+// next layer's are requested before the epilogue.  (Round 1: split bf16 x 3, one chain of 36 dependent MFMAs per tile, fragments
+// fetched behind the barrier: the three convs were 24 of the kernel's 45 us.)
+__global__ void pack_l0_f16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin, int cout) {
+    __shared__ int smax[4];
+    channel_absmax4(w, cin * 84, smax);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (dy, lane)
     if (i >= 12 * 64) return;
     const int dy = i / 64, lane = i - dy * 64;
     const int n = lane & 15, qq = lane >> 4;
     const int tau = n >> 2, co = n & 3;
+    const float sc = f16_weight_scale(__int_as_float(smax[co]));
+    if (dy == 0 && qq == 0 && tau == 0) reinterpret_cast<float*>(out + 24 * 64)[co] = 1.f / sc;
     unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
     for (int e = 0; e < 8; ++e) {
         const int pos = 2 * qq + (e >> 2), ci = e & 3;
         const int dx = pos - tau;
         float v = 0.f;
-        if (n < 8 && dx >= 0 && dx < 7 && ci < cin && co < cout) v = w[((ci * 12 + dy) * 7 + dx) * 4 + co];
-        const unsigned int hb = bf16_bits(v);
-        const unsigned int lb = bf16_bits(v - __uint_as_float(hb << 16));
+        if (n < 8 && dx >= 0 && dx < 7 && ci < cin && co < cout) v = sc * w[((ci * 12 + dy) * 7 + dx) * 4 + co];
+        const _Float16 hv = static_cast<_Float16>(v);
+        const unsigned int hb = __builtin_bit_cast(unsigned short, hv);
+        const unsigned int lb = f16_bits((v - static_cast<float>(hv)) * kP2pLoScale);
         hi[e >> 1] |= hb << (16 * (e & 1));
         lo[e >> 1] |= lb << (16 * (e & 1));
     }
@@ -2039,14 +2055,15 @@ __global__ __launch_bounds__(512) void layer0_mfma_kernel(Layer0Args a) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, q = lane >> 4;
     const int T = a.T, RP = a.RP, RPp = a.RPp, NF = a.NF;
-    // LDS: f32 map of the latest conv output [4][12][RP] (for up_sixth) | two channels-last maps, each hi plane + lo plane of
-    // [12][RPp] positions x 4 bf16 | the clip's CQT [H][T] (semitone phase only)
+    f16_saturate_mode();
+    // LDS: f32 map of the latest conv output [4][12][RP] (for up_sixth) | two channels-last maps of [12][RPp] positions x 4 f16 (sized
+    // as in round 1, when each had a hi and a lo plane) | the clip's CQT [H][T] (semitone phase only)
     float* const fmap = l0;
     unsigned short* const mapA = reinterpret_cast<unsigned short*>(l0 + 4 * 12 * RP);
-    const int plane = 12 * RPp * 4;                                   // bf16 elements per plane
+    const int plane = 12 * RPp * 4;                                   // f16 elements per map
     unsigned short* const mapB = mapA + 2 * plane;
     float* const ml = reinterpret_cast<float*>(mapB + 2 * plane);
-    for (int i = tid; i < 4 * 12 * RP + 2 * plane; i += 512) l0[i] = 0.f;   // (the two maps = 4 planes of bf16 = 2 * plane floats)
+    for (int i = tid; i < 4 * 12 * RP + 2 * plane; i += 512) l0[i] = 0.f;
     // ---- semitone conv + BN + LeakyReLU + octave fold -> channel 0 of map A ----
     {
         const float4* mel4 = reinterpret_cast<const float4*>(a.mel + static_cast<long long>(clip) * a.H * T);
@@ -2083,9 +2100,7 @@ __global__ __launch_bounds__(512) void layer0_mfma_kernel(Layer0Args a) {
                 v = v > 0.f ? v : v * kSlope;
                 best = fmaxf(best, v);
             }
-            const unsigned int hb = bf16_bits(best);
-            mapA[(p * RPp + 3 + t) * 4] = static_cast<unsigned short>(hb);
-            mapA[plane + (p * RPp + 3 + t) * 4] = static_cast<unsigned short>(bf16_bits(best - __uint_as_float(hb << 16)));
+            mapA[(p * RPp + 3 + t) * 4] = static_cast<unsigned short>(f16_bits(best));
             a.fold0[(static_cast<long long>(clip) * 12 + p) * T + t] = best;
         }
     }
@@ -2096,42 +2111,48 @@ __global__ __launch_bounds__(512) void layer0_mfma_kernel(Layer0Args a) {
     const int tau = (r16 >> 2) & 1, co = r16 & 3;
     const unsigned short* in = mapA;
     unsigned short* out = mapB;
-    for (int j = 0; j < a.n_conv; ++j) {
-        uint4 breg[24];
+    uint4 breg[12], bnext[12];                                            // this conv's weight fragments (hi halves), the next one's
+    auto frags_of = [&](int j) { return j == 0 ? a.frag[0] : j == 1 ? a.frag[1] : j == 2 ? a.frag[2] : a.frag[3]; };   // (no runtime index into the argument struct)
 #pragma unroll
-        for (int i = 0; i < 24; ++i) breg[i] = a.frag[j][i * 64 + lane];
+    for (int i = 0; i < 12; ++i) bnext[i] = a.n_conv > 0 ? frags_of(0)[2 * i * 64 + lane] : make_uint4(0, 0, 0, 0);
+    for (int j = 0; j < a.n_conv; ++j) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) breg[i] = bnext[i];
         const float bias = (r16 < 8 && co < NF) ? a.b[j][co] : 0.f;
+        const float iscale = reinterpret_cast<const float*>(frags_of(j) + 24 * 64)[co];
+        const bool write_dst = a.taps || j == a.n_conv - 1;
         float* const g = a.dst[j] + clip * a.dst_clip_stride[j];
+        if (j + 1 < a.n_conv) {                                           // in flight during this conv's multiply loop
+#pragma unroll
+            for (int i = 0; i < 12; ++i) bnext[i] = frags_of(j + 1)[2 * i * 64 + lane];
+        }
         for (int tile = wave; tile < n_tiles; tile += 8) {
             int m = tile * 16 + r16;
             m = m < M ? m : M - 1;
             const int p = m / J, jj = m - p * J;
-            f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4c acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // two chains: even / odd kernel rows
 #pragma unroll
             for (int dy = 0; dy < 12; ++dy) {
                 int row = p + dy;
                 row -= row >= 12 ? 12 : 0;
                 const int pos = row * RPp + 2 * jj + 2 * q;              // padded position of frame 2j - 3 + 2q
-                const bf16x8c ah = __builtin_bit_cast(bf16x8c, *reinterpret_cast<const uint4*>(in + pos * 4));
-                const bf16x8c al = __builtin_bit_cast(bf16x8c, *reinterpret_cast<const uint4*>(in + plane + pos * 4));
-                const bf16x8c bh = __builtin_bit_cast(bf16x8c, breg[2 * dy]), bl = __builtin_bit_cast(bf16x8c, breg[2 * dy + 1]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+                const f16x8c ah = __builtin_bit_cast(f16x8c, *reinterpret_cast<const uint4*>(in + pos * 4));
+                const f16x8c bh = __builtin_bit_cast(f16x8c, breg[dy]);
+                if (dy & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc2, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
             }
+            acc += acc2;
             if (r16 < 8 && co < NF) {                                    // D[m = 4q + i][n = (tau, co)]
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int mm = tile * 16 + 4 * q + i;
                     const int pp = mm / J, t = 2 * (mm - pp * J) + tau;
                     if (mm < M && t < T) {
-                        float v = acc[i] + bias;
-                        v = v > 0.f ? v : v * kSlope;
-                        const unsigned int hb = bf16_bits(v);
-                        out[(pp * RPp + 3 + t) * 4 + co] = static_cast<unsigned short>(hb);
-                        out[plane + (pp * RPp + 3 + t) * 4 + co] = static_cast<unsigned short>(bf16_bits(v - __uint_as_float(hb << 16)));
+                        float v = fmaf(acc[i], iscale, bias);
+                        v = fmaxf(v, v * kSlope);
+                        out[(pp * RPp + 3 + t) * 4 + co] = static_cast<unsigned short>(f16_bits(v));
                         fmap[(co * 12 + pp) * RP + 3 + t] = v;
-                        g[(static_cast<long long>(co) * 12 + pp) * T + t] = v;
+                        if (write_dst) g[(static_cast<long long>(co) * 12 + pp) * T + t] = v;
                     }
                 }
             }
