@@ -1007,21 +1007,20 @@ __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel
                 v[i] = fmaxf(x, x * kSlope);            // LeakyReLU (slope < 1)
             }
             if (OUT_CL || OUT_SEMI) {
-                // lanes (co, co ^ 1) trade halves: the even lane keeps rows m = 4q, 4q + 1 of both channels, the odd lane rows 4q + 2, 4q + 3
-                const bool odd = co & 1;
-                const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];
-                const float g0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0xB1, 0xF, 0xF, false));
-                const float g1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0xB1, 0xF, 0xF, false));
-                const float m0 = odd ? v[2] : v[0], m1 = odd ? v[3] : v[1];
-                const f32x2e xa = {odd ? g0 : m0, odd ? m0 : g0};       // (even channel, odd channel) of row ma
-                const f32x2e xb = {odd ? g1 : m1, odd ? m1 : g1};       // ... of row ma + 1
-                // OUT 1: the M-tile's own slab; OUT 2: the tile-wide patch, m counted over the tile (= position 2m + tau: T = 2J)
-                unsigned int* st = OUT_SEMI ? reinterpret_cast<unsigned int*>(opatch + obuf * kOP) + (wave * MT + mt) * 128
-                                            : reinterpret_cast<unsigned int*>(stage + mt * kP2pPsStage);
-                const int ma = 4 * q + (odd ? 2 : 0);
-                const int d = ma * 8 + tau * 4 + (co >> 1);              // [m][tau][co / 2] dwords
-                st[d] = __builtin_bit_cast(unsigned int, __builtin_convertvector(xa, f16x2c));
-                st[d + 8] = __builtin_bit_cast(unsigned int, __builtin_convertvector(xb, f16x2c));
+                // every lane writes its own channel's four rows as 2-byte LDS stores ([m][tau][8 co] halves: channels-last).  (Round 1
+                // traded halves between the lanes (co, co ^ 1) to write whole dwords: 2 DPP moves + 6 selects per M-tile -- vector
+                // instructions, which on this chip are paid in full next to the MFMAs, for LDS stores that cost next to nothing.)
+                // OUT 1: the M-tile's own slab; OUT 2 / 3: the tile-wide patch, m counted over the tile (= position 2m + tau: T = 2J)
+                unsigned short* st = OUT_SEMI ? reinterpret_cast<unsigned short*>(opatch + obuf * kOP) + (wave * MT + mt) * 256
+                                              : reinterpret_cast<unsigned short*>(stage + mt * kP2pPsStage);
+                const f32x2e x01 = {v[0], v[1]}, x23 = {v[2], v[3]};
+                const unsigned int p01 = __builtin_bit_cast(unsigned int, __builtin_convertvector(x01, f16x2c));
+                const unsigned int p23 = __builtin_bit_cast(unsigned int, __builtin_convertvector(x23, f16x2c));
+                const int e = (8 * q + tau) * 8 + co;                    // row m = 4q + i: + 16 i
+                st[e] = static_cast<unsigned short>(p01);
+                st[e + 16] = static_cast<unsigned short>(p01 >> 16);
+                st[e + 32] = static_cast<unsigned short>(p23);
+                st[e + 48] = static_cast<unsigned short>(p23 >> 16);
             } else {
                 float* st = reinterpret_cast<float*>(stage + mt * kP2pPsStage);
 #pragma unroll
