@@ -145,15 +145,28 @@ __global__ __launch_bounds__(256) void act_bwd_stats_kernel(float* __restrict__ 
     const float sc = aff[3 * c], sh = aff[3 * c + 1], ng = aff[3 * c + 2];
     const float mu = bstats[3 * c], rstd = rsqrtf(bstats[3 * c + 1] + 1e-5f);
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int i = threadIdx.x; i < HT; i += 256) {
-        const float zz = z[base + i];
+    auto one = [&](float gg, float zz) {
         const float pre = fmaf(zz, sc, sh);
-        const float g1 = g[base + i] * (pre > 0.f ? 1.f : ng);
-        g[base + i] = g1;
+        const float g1 = gg * (pre > 0.f ? 1.f : ng);
         const float zc = zz - mu;
         s1 += g1;
         s2 = fmaf(g1, zc * rstd, s2);
         s3 += zc;
+        return g1;
+    };
+    // 16-byte accesses when the slice allows it (the pass is memory-bound: 0.87 ms per step with 4-byte accesses)
+    const bool vec = (HT & 3) == 0 && (base & 3) == 0 && ((reinterpret_cast<unsigned long long>(g) | reinterpret_cast<unsigned long long>(z)) & 15) == 0;
+    if (vec) {
+        float4* g4 = reinterpret_cast<float4*>(g + base);
+        const float4* z4 = reinterpret_cast<const float4*>(z + base);
+        for (int i = threadIdx.x; i < HT / 4; i += 256) {
+            float4 gv = g4[i];
+            const float4 zv = z4[i];
+            gv.x = one(gv.x, zv.x); gv.y = one(gv.y, zv.y); gv.z = one(gv.z, zv.z); gv.w = one(gv.w, zv.w);
+            g4[i] = gv;
+        }
+    } else {
+        for (int i = threadIdx.x; i < HT; i += 256) g[base + i] = one(g[base + i], z[base + i]);
     }
     __shared__ float r1[4], r2[4], r3[4];
 #pragma unroll
@@ -193,6 +206,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
     const int c = blockIdx.x, clip = blockIdx.y;
     const long long base = (static_cast<long long>(clip) * ctot + coff + c) * HT;
     const float c0 = coef[4 * c], c1 = coef[4 * c + 1], c2 = coef[4 * c + 2], mu = coef[4 * c + 3];
+    const bool vec = (HT & 3) == 0 && (base & 3) == 0 && ((reinterpret_cast<unsigned long long>(g) | reinterpret_cast<unsigned long long>(z)) & 15) == 0;
+    if (vec) {
+        float4* g4 = reinterpret_cast<float4*>(g + base);
+        const float4* z4 = reinterpret_cast<const float4*>(z + base);
+        for (int i = threadIdx.x; i < HT / 4; i += 256) {
+            float4 gv = g4[i];
+            const float4 zv = z4[i];
+            gv.x = fmaf(gv.x, c0, fmaf(zv.x - mu, c1, c2)); gv.y = fmaf(gv.y, c0, fmaf(zv.y - mu, c1, c2));
+            gv.z = fmaf(gv.z, c0, fmaf(zv.z - mu, c1, c2)); gv.w = fmaf(gv.w, c0, fmaf(zv.w - mu, c1, c2));
+            g4[i] = gv;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < HT; i += 256) g[base + i] = fmaf(g[base + i], c0, fmaf(z[base + i] - mu, c1, c2));
 }
 
