@@ -757,6 +757,8 @@ struct Buffers {           // workspace carve
     // backward
     double* stats2 = nullptr;          // [bn_channels][3]  (sum g1, sum g1*zhat, sum (z - mean))
     gfx_t* gslots = nullptr;           // [kGradSlots][grad_floats] partial weight gradients (backward), 64-bit fixed point
+    float* wg_partial = nullptr;       // per-workgroup partial weight gradients of one convolution (conv_wgrad_kernel), reduced in order
+    size_t wg_partial_floats = 0;
     unsigned short* feat_cl = nullptr; // [2 planes][B][12][Tf][16]
     float* coef = nullptr;             // [bn_channels][4]  (c0, c1, c2, mean)
     float* g_map[3] = {nullptr, nullptr, nullptr};
@@ -815,6 +817,8 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
         b->stats = cv.take<double>(static_cast<size_t>(n->bn_channels) * 2 * kStatSlots);
         b->stats2 = cv.take<double>(static_cast<size_t>(n->bn_channels) * 3);
         b->gslots = cv.take<gfx_t>(static_cast<size_t>(kGradSlots) * n->grad_floats);
+        b->wg_partial_floats = static_cast<size_t>(B) * 98304;                         // 384 KB per clip: e.g. two workgroups per clip x the 43 K weights of a head conv
+        b->wg_partial = cv.take<float>(b->wg_partial_floats);
         b->bstats = cv.take<float>(static_cast<size_t>(n->bn_channels) * 3);
         b->coef = cv.take<float>(static_cast<size_t>(n->bn_channels) * 4);
         for (auto* v : {&b->semi_raw, &b->aff_semi, &b->aff_cat, &b->aff_p2pin, &b->g_pc, &b->g_cat, &b->g_semi, &b->g_p, &b->g_pin, &b->g_psix})

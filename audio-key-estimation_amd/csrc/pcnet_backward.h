@@ -86,6 +86,8 @@ struct Bwd {
         a.dst = const_cast<float*>(dz); a.dst_coff = dz_coff; a.dst_clip_stride = static_cast<long long>(dz_ctot) * a.H_out * a.T_out;
         a.in_affine = in_aff;
         wa.dW = dW; wa.slot_stride = static_cast<long long>(n->grad_floats); wa.KH = pc.kh; wa.KW = pc.kw;
+        static const bool noflush = std::getenv("AKE_WGRAD_NOFLUSH") != nullptr;
+        wa.dbg_noflush = noflush ? 1 : 0;
         const int KK = pc.kh * pc.kw;
         const int MTC = (pc.cout + 15) / 16, NTK = (KK + 15) / 16;
         // tile: rows x frames such that the patch of 8 channels + the dz tile fit the LDS budget
@@ -108,12 +110,28 @@ struct Bwd {
         wa.rt_per_block = std::max(1, (tiles + wgs_per_clip - 1) / wgs_per_clip);
         dim3 grid((tiles + wa.rt_per_block - 1) / wa.rt_per_block, 1, B), block(512);
         const size_t lds = lds_of(R, TT);
-        ake::ProfScope ps(name, s);
-#define AKE_WG(M_, N_) if (MTC == M_ && NTK == N_) { hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_>), grid, block, lds, s, wa); return AKE_OK; }
-        AKE_WG(1, 4) AKE_WG(1, 6) AKE_WG(2, 6) AKE_WG(1, 1) AKE_WG(2, 1) AKE_WG(1, 2) AKE_WG(2, 2)
+        // partial sums per workgroup + an ordered reduction when the scratch buffer holds them (see WgradArgs::partial)
+        const long long n_w = static_cast<long long>(pc.cout) * (src.c0 + src.c1) * KK;
+        const long long n_wg = static_cast<long long>(grid.x) * B;
+        static const bool partial_off = std::getenv("AKE_WGRAD_ATOMIC") != nullptr;
+        const bool use_partial = !partial_off && b.wg_partial && n_wg * n_w <= static_cast<long long>(b.wg_partial_floats);
+        if (use_partial) { wa.partial = b.wg_partial; wa.partial_stride = n_w; }
+        bool launched = false;
+        {
+            ake::ProfScope ps(name, s);
+#define AKE_WG(M_, N_) if (!launched && MTC == M_ && NTK == N_) { hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_>), grid, block, lds, s, wa); launched = true; }
+            AKE_WG(1, 4) AKE_WG(1, 6) AKE_WG(2, 6) AKE_WG(1, 1) AKE_WG(2, 1) AKE_WG(1, 2) AKE_WG(2, 2)
 #undef AKE_WG
-        ake::set_error("wgrad %s: no kernel for cout=%d taps=%d", name, pc.cout, KK);
-        return AKE_ERR_UNSUPPORTED;
+        }
+        if (!launched) {
+            ake::set_error("wgrad %s: no kernel for cout=%d taps=%d", name, pc.cout, KK);
+            return AKE_ERR_UNSUPPORTED;
+        }
+        if (use_partial) {
+            ake::ProfScope ps("wgrad_partial_reduce_kernel", s);
+            hipLaunchKernelGGL(wgrad_partial_reduce_kernel, dim3(static_cast<unsigned>((n_w + 63) / 64)), dim3(1024), 0, s, b.wg_partial, static_cast<int>(n_wg), n_w, dW);
+        }
+        return AKE_OK;
     }
 
     // data gradient of one convolution: dst(+)= conv(dz, flipped weights)

@@ -444,7 +444,41 @@ struct WgradArgs {
     long long slot_stride;    // floats between gradient slots
     int KH, KW;
     int rt_per_block;         // row tiles per workgroup
+    int dbg_noflush;          // timing experiments only (AKE_WGRAD_NOFLUSH): skip the atomics
+    // nullable: every workgroup stores its partial dW as plain floats at partial[(blockIdx.z * gridDim.x + blockIdx.x) * partial_stride + ...]
+    // and wgrad_partial_reduce_kernel adds them up in workgroup order (deterministic; one atomic per weight instead of one per weight
+    // and workgroup: 6.3 M 64-bit atomics per pitch-class convolution and step cost 0.3 of its 1.1 ms)
+    float* partial;
+    long long partial_stride;
 };
+
+// dW[i] += sum over the workgroups' partial sums in a fixed order: 16 groups of consecutive workgroups are summed side by side (a lane
+// per weight and group: 43 k weights alone leave most of the chip idle behind 256 dependent loads), then combined in group order
+__global__ __launch_bounds__(1024) void wgrad_partial_reduce_kernel(const float* __restrict__ partial, int n_wg, long long stride, gfx_t* __restrict__ dW) {
+    __shared__ double part[16][64];
+    const int li = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long long i = static_cast<long long>(blockIdx.x) * 64 + li;
+    const int per = (n_wg + 15) / 16;
+    const int w0 = grp * per, w1 = w0 + per < n_wg ? w0 + per : n_wg;
+    double s = 0.0;
+    if (i < stride) {
+        int w = w0;
+        for (; w + 4 <= w1; w += 4) {
+            const float a0 = partial[(w + 0) * stride + i], a1 = partial[(w + 1) * stride + i], a2 = partial[(w + 2) * stride + i],
+                        a3 = partial[(w + 3) * stride + i];
+            s += static_cast<double>(a0); s += static_cast<double>(a1); s += static_cast<double>(a2); s += static_cast<double>(a3);
+        }
+        for (; w < w1; ++w) s += static_cast<double>(partial[w * stride + i]);
+    }
+    part[grp][li] = s;
+    __syncthreads();
+    if (grp == 0 && i < stride) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += part[g][li];
+        grad_add(dW + i, static_cast<float>(t));
+    }
+}
 
 template <int MTC, int NTK>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs wa) {
@@ -561,7 +595,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs wa) {
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const int co = 16 * m + 4 * q + reg;
-                        if (co < a.cout && kk < KK) grad_add(dWs + (static_cast<long long>(co) * cin + ci) * KK + kk, acc[m][nt][reg]);
+                        if (co < a.cout && kk < KK && !wa.dbg_noflush) {
+                            const long long idx = (static_cast<long long>(co) * cin + ci) * KK + kk;
+                            if (wa.partial) wa.partial[(static_cast<long long>(blockIdx.z) * gridDim.x + blockIdx.x) * wa.partial_stride + idx] = acc[m][nt][reg];
+                            else grad_add(dWs + idx, acc[m][nt][reg]);
+                        }
                     }
                 }
         }
