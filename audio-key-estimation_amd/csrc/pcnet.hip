@@ -615,6 +615,43 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
     return true;
 }
 
+// 7 x 7 circular pitch convolution with f32-equivalent products (conv_p2p_f16x3_kernel): train-mode forward (in_aff, bias, statistics)
+// and data gradient (none of them).  false when the shape does not qualify: the caller then runs conv_mfma_kernel.
+bool run_p2p_f16x3(const ake_pcnet* n, long long frag_off, const Src& src, const float* in_aff, const float* bias, int batch, int H, int T, float* dst,
+                   int cout, double* stats, int stats_stride, hipStream_t s, const char* name) {
+    static const bool off = std::getenv("AKE_P2P_TRAIN_F32") != nullptr;
+    if (off || frag_off < 0 || T < 2 || (T & 1) || src.c0 < 1 || src.c0 + src.c1 > 8 || cout > 8 || src.ctot0 != 0) return false;
+    P2pTrArgs a;
+    std::memset(&a, 0, sizeof(a));
+    const int n_cus = device_cus();
+    if (n_cus < 8) return false;
+    a.J = T / 2; a.Tp = p2p_pitch(a.J);
+    auto plane_of = [&](int R) { return ((R + 6) * a.Tp + 63) / 64 * 64; };
+    auto lds_of = [&](int R) { return (static_cast<size_t>(4) * plane_of(R) + 8 * kP2pMT * kP2pPsStage) * sizeof(uint4); };
+    int R = std::max(1, std::min(H, 8 * kP2pMT * 16 / a.J));
+    while (R >= 1 && (lds_of(R) > 156 * 1024 || plane_of(R) > 3 * 512)) --R;         // (the loader: three positions per thread)
+    if (R < 1 || H < R + 6) return false;
+    a.R = R; a.plane_pos = plane_of(R);
+    a.H = H; a.T = T;
+    a.n_row_tiles = (H + R - 1) / R;
+    a.n_tiles = a.n_row_tiles * batch;
+    const long long clip_stride = static_cast<long long>(cout) * H * T;
+    if ((R * T) % 4 || (static_cast<long long>(H) * T) % 4 || clip_stride % 4 || (reinterpret_cast<uintptr_t>(dst) & 15)) return false;
+    a.p = src.p0; a.c0 = src.c0; a.u = src.p1 ? src.p1 : src.p0; a.c1 = src.p1 ? src.c1 : 0; a.h1 = src.h1 > 0 ? src.h1 : 1;
+    a.in_aff = in_aff; a.bfrag = n->bf_frags_dev + frag_off; a.bias = bias;
+    a.dst = dst; a.dst_clip_stride = clip_stride; a.cout = cout;
+    a.stats = stats; a.stats_stride = stats_stride;
+    static ake::DeviceOnce attr_set;
+    if (attr_set.need()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+        attr_set.mark();
+    }
+    dim3 grid(std::min(n_cus / 8 * 8, (a.n_tiles + 7) / 8 * 8)), block(512);
+    ake::ProfScope ps(name, s);
+    hipLaunchKernelGGL(conv_p2p_f16x3_kernel, grid, block, lds_of(R), s, a);
+    return true;
+}
+
 // semitone maps [clip][C][S][T] -> channels [coff, coff + C) of the concat buffer [clip][ctot][12][T]: max over the octaves
 int run_fold_max(const float* smap, int C, int S, int batch, int T, float* dst, int dst_ctot, int dst_coff, hipStream_t s) {
     const long long total = static_cast<long long>(batch) * C * 12 * T;
@@ -1386,6 +1423,23 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
             pc.bf_off = -1;
             if (pc.cin <= 8 && pc.cout == 8 && pc.kh == 7 && pc.kw == 7 && pc.co == 8) { pc.bf_off = static_cast<long long>(count); count += kBfFragsPerConv; }
         }
+    // train-mode forward and data gradient of the pitch convs (conv_p2p_f16x3_kernel): f16 hi + lo fragments from the raw weights
+    struct TrainFrag { PackedConv* pc; size_t raw; int cin, cout, flip; };
+    std::vector<TrainFrag> tfr;
+    if (!n->raw_w_off.empty())
+        for (size_t i = 1; i < n->p2p_t.size() && i < n->p2p_d.size(); ++i)
+            for (size_t j = 0; j < n->p2p_t[i].size() && j < n->p2p_d[i].size(); ++j) {
+                PackedConv& pt = n->p2p_t[i][j];
+                PackedConv& pd = n->p2p_d[i][j];
+                pt.bf_off = pd.bf_off = -1;
+                const auto it = n->spec_index.find("model." + std::to_string(i) + ".p2p.layer." + std::to_string(3 * j) + ".weight");
+                if (it == n->spec_index.end() || pt.kh != 7 || pt.kw != 7 || pt.cin > 8 || pt.cout > 8 || n->cfg.resblock || n->cfg.denseblock) continue;
+                const size_t raw = n->raw_w_off[it->second];
+                pt.bf_off = static_cast<long long>(count); count += kBfFragsPerConv;
+                tfr.push_back({&pt, raw, pt.cin, pt.cout, 0});
+                pd.bf_off = static_cast<long long>(count); count += kBfFragsPerConv;
+                tfr.push_back({&pd, raw, pt.cin, pt.cout, 1});
+            }
     std::vector<PackedConv*> pcs;                             // pitch-class convolutions: the PitchClass2PitchClass stacks and the heads' first conv
     for (auto& layer : n->pc2pc)
         for (PackedConv& pc : layer) pcs.push_back(&pc);
@@ -1439,6 +1493,8 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
         for (const PackedConv& pc : n->pc2pc[0])
             if (pc.l0_off >= 0)
                 hipLaunchKernelGGL(pack_l0_f16_kernel, dim3(3), dim3(256), 0, s, n->blob_dev + pc.w_off, n->bf_frags_dev + pc.l0_off, pc.cin, pc.cout);
+    for (const TrainFrag& t : tfr)
+        hipLaunchKernelGGL(pack_p2p_f16_raw_kernel, dim3((14 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + t.raw, n->bf_frags_dev + t.pc->bf_off, t.cin, t.cout, t.flip);
     for (size_t i = 1; i < n->semi.size(); ++i)
         if (n->semi[i].bf_off >= 0)
             hipLaunchKernelGGL(pack_semi_f16_kernel, dim3(1), dim3(192), 0, s, n->blob_dev + n->semi[i].w_off, n->bf_frags_dev + n->semi[i].bf_off);
@@ -1998,6 +2054,17 @@ struct Fwd {
                             return rc;
                     }
                     continue;
+                }
+                if (train && !c.pc2p_mem && !c.stay_sixth) {   // f16 x 3 on the persistent form (f32-equivalent products); else the f32 MFMA kernel
+                    const PackedConv& pt = n->p2p_t[i][j];
+                    const int bn = bn_of(m + "p2p.layer." + std::to_string(3 * j + 1));
+                    if (run_p2p_f16x3(n, pt.bf_off, sdesc, in_aff, n->blob_dev + pt.b_off, B, P, Ti, out, d.out_p, b.stats + 2 * n->bns[bn].ch_off,
+                                      2 * n->bn_channels, s, "conv_p2p_f16x3_kernel/p2p")) {
+                        finalize_bn(bn, static_cast<double>(B) * P * Ti, out_aff);
+                        sdesc = Src{out, d.out_p, nullptr, 0, 0};
+                        in_aff = out_aff;
+                        continue;
+                    }
                 }
                 if ((rc = conv(n->p2p[i][j], train ? n->p2p_t[i][j] : n->p2p[i][j], m + "p2p.layer." + std::to_string(3 * j + 1), 0, sdesc,
                                in_aff, B, P, Ti, true, out, d.out_p, 0, out_aff, "conv_mfma_kernel/p2p")))

@@ -144,6 +144,9 @@ struct Bwd {
         g.pad_l = fwd.kw - 1 - pad_fwd;
         g.T_out = T_in;
         g.H_out = H;
+        if (kind == 0 && !accumulate && dst_coff == 0 && dst_ctot == pd.cout && T_dz == T_in &&
+            run_p2p_f16x3(n, pd.bf_off, Src{dz, pd.cin, nullptr, 0, 0}, nullptr, nullptr, B, H, T_dz, dst, pd.cout, nullptr, 0, s, "conv_p2p_f16x3_kernel/p2p_dgrad"))
+            return AKE_OK;
         return run_conv(n, pd, kind == 0 ? 0 : 1, Src{dz, pd.cin, nullptr, 0, 0}, B, H, T_dz, true, false, dst, dst_ctot, dst_coff, s, name,
                         nullptr, nullptr, &g, accumulate);
     }

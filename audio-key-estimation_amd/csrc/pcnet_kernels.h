@@ -1160,6 +1160,199 @@ __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel
 }
 
 // ==========================================================================================
+// Training-mode form of the persistent pitch convolution ("f16 x 3"): the same tiling and MFMA form as conv_p2p_f16_ps_kernel, but with
+// f32-equivalent products -- the step's gradients are held to 2e-5 of float64 autograd, so nothing may be rounded to 11 bits here.
+//   x = xh + xl, w = wh + wl, all f16, the second halves stored times 2^11 (normal numbers):  x * w ~ xh*wh + 2^-11 (xl'*wh + xh*wl')
+//   (three MFMAs, two accumulator sets; the dropped xl*wl is 2^-22 of the product).
+// Used for (a) the train-mode forward: input = the previous layer's RAW output with its pending BatchNorm + LeakyReLU applied on load
+// (per-channel (scale, shift, slope) table, as conv_mfma_kernel<.., TRAIN>), output = raw f32 NCHW + per-channel sum / sum of squares
+// for this layer's BatchNorm; (b) the data gradient: input = dz, weights = the forward's transposed and flipped, no table, no bias, no
+// statistics.  Replaces conv_mfma_kernel (f32 MFMA, the vector rate) for these shapes: 0.53 -> 0.2 ms per convolution and 256 clips.
+// ==========================================================================================
+struct P2pTrArgs {
+    const float* p;               // input channels [0, c0): [clip][c0][H][T]
+    const float* u;               // input channels [c0, c0 + c1): [clip][c1][h1][T], row % h1 (the repeated up_sixth map), or unused (c1 = 0)
+    int c0, c1, h1;
+    const float* in_aff;          // [c0 + c1][3] (scale, shift, negative slope) applied on load, or null
+    const uint4* bfrag;           // [14 k-steps][hi | lo * 2^11][64 lanes] x 8 f16, then the 8 inverse channel scales
+    const float* bias;            // [cout] or null
+    float* dst;                   // raw output, NCHW f32 [clip][cout][H][T]
+    long long dst_clip_stride;
+    int cout;
+    double* stats;                // [kStatSlots][stats_stride]: (sum, sum of squares) of channel c at 2c, 2c + 1 (fixed point), or null
+    int stats_stride;
+    int H, T, R, J, Tp, n_row_tiles, n_tiles, plane_pos;
+};
+
+__global__ __launch_bounds__(512) void conv_p2p_f16x3_kernel(P2pTrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+    constexpr int MT = kP2pMT, NV = 8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int Tp = a.Tp, J = a.J, T = a.T;
+    const int npos = (a.R + 6) * Tp;
+    const int nwg = gridDim.x, per_xcd = nwg >> 3;
+    const int first = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int ctot = a.c0 + a.c1;
+    // LDS: [2 buffers][hi | lo][plane_pos] positions of 8 channels, then the waves' staging slabs
+    float vin[3][NV];
+    int pn[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int i = threadIdx.x + 512 * k;
+        const int ic = i < npos ? i : npos - 1;
+        const int rj = ic / Tp, f = ic - rj * Tp;
+        pn[k] = (rj << 16) | wrap(f - 3, T);
+    }
+    auto load_regs = [&](int tile) {
+        const int clip = tile / a.n_row_tiles;
+        const int y0 = (tile - clip * a.n_row_tiles) * a.R;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int row = y0 - 3 + (pn[k] >> 16);
+            row += row < 0 ? a.H : 0;
+            row -= row >= a.H ? a.H : 0;
+            const int t = pn[k] & 0xffff;
+            const float* pp = a.p + (static_cast<long long>(clip) * a.c0 * a.H + row) * T + t;
+            const float* pu = a.u + (static_cast<long long>(clip) * a.c1 * a.h1 + row % a.h1) * T + t;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                const int cc = c < ctot ? c : ctot - 1;
+                const float* src = cc < a.c0 ? pp + static_cast<long long>(cc) * a.H * T : pu + static_cast<long long>(cc - a.c0) * a.h1 * T;
+                vin[k][c] = *src;
+            }
+        }
+    };
+    // the pending BatchNorm + LeakyReLU of the input, per channel (registers: the table is tiny and read once)
+    float asc[NV], ash[NV], ang[NV];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const bool on = a.in_aff != nullptr && c < ctot;
+        asc[c] = on ? a.in_aff[3 * c] : 1.f; ash[c] = on ? a.in_aff[3 * c + 1] : 0.f; ang[c] = on ? a.in_aff[3 * c + 2] : 1.f;
+    }
+    auto write_lds = [&](int buf) {
+        uint4* const wH = lds4 + (2 * buf) * a.plane_pos;
+        uint4* const wL = wH + a.plane_pos;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                float x = 0.f;
+                if (c < ctot) {
+                    x = fmaf(vin[k][c], asc[c], ash[c]);
+                    x = x > 0.f ? x : x * ang[c];
+                }
+                const _Float16 h = static_cast<_Float16>(x);
+                const unsigned int hb = __builtin_bit_cast(unsigned short, h);
+                const unsigned int lb = f16_bits((x - static_cast<float>(h)) * kP2pLoScale);
+                hi[c >> 1] |= hb << (16 * (c & 1));
+                lo[c >> 1] |= lb << (16 * (c & 1));
+            }
+            const int i = threadIdx.x + 512 * k;
+            if (i < npos) { wH[i] = make_uint4(hi[0], hi[1], hi[2], hi[3]); wL[i] = make_uint4(lo[0], lo[1], lo[2], lo[3]); }
+        }
+    };
+    const int tile0 = first < a.n_tiles ? first : -1;
+    if (tile0 >= 0) { load_regs(tile0); write_lds(0); }
+    uint4 breg[28];
+#pragma unroll
+    for (int i = 0; i < 28; ++i) breg[i] = a.bfrag[i * 64 + lane];
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = (wave * MT + mt) * 16 + r16;
+        m = m < a.R * J ? m : a.R * J - 1;
+        const int r = m / J, j = m - r * J;
+        abase[mt] = r * Tp + 2 * j + q;
+    }
+    const int tau = r16 >> 3, co = r16 & 7;
+    const float bias = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+    const float iscale = reinterpret_cast<const float*>(a.bfrag + kP2pFragScale)[co];
+    uint4* const stage = lds4 + 4 * a.plane_pos + wave * (MT * kP2pPsStage);
+    typedef float f32x4c __attribute__((ext_vector_type(4)));
+    long long prev_base = 0;
+    int prev_mblk = 0;
+    bool has_prev = false;
+    auto store_pending = [&]() {          // lane = (channel, group of 4 frames), as the OUT = 0 form of conv_p2p_f16_ps_kernel
+        uint4 outv[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) outv[mt] = stage[mt * kP2pPsStage + (lane >> 3) * 9 + (lane & 7)];
+        if ((lane >> 3) >= a.cout) return;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = (wave * MT + mt) * 16 + 2 * (lane & 7);
+            float* o = a.dst + prev_base + static_cast<long long>(lane >> 3) * a.H * T + 2 * m;
+            if (m + 1 < prev_mblk) *reinterpret_cast<uint4*>(o) = outv[mt];
+            else if (m < prev_mblk) { o[0] = __uint_as_float(outv[mt].x); o[1] = __uint_as_float(outv[mt].y); }
+        }
+    };
+    float s1 = 0.f, s2 = 0.f;             // this lane's share of channel co's statistics, over all tiles of the workgroup
+    int cur = 0;
+    for (int tile = tile0; tile >= 0; cur ^= 1) {
+        const int next = tile + nwg < a.n_tiles ? tile + nwg : -1;
+        __syncthreads();                  // the patch of this tile is complete; every wave is done with the other buffer
+        const uint4* const pH = lds4 + (2 * cur) * a.plane_pos;
+        const uint4* const pL = pH + a.plane_pos;
+        f32x4c acc[MT], accl[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f}; accl[mt] = f32x4c{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < 14; ++ks) {
+            if (ks == 2 && next >= 0) load_regs(next);
+            if (ks == 6 && has_prev) store_pending();
+            const int dy = ks >> 1, h = ks & 1;
+            const f16x8c bh = __builtin_bit_cast(f16x8c, breg[2 * ks]), bl = __builtin_bit_cast(f16x8c, breg[2 * ks + 1]);
+            f16x8c ah[MT], al[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int ad = abase[mt] + dy * Tp + 4 * h;
+                ah[mt] = __builtin_bit_cast(f16x8c, pH[ad]);
+                al[mt] = __builtin_bit_cast(f16x8c, pL[ad]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) accl[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bh, accl[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) accl[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, accl[mt], 0, 0, 0);
+        }
+        const int clip = tile / a.n_row_tiles;
+        const int y0 = (tile - clip * a.n_row_tiles) * a.R;
+        const int rows_here = a.H - y0 < a.R ? a.H - y0 : a.R;
+        const int mblk = rows_here * J;
+        // epilogue: raw value (+ bias), statistics, transposed into the wave's staging slab
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float* st = reinterpret_cast<float*>(stage + mt * kP2pPsStage);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = fmaf(fmaf(accl[mt][i], kP2pLoInv, acc[mt][i]), iscale, bias);
+                if ((wave * MT + mt) * 16 + 4 * q + i < mblk) { s1 += v; s2 = fmaf(v, v, s2); }
+                st[co * 36 + (4 * q + i) * 2 + tau] = v;
+            }
+        }
+        if (next >= 0) write_lds(cur ^ 1);
+        prev_mblk = mblk;
+        prev_base = clip * a.dst_clip_stride + static_cast<long long>(y0) * T;
+        has_prev = true;
+        tile = next;
+    }
+    if (has_prev) store_pending();
+    if (a.stats) {                        // lanes of one channel: r16 = co and co + 8 (tau), four q
+        s1 += __shfl_xor(s1, 8); s2 += __shfl_xor(s2, 8);
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (lane < 8 && lane < a.cout) {
+            double* st = a.stats + static_cast<size_t>((blockIdx.x + wave) & (kStatSlots - 1)) * a.stats_stride;
+            fx_add(st + 2 * lane, s1, kFxStat);
+            fx_add(st + 2 * lane + 1, s2, kFxStat);
+        }
+    }
+}
+
+// ==========================================================================================
 // Equivariant pitch-class convolution (12 x 7 kernel, rows circular over the 12 pitch classes, time zero-padded or valid;
 // models.py:36-47) on bf16 MFMA with split operands -- the PitchClass2PitchClass stacks and the first convolution of the
 // key / tonic heads.  Same idea as conv_p2p_f16_kernel: channels-last activations [clip][12][T][16] as bf16 hi / lo planes,
@@ -1808,6 +2001,46 @@ __global__ void pack_semi_f16_kernel(const float* __restrict__ w, uint4* __restr
     }
     out[(2 * dy + 0) * 64 + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
     out[(2 * dy + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+// Weight fragments of conv_p2p_f16x3_kernel from the TORCH layout w[co][ci][7][7] (the raw copy of the parameter).
+// transpose_flip = 0: the forward (B[k = (tap, ci)][n = (tau, co)] = w[co][ci][dy][dx]); 1: the data gradient, a correlation of dz with
+// w'[n_out = ci][n_in = co][dy][dx] = w[co][ci][6 - dy][6 - dx].  n_in / n_out: channel counts of the convolution being packed (<= 8).
+__global__ void pack_p2p_f16_raw_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin_fwd, int cout_fwd, int transpose_flip) {
+    __shared__ int smax[8];
+    const int n_in = transpose_flip ? cout_fwd : cin_fwd, n_out = transpose_flip ? cin_fwd : cout_fwd;
+    auto wv = [&](int o, int i, int dy, int dx) {
+        return transpose_flip ? w[((o < cin_fwd && i < cout_fwd ? i * cin_fwd + o : 0) * 7 + (6 - dy)) * 7 + (6 - dx)]
+                              : w[((o < cout_fwd && i < cin_fwd ? o * cin_fwd + i : 0) * 7 + dy) * 7 + dx];
+    };
+    if (threadIdx.x < 8) smax[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_out * n_in * 49; k += blockDim.x) {
+        const int o = k / (n_in * 49), r = k - o * n_in * 49, i = r / 49, t = r - i * 49;
+        atomicMax(&smax[o], __float_as_int(fabsf(wv(o, i, t / 7, t % 7))));
+    }
+    __syncthreads();
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // (ks, lane)
+    if (idx >= 14 * 64) return;
+    const int ks = idx / 64, lane = idx - ks * 64;
+    const int dy = ks >> 1, h = ks & 1;
+    const int n = lane & 15, qq = lane >> 4;
+    const int tau = n >> 3, co = n & 7;
+    const int dx = 4 * h + qq - tau;
+    const float sc = f16_weight_scale(__int_as_float(smax[co]));
+    if (ks == 0 && qq == 0 && tau == 0) reinterpret_cast<float*>(out + kP2pFragScale)[co] = 1.f / sc;
+    unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+    for (int ci = 0; ci < 8; ++ci) {
+        float v = 0.f;
+        if (dx >= 0 && dx < 7 && ci < n_in && co < n_out) v = sc * wv(co, ci, dy, dx);
+        const _Float16 hv = static_cast<_Float16>(v);
+        const unsigned int hb = __builtin_bit_cast(unsigned short, hv);
+        const unsigned int lb = f16_bits((v - static_cast<float>(hv)) * kP2pLoScale);
+        hi[ci >> 1] |= hb << (16 * (ci & 1));
+        lo[ci >> 1] |= lb << (16 * (ci & 1));
+    }
+    out[(2 * ks + 0) * 64 + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    out[(2 * ks + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
 // Pitch2PitchClassPool (models.py:95-106) of ready semitone maps [clip][C][S][T], S a multiple of 12: max over the octaves
