@@ -139,6 +139,24 @@ def test_single_layer_and_no_genre():
     assert rows[len(rows) // 2][0] < 1e-4, rows[:5]
 
 
+def test_narrow_net_gradients():
+    """n_filters = 2: the pitch stack has 4 channels (3 + 2 = 5 -> 4 -> 4 -> 4): the f16 x 3 training kernels run with fewer than 8 output
+    channels (masked stores, statistics of 4 channels) in the forward and with 3 / 4 in the data gradient."""
+    opt = Namespace(conv_layers=3, n_filters=2, head_layers=2, time_pool_size=2, genre=True, max_pool=False, frames=5)
+    torch.manual_seed(11)
+    net = ake_amd.PitchClassNet(288, 12, 2, 7, opt)
+    sd32 = {k: v.clone() for k, v in net.state_dict().items()}
+    x, seq, labels = make_case(3, 40, 2)
+    loss_ref, ref = reference_grads(sd32, x, seq, labels)
+    net = net.to(DEV).train()
+    out = net(x.to(DEV), seq.to(DEV))
+    loss = loss_fn(out[0], out[1], out[2], *(t.to(DEV) for t in labels))
+    assert abs(float(loss.detach()) - loss_ref) < 2e-5 * max(1.0, abs(loss_ref))
+    loss.backward()
+    rows = grad_errors(net, ref)
+    assert rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 1e-4, rows[:5]
+
+
 @pytest.mark.parametrize("with_seq", [True, False])
 def test_max_pool_gradients(gold_default, with_seq):
     """--max_pool (models.py:764-797): torch.max over the frames -- for every clip without seq_length, for clip 0 only with it (the
