@@ -254,7 +254,9 @@ def train_main(args):
     print(json.dumps({
         "metric": "clips/s, PitchClassNet training step (fwd + bwd + grad all-reduce + Adam)", "value": round(value, 1), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 storage, accumulation and gradients; pitch convs (forward, data gradient) as f16 hi + lo x 3 MFMA products (2^-22 of a product "
+                 "dropped), their weight gradient as split bf16 x 3, everything else f32 MFMA", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[3]: {B} clips per GPU (288x76 log-CQT resident), default PitchClassNet, local BatchNorm, "
                                f"one all-reduce of the flat gradient buffer per step, fused Adam lr 3e-4",
                    "clips_per_gpu": B, "parallelism": f"data-parallel x{world}"},
