@@ -704,10 +704,28 @@ int run_pc2pc_fused(const ake_pcnet* n, int i, const float* src, int cin, int ba
     return AKE_OK;
 }
 
+// does the f16 x 3 training form of conv_pc_bf16_kernel take this convolution (fragments built, patch fits the LDS)?
+bool pc_f16x3_ok(const PackedConv& pt, int T_in, bool same_time) {
+    static const bool off = std::getenv("AKE_PC_TRAIN_F32") != nullptr;
+    if (off || pt.bf_off < 0 || pt.cin > 16) return false;
+    const int T_out = same_time ? T_in : T_in - pt.kw + 1;
+    if (T_out < 1) return false;
+    const size_t lds = (static_cast<size_t>(2) * 12 * (T_out + 8) * 2 + 2 * 4 * (pt.cout / 16) * 2 * 64) * sizeof(uint4);
+    return lds <= 150 * 1024;
+}
+
+// training: NCHW f32 (+ the producer's pending BatchNorm + LeakyReLU) -> f16 hi / lo * 2^11 planes [hi: batch * 12 * T * 16][lo: ...]
+void run_nchw_to_cl16_f16x2(const float* src, int C, int batch, int T, const float* aff, unsigned short* planes, hipStream_t s) {
+    const long long npos = static_cast<long long>(batch) * 12 * T;
+    ake::ProfScope ps("nchw_to_cl16_f16x2_kernel", s);
+    hipLaunchKernelGGL(nchw_to_cl16_f16x2_kernel, dim3(static_cast<unsigned>((npos + 255) / 256)), dim3(256), 0, s, src, static_cast<long long>(C) * 12 * T, C, T,
+                       aff, planes, planes + npos * 16, npos);
+}
+
 // pitch-class convolution on bf16 MFMA (conv_pc_bf16_kernel): channels-last planes in; planes (cout == 16) or NCHW f32 out
 int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* planes_in, int batch, int T_in, bool same_time, bool lrelu,
                 float* dst_nchw, unsigned short* planes_out, hipStream_t s, const char* name, const PackedConv* pc2 = nullptr,
-                unsigned short* planes_out2 = nullptr) {
+                unsigned short* planes_out2 = nullptr, bool f16x3 = false, double* stats = nullptr, int stats_stride = 0) {
     PcBfArgs a;
     std::memset(&a, 0, sizeof(a));
     const long long npos_in = static_cast<long long>(batch) * 12 * T_in;
@@ -728,6 +746,8 @@ int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
         a.bfrag2 = n->bf_frags_dev + pc2->bf_off; a.bias2 = n->blob_dev + pc2->b_off;
         a.oh2 = planes_out2; a.ol2 = planes_out2 + static_cast<long long>(batch) * H_out * a.T_out * pc.cout;
     }
+    a.stats = stats; a.stats_stride = stats_stride;
+    AKE_REQUIRE(!f16x3 || (dst_nchw && !planes_out && !pc2), AKE_ERR_STATE, "conv %s: the f16 x 3 form writes NCHW f32", name);
     const size_t lds = (static_cast<size_t>(2) * 12 * a.Tp * 2 + 2 * 4 * (pc.cout / 16) * 2 * 64) * sizeof(uint4);   // patch + weight ring
     AKE_REQUIRE(lds <= 150 * 1024, AKE_ERR_UNSUPPORTED, "conv %s: %d frames do not fit the bf16 kernel's LDS patch", name, T_in);
     static ake::DeviceOnce attr_set;
@@ -736,13 +756,17 @@ int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
         AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set.mark();
     }
     const int tiles = (H_out * a.T_out + 15) / 16;
     const int waves = std::min(8, (tiles + 3) / 4);
     dim3 grid((tiles + waves * 4 - 1) / (waves * 4), pc2 ? 2 : 1, batch), block(waves * 64);
     ake::ProfScope ps(name, s);
-    if (pc.cout == 16 && planes_out) hipLaunchKernelGGL((conv_pc_bf16_kernel<1, true>), grid, block, lds, s, a);
+    if (f16x3 && pc.cout == 16) hipLaunchKernelGGL((conv_pc_bf16_kernel<1, false, true>), grid, block, lds, s, a);
+    else if (f16x3) hipLaunchKernelGGL((conv_pc_bf16_kernel<2, false, true>), grid, block, lds, s, a);
+    else if (pc.cout == 16 && planes_out) hipLaunchKernelGGL((conv_pc_bf16_kernel<1, true>), grid, block, lds, s, a);
     else if (pc.cout == 16) hipLaunchKernelGGL((conv_pc_bf16_kernel<1, false>), grid, block, lds, s, a);
     else if (planes_out) hipLaunchKernelGGL((conv_pc_bf16_kernel<2, true>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((conv_pc_bf16_kernel<2, false>), grid, block, lds, s, a);
@@ -1440,6 +1464,20 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
                 pd.bf_off = static_cast<long long>(count); count += kBfFragsPerConv;
                 tfr.push_back({&pd, raw, pt.cin, pt.cout, 1});
             }
+    // training-mode forward of the pitch-class convs with 16 / 32 output channels (conv_pc_bf16_kernel<.., F16X3>): f16 hi + lo fragments
+    // from the training packs (raw weights in the VALU layout)
+    std::vector<PackedConv*> tpc;
+    if (!n->raw_w_off.empty() && !n->cfg.resblock && !n->cfg.denseblock) {
+        for (size_t i = 1; i < n->pc2pc_t.size(); ++i)
+            for (PackedConv& pc : n->pc2pc_t[i]) tpc.push_back(&pc);
+        if (!n->head_key_t.empty()) tpc.push_back(&n->head_key_t[0]);
+        if (!n->head_tonic_t.empty()) tpc.push_back(&n->head_tonic_t[0]);
+        if (n->head_genre_t.size() == 2) tpc.push_back(&n->head_genre_t[0]);
+    }
+    for (PackedConv* pc : tpc) {
+        pc->bf_off = -1;
+        if (pc_bf16_eligible(*pc)) { pc->bf_off = static_cast<long long>(count); count += static_cast<size_t>(pc->kh) * 4 * (pc->cout / 16) * 2 * 64 + 64; }
+    }
     std::vector<PackedConv*> pcs;                             // pitch-class convolutions: the PitchClass2PitchClass stacks and the heads' first conv
     for (auto& layer : n->pc2pc)
         for (PackedConv& pc : layer) pcs.push_back(&pc);
@@ -1493,6 +1531,12 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
         for (const PackedConv& pc : n->pc2pc[0])
             if (pc.l0_off >= 0)
                 hipLaunchKernelGGL(pack_l0_f16_kernel, dim3(3), dim3(256), 0, s, n->blob_dev + pc.w_off, n->bf_frags_dev + pc.l0_off, pc.cin, pc.cout);
+    for (const PackedConv* pc : tpc)
+        if (pc->bf_off >= 0) {
+            const int NT = pc->cout / 16;
+            hipLaunchKernelGGL(pack_pc_f16x3_kernel, dim3((pc->kh * 4 * NT * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
+                               n->bf_frags_dev + pc->bf_off, pc->cin, pc->cout, pc->co, NT, pc->kh);
+        }
     for (const TrainFrag& t : tfr)
         hipLaunchKernelGGL(pack_p2p_f16_raw_kernel, dim3((14 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + t.raw, n->bf_frags_dev + t.pc->bf_off, t.cin, t.cout, t.flip);
     for (size_t i = 1; i < n->semi.size(); ++i)
@@ -2161,6 +2205,18 @@ struct Fwd {
                     return rc;
                 continue;
             }
+            if (train && L > 1 && pc_f16x3_ok(n->pc2pc_t[i][j], Ti, true)) {   // f16 x 3 MFMA (f32-equivalent products) instead of the f32 MFMA kernel
+                const PackedConv& pt = n->pc2pc_t[i][j];
+                unsigned short* planes = reinterpret_cast<unsigned short*>(b.pcb[i]);       // (the inference ping-pong buffer: idle in training)
+                run_nchw_to_cl16_f16x2(psrc, cin, B, Ti, psrc_aff, planes, s);
+                const int bn = bn_of(m + std::to_string(3 * j + 1));
+                if ((rc = run_pc_bf16(n, pt, planes, B, Ti, true, false, pdst, nullptr, s, "conv_pc_f16x3_kernel/pc2pc", nullptr, nullptr, true,
+                                      b.stats + 2 * n->bns[bn].ch_off, 2 * n->bn_channels)))
+                    return rc;
+                finalize_bn(bn, static_cast<double>(B) * 12 * Ti, pdst_aff);
+                psrc = pdst; psrc_aff = pdst_aff; cin = cout;
+                continue;
+            }
             if ((rc = conv(n->pc2pc[i][j], train ? n->pc2pc_t[i][j] : n->pc2pc[i][j], m + std::to_string(3 * j + 1), 1,
                            Src{psrc, cin, nullptr, 0, 0}, psrc_aff, B, 12, Ti, true, pdst, cout, 0, pdst_aff,
                            L == 1 ? "conv_mfma_kernel/pc2pc0" : "conv_mfma_kernel/pc2pc")))
@@ -2182,6 +2238,7 @@ struct Fwd {
                             {&n->head_tonic, &n->head_tonic_t, b.hid_t, b.map_t, 1, "tonic_classifier"},
                             {&n->head_genre, &n->head_genre_t, b.hid_g, b.map_g, 2, "genre_classifier"}};
         int Tm = Tf;
+        bool head_planes_ready = false;           // training: the f16 hi / lo planes of the pooled features (b.feat_cl) exist
         int pooled_heads = 0;                     // heads whose outputs conv_head1_bf16_kernel already wrote
         // key / tonic heads: the first convolution (16 -> 32 channels, most of a head's work) on the bf16 kernel; both read the same
         // channels-last copy of the features
@@ -2248,6 +2305,22 @@ struct Fwd {
                 float* aff = (!train || lastj) ? nullptr : b.aff_hst[h][j];
                 if (head_bf && h < 2 && j == 0) {
                     if ((rc = run_pc_bf16(n, pe, feat_cl, B, Tcur, false, true, dst, nullptr, s, "conv_pc_bf16_kernel/head"))) return rc;
+                    src = dst; src_aff = aff; hc = pe.cout; Tcur -= c.kernel_size - 1;
+                    continue;
+                }
+                if (train && j == 0 && !lastj && pc_f16x3_ok((*heads[h].ct)[0], Tcur, false)) {   // the heads' first convs: f16 x 3 MFMA
+                    const PackedConv& pt = (*heads[h].ct)[0];
+                    if (!head_planes_ready) {               // one conversion of the pooled features serves the three heads
+                        run_nchw_to_cl16_f16x2(src, hc, B, Tcur, src_aff, b.feat_cl, s);
+                        head_planes_ready = true;
+                    }
+                    const int bn = bn_of(std::string(heads[h].nm) + ".1");
+                    if ((rc = run_pc_bf16(n, pt, b.feat_cl, B, Tcur, false, false, dst, nullptr, s,
+                                          h == 2 ? "conv_pc_f16x3_kernel/genre_head" : "conv_pc_f16x3_kernel/head", nullptr, nullptr, true,
+                                          b.stats + 2 * n->bns[bn].ch_off, 2 * n->bn_channels)))
+                        return rc;
+                    const int H_out = heads[h].kind == 2 ? 12 - pt.kh + 1 : 12;
+                    finalize_bn(bn, static_cast<double>(B) * H_out * (Tcur - pt.kw + 1), aff);
                     src = dst; src_aff = aff; hc = pe.cout; Tcur -= c.kernel_size - 1;
                     continue;
                 }

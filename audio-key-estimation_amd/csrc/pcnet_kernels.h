@@ -666,6 +666,14 @@ constexpr float kP2pLoScale = 2048.f, kP2pLoInv = 1.f / 2048.f;     // the lo we
 constexpr int kP2pFragScale = 14 * 2 * 64;                           // uint4 index of the 8 per-channel inverse scales behind a conv's fragments
 // v_cvt_f16_f32 saturates to +-65504 instead of producing inf (MODE.FP16_OVFL, bit 23)
 __device__ __forceinline__ void f16_saturate_mode() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
+// power of two s with s * wmax in [2^13, 2^14) (1 for an all-zero channel): the channel's weights use f16's normal range whatever
+// BatchNorm folded into them
+__device__ __forceinline__ float f16_weight_scale(float wmax) {
+    if (!(wmax > 0.f) || !(wmax < INFINITY)) return 1.f;
+    int e;
+    frexpf(wmax, &e);                                         // wmax = m * 2^e, m in [0.5, 1)
+    return ldexpf(1.f, 14 - e < 100 ? 14 - e : 100);          // (a channel of f32 denormals: the scale itself must stay finite)
+}
 __device__ __forceinline__ unsigned int f16_bits(float v) { return __builtin_bit_cast(unsigned short, static_cast<_Float16>(v)); }
 constexpr bool kP2pStreamB = true;
 constexpr int kP2pMT = 3;            // M-tiles (16 positions) per wave
@@ -1378,9 +1386,17 @@ struct PcBfArgs {
     const float* bias2;
     unsigned short* oh2;
     unsigned short* ol2;
+    // F16X3 (training): per-channel statistics of the raw output, [kStatSlots][stats_stride] doubles (fixed point), (sum, sum of squares)
+    // of channel c at 2c, 2c + 1; or null
+    double* stats;
+    int stats_stride;
 };
 
-template <int NT, bool OUT_CL>
+// F16X3 (training mode; forward with BatchNorm-on-load planes and the data gradients): the planes and fragments hold f16 hi and
+// f16 lo * 2^11 instead of bf16 hi / lo, the products are xh*wh and (xl'*wh + xh*wl') in an accumulator of their own folded in with 2^-11
+// (2^-22 of a product dropped: f32-equivalent, the gradient tests hold 2e-5), every output channel's weights are scaled by a power of
+// two (inverse scales behind the fragments), and the raw output's per-channel sums go to the BatchNorm statistics.
+template <int NT, bool OUT_CL, bool F16X3 = false>
 __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
     const int clip = blockIdx.z;
@@ -1441,11 +1457,14 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
         at[mt] = m - ay[mt] * a.T_out;
     }
     typedef float f32x4c __attribute__((ext_vector_type(4)));
-    f32x4c acc[MT][NT];
+    f32x4c acc[MT][NT], accl[F16X3 ? MT : 1][F16X3 ? NT : 1];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4c{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] = f32x4c{0.f, 0.f, 0.f, 0.f};
+            if (F16X3) accl[mt][nt] = f32x4c{0.f, 0.f, 0.f, 0.f};
+        }
     const int dxq = q >> 1, half = q & 1;
     for (int dy = 0; dy < a.KH; ++dy) {
         if (dy + 1 < a.KH) fetch_row(dy + 1);                 // lands in the other half during this row's MFMAs
@@ -1460,26 +1479,36 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            bf16x8c bh[NT], bl[NT];
+            uint4 bhu[NT], blu[NT], ahu[MT], alu[MT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                bh[nt] = __builtin_bit_cast(bf16x8c, wr[((p * NT + nt) * 2 + 0) * 64]);
-                bl[nt] = __builtin_bit_cast(bf16x8c, wr[((p * NT + nt) * 2 + 1) * 64]);
+                bhu[nt] = wr[((p * NT + nt) * 2 + 0) * 64];
+                blu[nt] = wr[((p * NT + nt) * 2 + 1) * 64];
             }
-            bf16x8c ah[MT], al[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                ah[mt] = __builtin_bit_cast(bf16x8c, pH[rowoff[mt] + 4 * p]);
-                al[mt] = __builtin_bit_cast(bf16x8c, pL[rowoff[mt] + 4 * p]);
+                ahu[mt] = pH[rowoff[mt] + 4 * p];
+                alu[mt] = pL[rowoff[mt] + 4 * p];
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
+                if (F16X3) {
+                    const f16x8c bh = __builtin_bit_cast(f16x8c, bhu[nt]), bl = __builtin_bit_cast(f16x8c, blu[nt]);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8c, ahu[mt]), bh, acc[mt][nt], 0, 0, 0);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt) accl[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8c, alu[mt]), bh, accl[mt][nt], 0, 0, 0);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt) accl[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8c, ahu[mt]), bl, accl[mt][nt], 0, 0, 0);
+                } else {
+                    const bf16x8c bh = __builtin_bit_cast(bf16x8c, bhu[nt]), bl = __builtin_bit_cast(bf16x8c, blu[nt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8c, ahu[mt]), bh, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8c, alu[mt]), bh, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8c, ahu[mt]), bl, acc[mt][nt], 0, 0, 0);
+                }
             }
         }
         }
@@ -1493,7 +1522,10 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = nt * 16 + r16;
-        const float bias = co < a.cout ? (second ? a.bias2 : a.bias)[co] : 0.f;
+        const float* const bptr = second ? a.bias2 : a.bias;
+        const float bias = (co < a.cout && bptr) ? bptr[co] : 0.f;
+        const float iscale = (F16X3 && co < a.cout) ? reinterpret_cast<const float*>(bfr + a.KH * 4 * NT * 2 * 64)[co] : 1.f;
+        float st1 = 0.f, st2 = 0.f;
         unsigned short* const oh = second ? a.oh2 : a.oh;
         unsigned short* const ol = second ? a.ol2 : a.ol;
 #pragma unroll
@@ -1503,7 +1535,8 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (m0 + i < Mtot && co < a.cout) {
-                    float v = acc[mt][nt][i] + bias;
+                    float v = F16X3 ? fmaf(fmaf(accl[F16X3 ? mt : 0][F16X3 ? nt : 0][i], kP2pLoInv, acc[mt][nt][i]), iscale, bias) : acc[mt][nt][i] + bias;
+                    if (F16X3) { st1 += v; st2 = fmaf(v, v, st2); }
                     if (a.lrelu) v = v > 0.f ? v : v * kSlope;
                     if (OUT_CL) {
                         const long long idx = ((static_cast<long long>(clip) * H_out + y) * a.T_out + t) * a.cl_stride + co;
@@ -1515,6 +1548,15 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
                     }
                 }
                 if (++t == a.T_out) { t = 0; ++y; }
+            }
+        }
+        if (F16X3 && a.stats) {   // channel co's statistics: the four q-groups of lanes hold different positions
+            st1 += __shfl_xor(st1, 16); st2 += __shfl_xor(st2, 16);
+            st1 += __shfl_xor(st1, 32); st2 += __shfl_xor(st2, 32);
+            if (q == 0 && co < a.cout) {
+                double* st = a.stats + static_cast<size_t>((blockIdx.x + 7 * blockIdx.z + wave) & (kStatSlots - 1)) * a.stats_stride;
+                fx_add(st + 2 * co, st1, kFxStat);
+                fx_add(st + 2 * co + 1, st2, kFxStat);
             }
         }
     }
@@ -1907,6 +1949,70 @@ __global__ void nchw_to_cl16_kernel(const float* __restrict__ src, long long src
     ol[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]); ol[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
 }
 
+// training: NCHW f32 [clip][C][12][T] (C <= 16), with the pending BatchNorm + LeakyReLU of its producer applied (aff: [C][3] scale, shift,
+// negative slope; or null) -> channels-last planes [clip][12][T][16] of f16 hi and f16 lo * 2^11 (conv_pc_bf16_kernel<.., F16X3>)
+__global__ void nchw_to_cl16_f16x2_kernel(const float* __restrict__ src, long long src_clip_stride, int C, int T, const float* __restrict__ aff,
+                                          unsigned short* __restrict__ xh, unsigned short* __restrict__ xl, long long npos) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;      // (clip, row, t)
+    if (i >= npos) return;
+    const int t = static_cast<int>(i % T);
+    const long long r = i / T;
+    const int y = static_cast<int>(r % 12);
+    const long long clip = r / 12;
+    const float* s = src + clip * src_clip_stride + static_cast<long long>(y) * T + t;
+    unsigned int hi[8], lo[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { hi[k] = 0; lo[k] = 0; }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float v = 0.f;
+        if (c < C) {
+            v = s[static_cast<long long>(c) * 12 * T];
+            if (aff) { v = fmaf(v, aff[3 * c], aff[3 * c + 1]); v = v > 0.f ? v : v * aff[3 * c + 2]; }
+        }
+        const _Float16 h = static_cast<_Float16>(v);
+        hi[c >> 1] |= static_cast<unsigned int>(__builtin_bit_cast(unsigned short, h)) << (16 * (c & 1));
+        lo[c >> 1] |= f16_bits((v - static_cast<float>(h)) * kP2pLoScale) << (16 * (c & 1));
+    }
+    uint4* oh = reinterpret_cast<uint4*>(xh) + i * 2;
+    uint4* ol = reinterpret_cast<uint4*>(xl) + i * 2;
+    oh[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); oh[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+    ol[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]); ol[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+}
+
+// f16 hi / lo * 2^11 weight fragments of conv_pc_bf16_kernel<.., F16X3> (same order as pack_pc_bf16_kernel), every output channel scaled
+// into [2^13, 2^14); the cout inverse scales follow the fragments.  From the VALU-layout TRAINING pack [co group of CO][ci][KH][7][CO].
+__global__ void pack_pc_f16x3_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin, int cout, int CO, int NT, int KH) {
+    __shared__ int smax[32];
+    if (threadIdx.x < 32) smax[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < cout * cin * KH * 7; k += blockDim.x) {
+        const int c = k % CO, r = k / CO;                    // r = ((g * cin + ci) * KH + dy) * 7 + dx
+        const int g = r / (cin * KH * 7);
+        atomicMax(&smax[g * CO + c], __float_as_int(fabsf(w[k])));
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= KH * 4 * NT * 64) return;
+    const int lane = i & 63, nt = (i >> 6) % NT, ks = i / (64 * NT);
+    const int dy = ks >> 2, p = ks & 3;
+    const int co = nt * 16 + (lane & 15), qq = lane >> 4;
+    const int dx = 2 * p + (qq >> 1), c8 = 8 * (qq & 1);
+    const float sc = co < cout ? f16_weight_scale(__int_as_float(smax[co])) : 1.f;
+    if (ks == 0 && qq == 0 && co < cout) reinterpret_cast<float*>(out + KH * 4 * NT * 2 * 64)[co] = 1.f / sc;
+    unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+    for (int e = 0; e < 8; ++e) {
+        const int ci = c8 + e;
+        float v = 0.f;
+        if (dx < 7 && ci < cin && co < cout) v = sc * w[((((co / CO) * cin + ci) * KH + dy) * 7 + dx) * CO + (co % CO)];
+        const _Float16 hv = static_cast<_Float16>(v);
+        hi[e >> 1] |= static_cast<unsigned int>(__builtin_bit_cast(unsigned short, hv)) << (16 * (e & 1));
+        lo[e >> 1] |= f16_bits((v - static_cast<float>(hv)) * kP2pLoScale) << (16 * (e & 1));
+    }
+    out[((ks * NT + nt) * 2 + 0) * 64 + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    out[((ks * NT + nt) * 2 + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
 // debug taps: channels-last split-bf16 planes (xl != null) or one f16 plane (xl == null) [clip][H][T][C] -> NCHW f32 [clip][C][H][T]
 __global__ void cl_to_nchw_kernel(const unsigned short* __restrict__ xh, const unsigned short* __restrict__ xl, float* __restrict__ out, int C, int H,
                                   int T, long long total) {
@@ -1926,14 +2032,6 @@ __global__ void cl_to_nchw_kernel(const unsigned short* __restrict__ xh, const u
 // B fragments of conv_p2p_f16_kernel from the VALU-layout eval pack [ci < cin][dy][dx][8 co] (BatchNorm already folded; input
 // channels >= cin get zero weights): f16 hi = rn(w), f16 lo = rn((w - hi) * 2^11);
 // one thread per (k-step, lane, element).
-// power of two s with s * wmax in [2^13, 2^14) (1 for an all-zero channel): the channel's weights use f16's normal range whatever
-// BatchNorm folded into them
-__device__ __forceinline__ float f16_weight_scale(float wmax) {
-    if (!(wmax > 0.f) || !(wmax < INFINITY)) return 1.f;
-    int e;
-    frexpf(wmax, &e);                                         // wmax = m * 2^e, m in [0.5, 1)
-    return ldexpf(1.f, 14 - e < 100 ? 14 - e : 100);          // (a channel of f32 denormals: the scale itself must stay finite)
-}
 
 // max |w| of each of the 8 output channels of a pack [n_k][8 co], by the whole block (bit patterns of non-negative floats order as ints)
 __device__ __forceinline__ void channel_absmax8(const float* __restrict__ w, int n_k, int* smax) {
