@@ -3,7 +3,7 @@
 // ake_pcnet_backward_f32 consumes the workspace left by ake_pcnet_forward_train_f32 (raw convolution outputs, BatchNorm
 // batch statistics and affine tables) and the gradients of the loss with respect to the three outputs, and writes
 // dL/d(parameter) for every float entry of the state_dict into one flat buffer (layout: ake_pcnet_grad_offset).
-// Built for num_layers <= 2 (the reference default); deeper nets return AKE_ERR_UNSUPPORTED.
+// Any num_layers >= 1 (the reference default is 2): the layer walk below loops over models.py:370-396 backwards.
 #pragma once
 
 namespace {
@@ -68,68 +68,72 @@ struct Bwd {
             hipLaunchKernelGGL(conv_wgrad_p2p_bf16_kernel, grid, dim3(256), lds, s, w);
             return AKE_OK;
         }
-        WgradArgs wa;
-        std::memset(&wa, 0, sizeof(wa));
-        ConvArgs& a = wa.c;
-        a.src0 = src.p0; a.c0 = src.c0; a.src1 = src.p1; a.c1 = src.c1; a.h1 = src.h1 > 0 ? src.h1 : 1;
-        a.H = H; a.T_in = T_in;
-        a.src0_clip_stride = static_cast<long long>(src.c0) * H * T_in;
-        a.src1_clip_stride = static_cast<long long>(src.c1) * a.h1 * T_in;
-        if (kind == 0) { a.py = pc.kh / 2; a.pad_l = pc.kw / 2; a.time_circ = 1; a.T_out = T_in; a.H_out = H; }
-        else {
-            a.py = 0; a.time_circ = 0;
-            a.pad_l = same_time ? pc.kw / 2 : 0;
-            a.T_out = same_time ? T_in : T_in - pc.kw + 1;
-            a.H_out = kind == 1 ? H : H - pc.kh + 1;
-        }
-        a.cout = pc.cout;
-        a.dst = const_cast<float*>(dz); a.dst_coff = dz_coff; a.dst_clip_stride = static_cast<long long>(dz_ctot) * a.H_out * a.T_out;
-        a.in_affine = in_aff;
-        wa.dW = dW; wa.slot_stride = static_cast<long long>(n->grad_floats); wa.KH = pc.kh; wa.KW = pc.kw;
-        static const bool noflush = std::getenv("AKE_WGRAD_NOFLUSH") != nullptr;
-        wa.dbg_noflush = noflush ? 1 : 0;
-        const int KK = pc.kh * pc.kw;
-        const int MTC = (pc.cout + 15) / 16, NTK = (KK + 15) / 16;
-        // tile: rows x frames such that the patch of 8 channels + the dz tile fit the LDS budget
-        const int T4 = (a.T_out + 3) / 4 * 4;
-        int TT = std::min(T4, 128);
-        int R = kind == 0 ? std::min(H, 16) : H;
-        auto lds_of = [&](int R_, int TT_) {
-            const int Tp = (TT_ + pc.kw - 1 + 3) / 4 * 4;
-            return (static_cast<size_t>(8) * (R_ + pc.kh - 1) * Tp + static_cast<size_t>(pc.cout) * R_ * TT_) * sizeof(float);
-        };
-        while (lds_of(R, TT) > kLdsBudget && kind == 0 && R > 1) --R;
-        while (lds_of(R, TT) > kLdsBudget && TT > 4) TT -= 4;
-        AKE_REQUIRE(lds_of(R, TT) <= 160 * 1024, AKE_ERR_UNSUPPORTED, "wgrad %s: tile does not fit LDS", name);
-        a.R = R; a.TT = TT; a.Tp = (TT + pc.kw - 1 + 3) / 4 * 4;
-        a.n_row_tiles = (a.H_out + R - 1) / R;
-        a.n_time_tiles = (a.T_out + TT - 1) / TT;
-        const int tiles = a.n_row_tiles * a.n_time_tiles;
-        // workgroups per clip: 4 at training batch sizes (fewer atomics), more for small batches so that the chip still fills
-        const int wgs_per_clip = std::min(tiles, std::max(4, (512 + B - 1) / B));
-        wa.rt_per_block = std::max(1, (tiles + wgs_per_clip - 1) / wgs_per_clip);
-        dim3 grid((tiles + wa.rt_per_block - 1) / wa.rt_per_block, 1, B), block(512);
-        const size_t lds = lds_of(R, TT);
-        // partial sums per workgroup + an ordered reduction when the scratch buffer holds them (see WgradArgs::partial)
-        const long long n_w = static_cast<long long>(pc.cout) * (src.c0 + src.c1) * KK;
-        const long long n_wg = static_cast<long long>(grid.x) * B;
-        static const bool partial_off = std::getenv("AKE_WGRAD_ATOMIC") != nullptr;
-        const bool use_partial = !partial_off && b.wg_partial && n_wg * n_w <= static_cast<long long>(b.wg_partial_floats);
-        if (use_partial) { wa.partial = b.wg_partial; wa.partial_stride = n_w; }
-        bool launched = false;
-        {
-            ake::ProfScope ps(name, s);
-#define AKE_WG(M_, N_) if (!launched && MTC == M_ && NTK == N_) { hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_>), grid, block, lds, s, wa); launched = true; }
-            AKE_WG(1, 4) AKE_WG(1, 6) AKE_WG(2, 6) AKE_WG(1, 1) AKE_WG(2, 1) AKE_WG(1, 2) AKE_WG(2, 2)
-#undef AKE_WG
-        }
-        if (!launched) {
-            ake::set_error("wgrad %s: no kernel for cout=%d taps=%d", name, pc.cout, KK);
-            return AKE_ERR_UNSUPPORTED;
-        }
-        if (use_partial) {
-            ake::ProfScope ps("wgrad_partial_reduce_kernel", s);
-            hipLaunchKernelGGL(wgrad_partial_reduce_kernel, dim3(static_cast<unsigned>((n_w + 63) / 64)), dim3(1024), 0, s, b.wg_partial, static_cast<int>(n_wg), n_w, dW);
+        // the kernel's accumulator tiles cover <= 32 output channels: wider convolutions (deeper / wider nets) run as slices of 32
+        for (int co0 = 0; co0 < pc.cout; co0 += 32) {
+            const int co_n = std::min(32, pc.cout - co0);
+            WgradArgs wa;
+            std::memset(&wa, 0, sizeof(wa));
+            ConvArgs& a = wa.c;
+            a.src0 = src.p0; a.c0 = src.c0; a.src1 = src.p1; a.c1 = src.c1; a.h1 = src.h1 > 0 ? src.h1 : 1;
+            a.H = H; a.T_in = T_in;
+            a.src0_clip_stride = static_cast<long long>(src.c0) * H * T_in;
+            a.src1_clip_stride = static_cast<long long>(src.c1) * a.h1 * T_in;
+            if (kind == 0) { a.py = pc.kh / 2; a.pad_l = pc.kw / 2; a.time_circ = 1; a.T_out = T_in; a.H_out = H; }
+            else {
+                a.py = 0; a.time_circ = 0;
+                a.pad_l = same_time ? pc.kw / 2 : 0;
+                a.T_out = same_time ? T_in : T_in - pc.kw + 1;
+                a.H_out = kind == 1 ? H : H - pc.kh + 1;
+            }
+            a.cout = co_n;
+            a.dst = const_cast<float*>(dz); a.dst_coff = dz_coff + co0; a.dst_clip_stride = static_cast<long long>(dz_ctot) * a.H_out * a.T_out;
+            a.in_affine = in_aff;
+            wa.dW = dW + static_cast<long long>(co0) * (src.c0 + src.c1) * pc.kh * pc.kw; wa.slot_stride = static_cast<long long>(n->grad_floats); wa.KH = pc.kh; wa.KW = pc.kw;
+            static const bool noflush = std::getenv("AKE_WGRAD_NOFLUSH") != nullptr;
+            wa.dbg_noflush = noflush ? 1 : 0;
+            const int KK = pc.kh * pc.kw;
+            const int MTC = (co_n + 15) / 16, NTK = (KK + 15) / 16;
+            // tile: rows x frames such that the patch of 8 channels + the dz tile fit the LDS budget
+            const int T4 = (a.T_out + 3) / 4 * 4;
+            int TT = std::min(T4, 128);
+            int R = kind == 0 ? std::min(H, 16) : H;
+            auto lds_of = [&](int R_, int TT_) {
+                const int Tp = (TT_ + pc.kw - 1 + 3) / 4 * 4;
+                return (static_cast<size_t>(8) * (R_ + pc.kh - 1) * Tp + static_cast<size_t>(co_n) * R_ * TT_) * sizeof(float);
+            };
+            while (lds_of(R, TT) > kLdsBudget && kind == 0 && R > 1) --R;
+            while (lds_of(R, TT) > kLdsBudget && TT > 4) TT -= 4;
+            AKE_REQUIRE(lds_of(R, TT) <= 160 * 1024, AKE_ERR_UNSUPPORTED, "wgrad %s: tile does not fit LDS", name);
+            a.R = R; a.TT = TT; a.Tp = (TT + pc.kw - 1 + 3) / 4 * 4;
+            a.n_row_tiles = (a.H_out + R - 1) / R;
+            a.n_time_tiles = (a.T_out + TT - 1) / TT;
+            const int tiles = a.n_row_tiles * a.n_time_tiles;
+            // workgroups per clip: 4 at training batch sizes (fewer atomics), more for small batches so that the chip still fills
+            const int wgs_per_clip = std::min(tiles, std::max(4, (512 + B - 1) / B));
+            wa.rt_per_block = std::max(1, (tiles + wgs_per_clip - 1) / wgs_per_clip);
+            dim3 grid((tiles + wa.rt_per_block - 1) / wa.rt_per_block, 1, B), block(512);
+            const size_t lds = lds_of(R, TT);
+            // partial sums per workgroup + an ordered reduction when the scratch buffer holds them (see WgradArgs::partial)
+            const long long n_w = static_cast<long long>(co_n) * (src.c0 + src.c1) * KK;
+            const long long n_wg = static_cast<long long>(grid.x) * B;
+            static const bool partial_off = std::getenv("AKE_WGRAD_ATOMIC") != nullptr;
+            const bool use_partial = !partial_off && b.wg_partial && n_wg * n_w <= static_cast<long long>(b.wg_partial_floats);
+            if (use_partial) { wa.partial = b.wg_partial; wa.partial_stride = n_w; }
+            bool launched = false;
+            {
+                ake::ProfScope ps(name, s);
+    #define AKE_WG(M_, N_) if (!launched && MTC == M_ && NTK == N_) { hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_>), grid, block, lds, s, wa); launched = true; }
+                AKE_WG(1, 4) AKE_WG(2, 4) AKE_WG(1, 6) AKE_WG(2, 6) AKE_WG(1, 1) AKE_WG(2, 1) AKE_WG(1, 2) AKE_WG(2, 2)
+    #undef AKE_WG
+            }
+            if (!launched) {
+                ake::set_error("wgrad %s: no kernel for cout=%d taps=%d", name, co_n, KK);
+                return AKE_ERR_UNSUPPORTED;
+            }
+            if (use_partial) {
+                ake::ProfScope ps("wgrad_partial_reduce_kernel", s);
+                hipLaunchKernelGGL(wgrad_partial_reduce_kernel, dim3(static_cast<unsigned>((n_w + 63) / 64)), dim3(1024), 0, s, b.wg_partial, static_cast<int>(n_wg), n_w, wa.dW);
+            }
         }
         return AKE_OK;
     }
@@ -184,7 +188,6 @@ struct Bwd {
     int run(const float* mel, const int64_t* seq, const float* d_key, const float* d_tonic, const float* d_genre, const float* key_out) {
         const auto& c = n->cfg;
         const int L = c.num_layers, P = c.pitches, tp = c.time_pool_size;
-        AKE_REQUIRE(L <= 2, AKE_ERR_UNSUPPORTED, "backward: num_layers > 2 is not built yet");
         int rc;
         const int Tf = b.Tf;
         const int Tm = Tf - (c.kernel_size - 1) * c.head_layers;
@@ -259,7 +262,7 @@ struct Bwd {
             const long long total = static_cast<long long>(B) * d.out_pc * 12 * ((Ti / tp) + (Ti % tp ? 1 : 0));
             ake::ProfScope ps("time_pool_bwd_kernel", s);
             hipLaunchKernelGGL(time_pool_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_pcf, b.pcst[i].back(),
-                               b.aff_pcst[i].back(), g_last, d.out_pc, 12, Ti, tp, d.out_pc, 0, total);
+                               b.aff_pcst[i].back(), g_last, d.out_pc, 12, Ti, tp, d.out_pc, 0, total, 0);
         }
         if (L == 1) {
             // single layer: pc2pc0 stack straight down to fold0
@@ -269,55 +272,81 @@ struct Bwd {
             return semi_backward(0, mel, nullptr, b.g_fold0, 1, 0, nullptr);
         }
 
-        // ---- layer 1: pc2pc stack (input = concat buffer) ----
-        const int ctot = d.prev_pc + d.out_p;
-        if ((rc = stack_backward(n->pc2pc_t[1], n->pc2pc_d[1], "model.1.pc2pc.layer.", true, 1, Src{b.cat[1], ctot, nullptr, 0, 0}, b.aff_cat[1],
-                                 b.pcst[1], b.aff_pcst[1], 12, Ti, g_last, g_last2, b.g_cat[1], ctot, "conv_wgrad_kernel/pc2pc", "conv_mfma_kernel/pc2pc_dgrad")))
-            return rc;
-        // channels [prev_pc, ctot) of g_cat: gradient of the folded semitone features -> pool_semi(1) -> pitch stream
-        const std::vector<float*>& zp = b.pst[1];
-        float* g_p = b.g_p[1];
-        float* g_p2 = b.g_p[1] + static_cast<size_t>(B) * d.out_p * P * Ti;
-        if ((rc = semi_backward(1, zp.back(), b.aff_pst[1].back(), b.g_cat[1], ctot, d.prev_pc, g_p))) return rc;
-        // ---- pitch convs; input = (mel | psix repeated) ----
-        Src pin{mel, d.prev_p, b.psix[1], d.prev_pc, 36};
-        if ((rc = stack_backward(n->p2p_t[1], n->p2p_d[1], "model.1.p2p.layer.", false, 0, pin, b.aff_p2pin[1], zp, b.aff_pst[1], P, Ti, g_p, g_p2,
-                                 b.g_pin[1], d.prev_p + d.prev_pc, "conv_wgrad_kernel/p2p", "conv_mfma_kernel/p2p_dgrad")))
-            return rc;
-        // ---- repeat (x P/36) backward, then up_sixth ----
-        {
-            const long long total = static_cast<long long>(B) * d.prev_pc * 36 * Ti;
-            ake::ProfScope ps("repeat_sum_kernel", s);
-            hipLaunchKernelGGL(repeat_sum_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_pin[1], b.g_psix[1],
-                               d.prev_p + d.prev_pc, d.prev_p, d.prev_pc, P, Ti, total);
+        // ---- layers L-1 .. 1 (models.py:370-396 backwards).  g_pc[i] holds dL/d(activation of layer i's last pc2pc conv) on entry ----
+        for (int li = L - 1; li >= 1; --li) {
+            const LayerDims& dl = n->dims[li];
+            const int Tl = b.Tl[li];
+            const int ctot = dl.prev_pc + dl.out_p;
+            const bool inner = li < L - 1;
+            const std::string m = "model." + std::to_string(li) + ".";
+            float* gl = b.g_pc[li];
+            float* gl2 = gl + static_cast<size_t>(B) * dl.out_pc * 12 * Tl;
+            // pc2pc stack (input = concat buffer: pitch classes of the layer below | folded semitone maps)
+            if ((rc = stack_backward(n->pc2pc_t[li], n->pc2pc_d[li], m + "pc2pc.layer.", true, 1, Src{b.cat[li], ctot, nullptr, 0, 0}, b.aff_cat[li],
+                                     b.pcst[li], b.aff_pcst[li], 12, Tl, gl, gl2, b.g_cat[li], ctot, "conv_wgrad_kernel/pc2pc", "conv_mfma_kernel/pc2pc_dgrad")))
+                return rc;
+            // channels [prev_pc, ctot) of g_cat: gradient of the folded semitone features -> pool_semi(li) -> pitch stream
+            const std::vector<float*>& zp = b.pst[li];
+            float* g_p = b.g_p[li];
+            float* g_p2 = b.g_p[li] + static_cast<size_t>(B) * dl.out_p * P * Tl;
+            if ((rc = semi_backward(li, zp.back(), b.aff_pst[li].back(), b.g_cat[li], ctot, dl.prev_pc, g_p))) return rc;
+            if (inner) {   // second consumer of an inner layer's pitch stream: its time-pooled copy is the next layer's pitch input (models.py:395)
+                const LayerDims& dn = n->dims[li + 1];
+                const long long total = static_cast<long long>(B) * dl.out_p * P * ((Tl / tp) + (Tl % tp ? 1 : 0));
+                ake::ProfScope ps("time_pool_bwd_kernel", s);
+                hipLaunchKernelGGL(time_pool_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_pin[li + 1], zp.back(),
+                                   b.aff_pst[li].back(), g_p, dl.out_p, P, Tl, tp, dn.prev_p + dn.prev_pc, 0, total, 1);
+            }
+            // ---- pitch convs; input = (pitch stream | psix repeated) ----
+            Src pin{li == 1 ? mel : b.ppool[li - 1], dl.prev_p, b.psix[li], dl.prev_pc, 36};
+            if ((rc = stack_backward(n->p2p_t[li], n->p2p_d[li], m + "p2p.layer.", false, 0, pin, b.aff_p2pin[li], zp, b.aff_pst[li], P, Tl, g_p, g_p2,
+                                     b.g_pin[li], dl.prev_p + dl.prev_pc, "conv_wgrad_kernel/p2p", "conv_mfma_kernel/p2p_dgrad")))
+                return rc;
+            // ---- repeat (x P/36) backward, then up_sixth ----
+            {
+                const long long total = static_cast<long long>(B) * dl.prev_pc * 36 * Tl;
+                ake::ProfScope ps("repeat_sum_kernel", s);
+                hipLaunchKernelGGL(repeat_sum_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_pin[li], b.g_psix[li],
+                                   dl.prev_p + dl.prev_pc, dl.prev_p, dl.prev_pc, P, Tl, total);
+            }
+            bn_block_backward(m + "up_sixth_b", b.g_psix[li], b.psix[li], b.aff_p2pin[li] + 3 * dl.prev_p, dl.prev_pc, 0, 36 * Tl);
+            {
+                ake::ProfScope ps("up_sixth_bwd_weight_kernel", s);
+                hipLaunchKernelGGL(up_sixth_bwd_weight_kernel, dim3(dl.prev_pc * dl.prev_pc * 3, B), dim3(64), 0, s, b.g_psix[li], b.cat[li],
+                                   static_cast<long long>(ctot) * 12 * Tl, b.aff_cat[li], grad_of(m + "up_sixth.weight"),
+                                   static_cast<long long>(n->grad_floats), dl.prev_pc, Tl);
+            }
+            {
+                const long long total = static_cast<long long>(B) * dl.prev_pc * 12 * Tl;
+                ake::ProfScope ps("up_sixth_bwd_data_kernel", s);
+                hipLaunchKernelGGL(up_sixth_bwd_data_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_psix[li],
+                                   raw_of(m + "up_sixth.weight"), b.g_cat[li], ctot, dl.prev_pc, Tl, total);
+            }
+            if (li >= 2) {   // channels [0, prev_pc) of the concat buffer = the time-pooled pitch classes of the layer below (models.py:394)
+                const LayerDims& dp = n->dims[li - 1];
+                const int Tp = b.Tl[li - 1];
+                const long long total = static_cast<long long>(B) * dp.out_pc * 12 * ((Tp / tp) + (Tp % tp ? 1 : 0));
+                ake::ProfScope ps("time_pool_bwd_kernel", s);
+                hipLaunchKernelGGL(time_pool_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_cat[li], b.pcst[li - 1].back(),
+                                   b.aff_pcst[li - 1].back(), b.g_pc[li - 1], dp.out_pc, 12, Tp, tp, ctot, 0, total, 0);
+            }
         }
-        bn_block_backward("model.1.up_sixth_b", b.g_psix[1], b.psix[1], b.aff_p2pin[1] + 3 * d.prev_p, d.prev_pc, 0, 36 * Ti);
-        {
-            ake::ProfScope ps("up_sixth_bwd_weight_kernel", s);
-            hipLaunchKernelGGL(up_sixth_bwd_weight_kernel, dim3(d.prev_pc * d.prev_pc * 3, B), dim3(64), 0, s, b.g_psix[1], b.cat[1],
-                               static_cast<long long>(ctot) * 12 * Ti, b.aff_cat[1], grad_of("model.1.up_sixth.weight"),
-                               static_cast<long long>(n->grad_floats), d.prev_pc, Ti);
-        }
-        {
-            const long long total = static_cast<long long>(B) * d.prev_pc * 12 * Ti;
-            ake::ProfScope ps("up_sixth_bwd_data_kernel", s);
-            hipLaunchKernelGGL(up_sixth_bwd_data_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_psix[1],
-                               raw_of("model.1.up_sixth.weight"), b.g_cat[1], ctot, d.prev_pc, Ti, total);
-        }
+        const int ctot = n->dims[1].prev_pc + n->dims[1].out_p;
+        const int T0 = b.Tl[1];
         // ---- layer 0: its last conv's activation = channels [0, nf) of the concat buffer (two consumers, both summed into g_cat) ----
         {
             // move the slice into the dense pc0 gradient buffer, then the generic stack walk
             float* g0 = b.g_pc[0];
-            AKE_HIP_CHECK(hipMemcpy2DAsync(g0, sizeof(float) * c.n_filters * 12 * Ti, b.g_cat[1], sizeof(float) * ctot * 12 * Ti,
-                                           sizeof(float) * c.n_filters * 12 * Ti, B, hipMemcpyDeviceToDevice, s));
+            AKE_HIP_CHECK(hipMemcpy2DAsync(g0, sizeof(float) * c.n_filters * 12 * T0, b.g_cat[1], sizeof(float) * ctot * 12 * T0,
+                                           sizeof(float) * c.n_filters * 12 * T0, B, hipMemcpyDeviceToDevice, s));
             // the raw output of that conv lives inside cat[1] (strided): the stack walk needs it dense as well
-            AKE_HIP_CHECK(hipMemcpy2DAsync(b.pcst[0].back(), sizeof(float) * c.n_filters * 12 * Ti, b.cat[1], sizeof(float) * ctot * 12 * Ti,
-                                           sizeof(float) * c.n_filters * 12 * Ti, B, hipMemcpyDeviceToDevice, s));
+            AKE_HIP_CHECK(hipMemcpy2DAsync(b.pcst[0].back(), sizeof(float) * c.n_filters * 12 * T0, b.cat[1], sizeof(float) * ctot * 12 * T0,
+                                           sizeof(float) * c.n_filters * 12 * T0, B, hipMemcpyDeviceToDevice, s));
             std::vector<float*> aff0 = b.aff_pcst[0];
             aff0.back() = b.aff_cat[1];
-            float* g02 = g0 + static_cast<size_t>(B) * c.n_filters * 12 * Ti;
+            float* g02 = g0 + static_cast<size_t>(B) * c.n_filters * 12 * T0;
             if ((rc = stack_backward(n->pc2pc_t[0], n->pc2pc_d[0], "model.0.pc2pc.layer.", true, 1, Src{b.fold0, 1, nullptr, 0, 0}, nullptr, b.pcst[0],
-                                     aff0, 12, Ti, g0, g02, b.g_fold0, 1, "conv_wgrad_kernel/pc2pc0", "conv_mfma_kernel/pc2pc0_dgrad")))
+                                     aff0, 12, T0, g0, g02, b.g_fold0, 1, "conv_wgrad_kernel/pc2pc0", "conv_mfma_kernel/pc2pc0_dgrad")))
                 return rc;
         }
         return semi_backward(0, mel, nullptr, b.g_fold0, 1, 0, nullptr);
@@ -341,13 +370,13 @@ struct Bwd {
             ake::ProfScope ps("semi_bwd_weight_kernel", s);
             const size_t lds = std::max<size_t>(static_cast<size_t>(4) * (C * Tn + 3 * C * (Tn + 2)), 4 * 9 * 64) * sizeof(float);
             const size_t cap = 160 * 1024;          // one workgroup per CU beyond 64 KB (--local clips: no time pooling, more frames)
-            AKE_REQUIRE(C <= 8 && lds <= cap, AKE_ERR_UNSUPPORTED, "backward: pool_semi weight gradient handles <= 8 channels and %zu B of LDS (got %zu: too many frames)", cap, lds);
+            AKE_REQUIRE(lds <= cap, AKE_ERR_UNSUPPORTED, "backward: pool_semi weight gradient stages %zu B of LDS per workgroup (got %zu: too many channels x frames)", cap, lds);
             static ake::DeviceOnce semi_attr;
             if (lds > kLdsBudget && semi_attr.need()) {
                 AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(semi_bwd_weight_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(cap)));
                 semi_attr.mark();
             }
-            hipLaunchKernelGGL(semi_bwd_weight_kernel, dim3((P / 3 + kSemiRows - 1) / kSemiRows, B), dim3(256), lds, s, g, x, x_aff,
+            hipLaunchKernelGGL(semi_bwd_weight_kernel, dim3((P / 3 + kSemiRows - 1) / kSemiRows, B, (C * C + 63) / 64), dim3(256), lds, s, g, x, x_aff,
                                grad_of(m + "pool_semi.weight"), static_cast<long long>(n->grad_floats), C, P, Tn);
         }
         if (ga_x) {

@@ -239,9 +239,10 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 
 // ---- pooling / fold / repeat routing -------------------------------------------------------------------------------
 // MaxPool2d((1,tp)) backward: the pooled input was a = act(z) (aff may be null = already final); the gradient goes to the
-// first maximum of each window, everything else (and the floor tail) gets zero.  One thread per pooled element.
+// first maximum of each window, everything else (and the floor tail) gets zero.  One thread per pooled element.  accumulate: ga
+// already holds the gradient of the activation's other consumer (an inner layer's pitch stream also feeds pool_semi): add to it.
 __global__ void time_pool_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ z, const float* __restrict__ aff,
-                                     float* __restrict__ ga, int C, int H, int T, int tp, int gp_ctot, int gp_coff, long long total) {
+                                     float* __restrict__ ga, int C, int H, int T, int tp, int gp_ctot, int gp_coff, long long total, int accumulate) {
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int To = T / tp;
@@ -254,7 +255,7 @@ __global__ void time_pool_bwd_kernel(const float* __restrict__ gp, const float* 
     const long long clip = q / C;
     const long long zb = ((clip * C + c) * H + y) * T;
     if (t >= To) {
-        for (int j = To * tp; j < T; ++j) ga[zb + j] = 0.f;
+        for (int j = To * tp; j < T && !accumulate; ++j) ga[zb + j] = 0.f;
         return;
     }
     int best = 0;
@@ -264,6 +265,7 @@ __global__ void time_pool_bwd_kernel(const float* __restrict__ gp, const float* 
         if (v > bv) { bv = v; best = j; }
     }
     const float g = gp[((clip * gp_ctot + gp_coff + c) * H + y) * To + t];
+    if (accumulate) { ga[zb + static_cast<long long>(t) * tp + best] += g; return; }
     for (int j = 0; j < tp; ++j) ga[zb + static_cast<long long>(t) * tp + j] = j == best ? g : 0.f;
 }
 
@@ -347,7 +349,8 @@ __global__ __launch_bounds__(256) void semi_bwd_weight_kernel(const float* __res
     float* ldz = semi_lds + wave * (C * T + 3 * C * Tp);      // [co][T]
     float* lx = ldz + C * T;                                  // [ci][3][T + 2]   (index 0 <-> frame -1)
     const int pairs = C * C;
-    const int co = lane / C, ci = lane - co * C;
+    const int pair = blockIdx.z * 64 + lane;                  // wider layers (C > 8): blockIdx.z walks the (co, ci) pairs 64 at a time
+    const int co = pair / C, ci = pair - co * C;
     float acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.f;
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256) void semi_bwd_weight_kernel(const float* __res
             lx[i] = affine_act(x[((static_cast<long long>(clip) * C + c) * H + 3 * srow + r) * T + t], x_aff, c);
         }
         // a wave's LDS slice is private: no workgroup barrier, the waitcnt the compiler inserts for the reads is enough
-        if (lane < pairs) {
+        if (pair < pairs) {
             const float* dr = ldz + co * T;
             const float* xr = lx + ci * 3 * Tp;
             for (int t = 0; t < T; ++t) {
@@ -381,12 +384,12 @@ __global__ __launch_bounds__(256) void semi_bwd_weight_kernel(const float* __res
     // every wave added its own partial sums)
     __syncthreads();
     float* red = semi_lds;                                        // [4 waves][9][64]
-    if (lane < pairs) {
+    if (pair < pairs) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) red[(wave * 9 + k) * 64 + lane] = acc[k];
     }
     __syncthreads();
-    if (wave == 0 && lane < pairs) {
+    if (wave == 0 && pair < pairs) {
 #pragma unroll
         for (int k = 0; k < 9; ++k)
             grad_add(grad_slot(dW, slot_stride) + (co * C + ci) * 9 + k, (red[k * 64 + lane] + red[(9 + k) * 64 + lane]) + (red[(18 + k) * 64 + lane] + red[(27 + k) * 64 + lane]));

@@ -213,7 +213,7 @@ int ake_pcnet_forward_train_f32(const ake_pcnet* net, const float* mel_dev, int 
  * accumulate != 0 adds to grads_out_dev instead of overwriting it (accumulate_grad_batches, train_model.py:118).
  * For a --local net d_* and key_out carry the per-frame shapes of the local forward (the sliding-window max routes each frame's
  * gradient to the first maximum of its window, as nn.MaxPool2d does).
- * Built for num_layers <= 2; --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth / --denseblock: AKE_ERR_UNSUPPORTED. */
+ * Any num_layers; --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth / --denseblock: AKE_ERR_UNSUPPORTED. */
 size_t ake_pcnet_grad_floats(const ake_pcnet* net);
 int64_t ake_pcnet_grad_offset(const ake_pcnet* net, const char* name);
 int ake_pcnet_backward_f32(const ake_pcnet* net, const float* mel_dev, int batch, int frames, const int64_t* seq_length_dev,

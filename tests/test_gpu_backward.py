@@ -157,6 +157,31 @@ def test_narrow_net_gradients():
     assert rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 1e-4, rows[:5]
 
 
+@pytest.mark.parametrize("n_filters,seed", [(1, 1), (2, 1), (4, 6)])
+def test_three_layer_net_gradients(n_filters, seed):
+    """num_layers = 3 (models.py:281-308, 370-396): the backward walks layers 2 -> 1 -> 0.  Layer 1 is an INNER layer here: its pitch
+    stream has two consumers (pool_semi and, time-pooled, layer 2's pitch convolutions) and its pitch classes reach layer 2 through
+    the time pool.  n_filters = 4 makes layer 2 (24 -> 32 pitch / 48 -> 64 pitch-class channels) and the heads (64 -> 128) wider
+    than anything in the default net: the weight-gradient kernel runs in slices of 32 output channels, pool_semi's in pair groups.
+    The (weights, data) seeds are kink-free picks of tests/tools/deep_grad_scan.py (random-init nets of this size flip one LeakyReLU /
+    max-pool decision between the f32 and the f64 forward in most draws, which moves every gradient below it by 1e-3..1e-2)."""
+    opt = Namespace(conv_layers=2, n_filters=n_filters, head_layers=2, time_pool_size=2, genre=True, max_pool=False, frames=5)
+    torch.manual_seed(5 + seed)
+    net = ake_amd.PitchClassNet(288, 12, 3, 7, opt)
+    sd32 = {k: v.clone() for k, v in net.state_dict().items()}
+    x, seq, labels = make_case(2, 96, seed)
+    loss_ref, ref = reference_grads(sd32, x, seq, labels)
+    net = net.to(DEV).train()
+    out = net(x.to(DEV), seq.to(DEV))
+    loss = loss_fn(out[0], out[1], out[2], *(t.to(DEV) for t in labels))
+    assert abs(float(loss.detach()) - loss_ref) < 2e-5 * max(1.0, abs(loss_ref))
+    loss.backward()
+    rows = grad_errors(net, ref)
+    # model.0.pool_semi_b.weight: max |ref| ~1e-6 next to O(1) gradients, a cancelling sum (see grad_errors)
+    tight = [r for r in rows if r[1] != "model.0.pool_semi_b.weight"]
+    assert tight[0][0] < 3e-4 and rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
+
+
 @pytest.mark.parametrize("with_seq", [True, False])
 def test_max_pool_gradients(gold_default, with_seq):
     """--max_pool (models.py:764-797): torch.max over the frames -- for every clip without seq_length, for clip 0 only with it (the
