@@ -892,20 +892,23 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
             b->semi_raw[i] = cv.take<float>(B * cs * (P / 3) * Ti);
             b->g_semi[i] = cv.take<float>(B * cs * (P / 3) * Ti);
             b->aff_semi[i] = cv.take<float>(3 * cs);
-            for (int j = 0; j < c.conv_layers; ++j) {
-                b->pcst[i].push_back(cv.take<float>(B * pc_out * 12 * Ti));
-                b->aff_pcst[i].push_back(cv.take<float>(3 * pc_out));
+            // --resblock: [conv0, (conv1 (2C), conv2, block output) per block] (res_stack_train); gradients: g, skip copy, 2C hidden map
+            const int n_st = c.resblock ? 1 + 3 * c.conv_layers : c.conv_layers;
+            auto width = [&](int j) { return c.resblock && j % 3 == 1 ? 2 : 1; };
+            for (int j = 0; j < n_st; ++j) {
+                b->pcst[i].push_back(cv.take<float>(width(j) * B * pc_out * 12 * Ti));
+                b->aff_pcst[i].push_back(cv.take<float>(3 * width(j) * pc_out));
             }
-            b->g_pc[i] = cv.take<float>(2 * B * pc_out * 12 * Ti);
+            b->g_pc[i] = cv.take<float>((c.resblock ? 4 : 2) * B * pc_out * 12 * Ti);
             if (i >= 1) {
                 b->aff_cat[i] = cv.take<float>(3 * (d.prev_pc + d.out_p));
                 b->aff_p2pin[i] = cv.take<float>(3 * (d.prev_pc + d.prev_p));
                 b->g_cat[i] = cv.take<float>(B * (d.prev_pc + d.out_p) * 12 * Ti);
-                for (int j = 0; j < c.conv_layers; ++j) {
-                    b->pst[i].push_back(cv.take<float>(B * d.out_p * P * Ti));
-                    b->aff_pst[i].push_back(cv.take<float>(3 * d.out_p));
+                for (int j = 0; j < n_st; ++j) {
+                    b->pst[i].push_back(cv.take<float>(width(j) * B * d.out_p * P * Ti));
+                    b->aff_pst[i].push_back(cv.take<float>(3 * width(j) * d.out_p));
                 }
-                b->g_p[i] = cv.take<float>(2 * B * d.out_p * P * Ti);
+                b->g_p[i] = cv.take<float>((c.resblock ? 4 : 2) * B * d.out_p * P * Ti);
                 b->g_pin[i] = cv.take<float>(B * (d.prev_p + d.prev_pc) * P * Ti);
                 b->g_psix[i] = cv.take<float>(B * d.prev_pc * 36 * Ti);
             }
@@ -1201,12 +1204,18 @@ static void build_packs(ake_pcnet* n, bool train) {
             for (double v : b) n->blob.push_back(static_cast<float>(v));
             up[i] = u;
             }
-            if (c.resblock) {   // [conv0, (conv1, conv2) per block]; inference only: no data-gradient packs
-                p2p[i].push_back(fold_pack(n, m + "p2p.layer.0", bn(m + "p2p.layer.1", d.out_p), d.out_p, c.pc2p_mem ? d.prev_p : d.prev_pc + d.prev_p, k, k));
+            if (c.resblock) {   // [conv0, (conv1, conv2) per block]; the data-gradient packs in the same order
+                const int cin0 = c.pc2p_mem ? d.prev_p : d.prev_pc + d.prev_p;
+                p2p[i].push_back(fold_pack(n, m + "p2p.layer.0", bn(m + "p2p.layer.1", d.out_p), d.out_p, cin0, k, k));
+                if (train) n->p2p_d[i].push_back(dgrad_pack(n, m + "p2p.layer.0.weight", d.out_p, cin0, k, k));
                 for (int r = 0; r < c.conv_layers; ++r) {
                     const std::string bp = m + "p2p.layer." + std::to_string(3 + r) + ".";
                     p2p[i].push_back(fold_pack(n, bp + "conv1", bn(bp + "b1", 2 * d.out_p), 2 * d.out_p, d.out_p, k, k));
                     p2p[i].push_back(fold_pack(n, bp + "conv2", bn(bp + "b2", d.out_p), d.out_p, 2 * d.out_p, k, k));
+                    if (train) {
+                        n->p2p_d[i].push_back(dgrad_pack(n, bp + "conv1.weight", 2 * d.out_p, d.out_p, k, k));
+                        n->p2p_d[i].push_back(dgrad_pack(n, bp + "conv2.weight", d.out_p, 2 * d.out_p, k, k));
+                    }
                 }
             }
             if (c.denseblock && !train) dense_block(m + "p2p.layer.0.", d.prev_pc + d.prev_p, false, n->dense_p[i]);
@@ -1234,10 +1243,15 @@ static void build_packs(ake_pcnet* n, bool train) {
         const int pc_in = i == 0 ? 1 : d.out_p + d.prev_pc, pc_out = i == 0 ? c.n_filters : d.out_pc;
         if (c.resblock) {
             pc2pc[i].push_back(fold_pack(n, m + "pc2pc.layer.0.conv2d", bn(m + "pc2pc.layer.1", pc_out), pc_out, pc_in, 12, k));
+            if (train) n->pc2pc_d[i].push_back(dgrad_pack(n, m + "pc2pc.layer.0.conv2d.weight", pc_out, pc_in, 12, k));
             for (int r = 0; r < c.conv_layers; ++r) {
                 const std::string bp = m + "pc2pc.layer." + std::to_string(3 + r) + ".";
                 pc2pc[i].push_back(fold_pack(n, bp + "conv1.conv2d", bn(bp + "b1", 2 * pc_out), 2 * pc_out, pc_out, 12, k));
                 pc2pc[i].push_back(fold_pack(n, bp + "conv2.conv2d", bn(bp + "b2", pc_out), pc_out, 2 * pc_out, 12, k));
+                if (train) {
+                    n->pc2pc_d[i].push_back(dgrad_pack(n, bp + "conv1.conv2d.weight", 2 * pc_out, pc_out, 12, k));
+                    n->pc2pc_d[i].push_back(dgrad_pack(n, bp + "conv2.conv2d.weight", pc_out, 2 * pc_out, 12, k));
+                }
             }
         }
         if (c.denseblock && !train) dense_block(m + "pc2pc.layer.0.", pc_in, true, n->dense_pc[i]);
@@ -1674,11 +1688,11 @@ struct Fwd {
     int bn_of(const std::string& name) const { return n->bn_index.at(name); }
 
     // launch BatchNorm finalisation of layer `bn` (count values per channel) into the affine table `aff_out`
-    void finalize_bn(int bn, double count, float* aff_out) {
+    void finalize_bn(int bn, double count, float* aff_out, float slope = kSlope) {
         const auto& l = n->bns[bn];
         ake::ProfScope ps("bn_finalize_kernel", s);
         hipLaunchKernelGGL(bn_finalize_kernel, dim3((l.C + 63) / 64), dim3(64), 0, s, b.stats + 2 * l.ch_off, 2 * n->bn_channels, count,
-                           n->blob_dev + l.gamma_off, n->blob_dev + l.beta_off, aff_out, b.bstats + 3 * l.ch_off, l.C);
+                           n->blob_dev + l.gamma_off, n->blob_dev + l.beta_off, aff_out, b.bstats + 3 * l.ch_off, l.C, slope);
         // the element count rides along for the unbiased running variance (written by the host-visible copy below)
     }
     void identity(float* aff, int C) {
@@ -1741,6 +1755,45 @@ struct Fwd {
             if ((rc = conv(st[2 + 2 * r], st[2 + 2 * r], "bn", kind, Src{Hb, 2 * C, nullptr, 0, 0}, nullptr, B, H, T, true, to_final ? final_dst : X,
                            to_final ? final_ctot : C, 0, nullptr, label, X)))
                 return rc;
+        }
+        return AKE_OK;
+    }
+
+    // --resblock stack, training (batch statistics): st = the raw-weight packs [conv0, (conv1, conv2) per block], BatchNorms
+    // `prefix`1 and `prefix`{3+r}.b1 / .b2.  Every tensor the backward needs stays: z = [conv0 raw, (conv1 raw (2C), conv2 raw,
+    // block output) per block] with the pending tables in aff (b2's carries slope 1: no activation of its own; a block output's is
+    // the identity).  The last block writes channels [0, C) of final_dst (final_ctot channels) instead of z.back() when given.
+    int res_stack_train(const std::vector<PackedConv>& st, const std::string& prefix, int kind, Src first, const float* first_aff, int B, int H, int T,
+                        const std::vector<float*>& z, const std::vector<float*>& aff, float* final_dst, int final_ctot, const char* label) {
+        const int C = st[0].cout;
+        const int nb = (static_cast<int>(st.size()) - 1) / 2;
+        AKE_REQUIRE(static_cast<int>(z.size()) == 1 + 3 * nb && z.size() == aff.size(), AKE_ERR_STATE, "resblock %s: buffer bookkeeping", label);
+        int rc = conv(st[0], st[0], prefix + "1", kind, first, first_aff, B, H, T, true, z[0], C, 0, aff[0], label);
+        if (rc) return rc;
+        const float* x = z[0];
+        const float* x_aff = aff[0];
+        const double count = static_cast<double>(B) * H * T;
+        for (int r = 0; r < nb; ++r) {
+            const std::string bp = prefix + std::to_string(3 + r) + ".";
+            float* z1 = z[1 + 3 * r];
+            float* z2 = z[2 + 3 * r];
+            if ((rc = conv(st[1 + 2 * r], st[1 + 2 * r], bp + "b1", kind, Src{x, C, nullptr, 0, 0}, x_aff, B, H, T, true, z1, 2 * C, 0, aff[1 + 3 * r], label)))
+                return rc;
+            const int bn2 = bn_of(bp + "b2");
+            if ((rc = run_conv(n, st[2 + 2 * r], kind, Src{z1, 2 * C, nullptr, 0, 0}, B, H, T, true, false, z2, C, 0, s, label, aff[1 + 3 * r],
+                               b.stats + 2 * n->bns[bn2].ch_off)))
+                return rc;
+            finalize_bn(bn2, count, aff[2 + 3 * r], 1.f);
+            const bool to_final = r == nb - 1 && final_dst;
+            float* xo = to_final ? final_dst : z[3 + 3 * r];
+            {
+                const long long total = static_cast<long long>(B) * C * H * T;
+                ake::ProfScope ps("res_add_act_kernel", s);
+                hipLaunchKernelGGL(res_add_act_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, z2, aff[2 + 3 * r], x, x_aff, xo, C,
+                                   H * T, to_final ? final_ctot : C, total);
+            }
+            identity(aff[3 + 3 * r], C);
+            x = xo; x_aff = aff[3 + 3 * r];
         }
         return AKE_OK;
     }
@@ -1963,7 +2016,12 @@ struct Fwd {
         const float* src_aff = nullptr;
         int cin = 1;
         const std::string m = "model.0.pc2pc.layer.";
-        if (c.resblock) {
+        if (c.resblock && train) {   // the last block's output = channels [0, nf) of layer 1's concat buffer, final (identity table)
+            if ((rc = res_stack_train(n->pc2pc_t[0], m, 1, Src{b.fold0, 1, nullptr, 0, 0}, nullptr, B, 12, T0, b.pcst[0], b.aff_pcst[0], b.cat[1], ctot1,
+                                      "conv_mfma_kernel/pc2pc0")))
+                return rc;
+            identity(b.aff_cat[1], c.n_filters);
+        } else if (c.resblock) {
             if ((rc = res_stack(n->pc2pc[0], 1, Src{b.fold0, 1, nullptr, 0, 0}, B, 12, T0, b.pca[0], b.pcb[0], b.cat[1], ctot1, "conv_mfma_kernel/pc2pc0"))) return rc;
         }
         for (int j = 0; j < c.conv_layers && !c.resblock; ++j) {
@@ -2062,7 +2120,11 @@ struct Fwd {
             AKE_REQUIRE(!mel_fm || (bf && i == 1 && L == 2 && !c.resblock && !c.pc2p_mem && !c.stay_sixth), AKE_ERR_UNSUPPORTED,
                         "pcnet: this configuration does not take the frames-major input (ake_pcnet_accepts_frames_major)");
             bool fused_semi = false, fused_fold = false;
-            if (c.resblock) {
+            if (c.resblock && train) {
+                if ((rc = res_stack_train(n->p2p_t[i], m + "p2p.layer.", 0, sdesc, in_aff, B, P, Ti, b.pst[i], b.aff_pst[i], nullptr, 0, "conv_mfma_kernel/p2p")))
+                    return rc;
+                out = b.pst[i].back(); out_aff = b.aff_pst[i].back();
+            } else if (c.resblock) {
                 if ((rc = res_stack(n->p2p[i], 0, sdesc, B, P, Ti, b.pa[i], b.pb[i], nullptr, 0, "conv_mfma_kernel/p2p"))) return rc;
                 out = b.pa[i];
             }
@@ -2130,7 +2192,12 @@ struct Fwd {
             int cin = ctot;
             float* pdst = nullptr;
             float* pdst_aff = nullptr;
-            if (c.resblock) {
+            if (c.resblock && train) {
+                if ((rc = res_stack_train(n->pc2pc_t[i], m + "pc2pc.layer.", 1, Src{psrc, cin, nullptr, 0, 0}, psrc_aff, B, 12, Ti, b.pcst[i], b.aff_pcst[i],
+                                          nullptr, 0, "conv_mfma_kernel/pc2pc")))
+                    return rc;
+                pdst = b.pcst[i].back(); pdst_aff = b.aff_pcst[i].back();
+            } else if (c.resblock) {
                 if ((rc = res_stack(n->pc2pc[i], 1, Src{psrc, cin, nullptr, 0, 0}, B, 12, Ti, b.pca[i], b.pcb[i], nullptr, 0, "conv_mfma_kernel/pc2pc"))) return rc;
                 pdst = b.pca[i];
             }
@@ -2181,7 +2248,12 @@ struct Fwd {
         if (pc_fused) {
             if ((rc = run_pc2pc_fused(n, i, psrc, cin, B, Ti, b.pcf, head_bf ? b.feat_cl : nullptr, s))) return rc;
         } else if (pc_bf) run_nchw_to_cl16(psrc, cin, B, Ti, reinterpret_cast<unsigned short*>(b.pcb[i]), s);
-        if (c.resblock) {
+        if (c.resblock && train) {
+            if ((rc = res_stack_train(n->pc2pc_t[i], m, 1, Src{psrc, cin, nullptr, 0, 0}, psrc_aff, B, 12, Ti, b.pcst[i], b.aff_pcst[i], nullptr, 0,
+                                      L == 1 ? "conv_mfma_kernel/pc2pc0" : "conv_mfma_kernel/pc2pc")))
+                return rc;
+            pdst = b.pcst[i].back(); pdst_aff = b.aff_pcst[i].back();
+        } else if (c.resblock) {
             if ((rc = res_stack(n->pc2pc[i], 1, Src{psrc, cin, nullptr, 0, 0}, B, 12, Ti, b.pca[i], b.pcb[i], nullptr, 0,
                                 L == 1 ? "conv_mfma_kernel/pc2pc0" : "conv_mfma_kernel/pc2pc")))
                 return rc;
@@ -2422,8 +2494,8 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     AKE_REQUIRE(n && mel && key_out && d_key && d_tonic && grads_out, AKE_ERR_INVALID, "pcnet backward: null argument");
     AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
     AKE_REQUIRE(!n->cfg.genre || d_genre, AKE_ERR_INVALID, "pcnet backward: genre head enabled but d_genre is null");
-    AKE_REQUIRE(!(n->cfg.resblock || n->cfg.pc2p_mem || n->cfg.p2pc_conv || n->cfg.stay_sixth || n->cfg.denseblock), AKE_ERR_UNSUPPORTED,
-                "pcnet: training a --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth net is not built");
+    AKE_REQUIRE(!(n->cfg.pc2p_mem || n->cfg.p2pc_conv || n->cfg.stay_sixth || n->cfg.denseblock), AKE_ERR_UNSUPPORTED,
+                "pcnet: training a --pc2p_mem / --p2pc_conv / --stay_sixth / --denseblock net is not built");
     Buffers b;
     int rc = plan_buffers(n, batch, batch, frames, workspace, &b, true);
     if (rc) return rc;
@@ -2490,8 +2562,8 @@ int ake_pcnet_forward_frames_major_f32(const ake_pcnet* n, const float* mel_fm, 
 int ake_pcnet_forward_train_f32(const ake_pcnet* n, const float* mel, int batch, int frames, const int64_t* seq_length,
                                 float* key_out, float* tonic_out, float* genre_out, float* bn_stats_out, void* workspace,
                                 size_t ws_bytes, ake_stream_t stream) {
-    AKE_REQUIRE(!n || !(n->cfg.resblock || n->cfg.pc2p_mem || n->cfg.p2pc_conv || n->cfg.stay_sixth || n->cfg.denseblock), AKE_ERR_UNSUPPORTED,
-                "pcnet: training a --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth net is not built (inference only)");
+    AKE_REQUIRE(!n || !(n->cfg.pc2p_mem || n->cfg.p2pc_conv || n->cfg.stay_sixth || n->cfg.denseblock), AKE_ERR_UNSUPPORTED,
+                "pcnet: training a --pc2p_mem / --p2pc_conv / --stay_sixth / --denseblock net is not built (inference only)");
     return forward_impl(n, true, mel, batch, frames, seq_length, key_out, tonic_out, genre_out, bn_stats_out, workspace, ws_bytes, stream);
 }
 

@@ -167,6 +167,9 @@ struct Bwd {
                        int H, int Tn, float* g, float* g2, float* g_in, int g_in_ctot, const char* wname, const char* dname) {
         const int nconv = static_cast<int>(fwd_t.size());
         int rc;
+        if (n->cfg.resblock)   // the gradient buffers of a --resblock net are 4 maps wide: g | skip copy | the blocks' 2C-channel hidden map
+            return res_stack_backward(fwd_t, dpack, prefix, conv2d_suffix, kind, stack_in, stack_in_aff, z, aff, H, Tn, g, g2,
+                                      g2 + static_cast<size_t>(B) * fwd_t[0].cout * H * Tn, g_in, g_in_ctot, wname, dname);
         for (int j = nconv - 1; j >= 0; --j) {
             const PackedConv& pc = fwd_t[j];
             const std::string cname = prefix + std::to_string(3 * j) + (conv2d_suffix ? ".conv2d" : "");
@@ -182,6 +185,44 @@ struct Bwd {
             }
             if (j > 0) std::swap(g, g2);
         }
+        return AKE_OK;
+    }
+
+    // --resblock stack (models.py:181-187 / 218-224, 402-454): conv0 + BN + LReLU, then per block x <- LReLU(x + b2(conv2(LReLU(b1(conv1(x)))))).
+    // fwd_t / dpack = [conv0, (conv1, conv2) per block]; z / aff = res_stack_train's tensors [conv0 raw, (conv1 raw, conv2 raw, block
+    // output) per block].  g: ga w.r.t. the last block's output on entry; gs: skip copy; gh: the 2C-channel hidden gradient.
+    int res_stack_backward(const std::vector<PackedConv>& fwd_t, const std::vector<PackedConv>& dpack, const std::string& prefix, bool conv2d_suffix,
+                           int kind, Src stack_in, const float* stack_in_aff, const std::vector<float*>& z, const std::vector<float*>& aff, int H, int Tn,
+                           float* g, float* gs, float* gh, float* g_in, int g_in_ctot, const char* wname, const char* dname) {
+        const int nb = (static_cast<int>(fwd_t.size()) - 1) / 2;
+        const int C = fwd_t[0].cout;
+        const std::string sfx = conv2d_suffix ? ".conv2d" : "";
+        AKE_REQUIRE(static_cast<int>(z.size()) == 1 + 3 * nb && dpack.size() == fwd_t.size(), AKE_ERR_STATE, "resblock backward: buffer bookkeeping");
+        int rc;
+        for (int r = nb - 1; r >= 0; --r) {
+            const std::string bp = prefix + std::to_string(3 + r) + ".";
+            {
+                const long long total = static_cast<long long>(B) * C * H * Tn;
+                ake::ProfScope ps("res_act_bwd_kernel", s);
+                hipLaunchKernelGGL(res_act_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, g, z[3 + 3 * r], gs, total);
+            }
+            // b2 has no activation of its own: its table carries slope 1, so the generic block applies LeakyReLU' = 1
+            bn_block_backward(bp + "b2", g, z[2 + 3 * r], aff[2 + 3 * r], C, 0, H * Tn);
+            if ((rc = wgrad(fwd_t[2 + 2 * r], kind, Src{z[1 + 3 * r], 2 * C, nullptr, 0, 0}, aff[1 + 3 * r], H, Tn, true, g, C, 0,
+                            grad_of(bp + "conv2" + sfx + ".weight"), wname)))
+                return rc;
+            if ((rc = dgrad(dpack[2 + 2 * r], fwd_t[2 + 2 * r], kind, g, H, Tn, Tn, true, gh, 2 * C, 0, false, dname))) return rc;
+            bn_block_backward(bp + "b1", gh, z[1 + 3 * r], aff[1 + 3 * r], 2 * C, 0, H * Tn);
+            // the block's input: the previous block's output (final, identity table) or conv0's raw output + its BatchNorm
+            if ((rc = wgrad(fwd_t[1 + 2 * r], kind, Src{z[3 * r], C, nullptr, 0, 0}, aff[3 * r], H, Tn, true, gh, 2 * C, 0,
+                            grad_of(bp + "conv1" + sfx + ".weight"), wname)))
+                return rc;
+            if ((rc = dgrad(dpack[1 + 2 * r], fwd_t[1 + 2 * r], kind, gh, H, Tn, Tn, true, gs, C, 0, true, dname))) return rc;   // + the skip copy
+            std::swap(g, gs);
+        }
+        bn_block_backward(prefix + "1", g, z[0], aff[0], C, 0, H * Tn);
+        if ((rc = wgrad(fwd_t[0], kind, stack_in, stack_in_aff, H, Tn, true, g, C, 0, grad_of(prefix + "0" + sfx + ".weight"), wname))) return rc;
+        if (g_in && (rc = dgrad(dpack[0], fwd_t[0], kind, g, H, Tn, Tn, true, g_in, g_in_ctot, 0, false, dname))) return rc;
         return AKE_OK;
     }
 

@@ -237,6 +237,17 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     if (threadIdx.x == 0) grad_add(grad_slot(out, slot_stride) + c, r[0] + r[1] + r[2] + r[3]);
 }
 
+// ---- --resblock: the activation behind the residual add -----------------------------------------------------------------
+// x_out = LeakyReLU(s), s = b2(z2) + x_in (sign(x_out) = sign(s)): g <- g * LeakyReLU'(s) is the gradient of BOTH summands; the copy in
+// g_skip travels down the skip connection while g goes through b2 / conv2 / b1 / conv1.
+__global__ void res_act_bwd_kernel(float* __restrict__ g, const float* __restrict__ x_out, float* __restrict__ g_skip, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float v = g[i] * (x_out[i] > 0.f ? 1.f : kSlope);
+    g[i] = v;
+    g_skip[i] = v;
+}
+
 // ---- pooling / fold / repeat routing -------------------------------------------------------------------------------
 // MaxPool2d((1,tp)) backward: the pooled input was a = act(z) (aff may be null = already final); the gradient goes to the
 // first maximum of each window, everything else (and the floor tail) gets zero.  One thread per pooled element.  accumulate: ga

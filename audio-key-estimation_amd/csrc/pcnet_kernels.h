@@ -2728,7 +2728,7 @@ __global__ void time_pool_affine_kernel(const float* __restrict__ src, const flo
 // (sum, sumsq) over `count` values per channel -> BatchNorm(train) as an affine triple, plus (batch mean, biased
 // variance, count) for the running-statistics update done by the caller (momentum 0.1, unbiased variance: torch semantics).
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, int stats_stride, double count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ aff, float* __restrict__ batch_stats, int C) {
+                                   const float* __restrict__ beta, float* __restrict__ aff, float* __restrict__ batch_stats, int C, float slope) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     long long i1 = 0, i2 = 0;                                      // the slots hold fixed-point sums (fx_add): exact integer adds
@@ -2743,7 +2743,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int stats_s
     const double sc = static_cast<double>(gamma[c]) / sqrt(var + 1e-5);
     aff[3 * c] = static_cast<float>(sc);
     aff[3 * c + 1] = static_cast<float>(static_cast<double>(beta[c]) - mean * sc);
-    aff[3 * c + 2] = kSlope;
+    aff[3 * c + 2] = slope;                                        // kSlope; 1 for a BatchNorm with no activation of its own (ResBlock b2)
     batch_stats[3 * c] = static_cast<float>(mean);
     batch_stats[3 * c + 1] = static_cast<float>(var);
     batch_stats[3 * c + 2] = static_cast<float>(count);
@@ -2753,6 +2753,21 @@ __global__ void affine_identity_kernel(float* __restrict__ aff, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     aff[3 * c] = 1.f; aff[3 * c + 1] = 0.f; aff[3 * c + 2] = 1.f;
+}
+
+// --resblock, training (models.py:402-454): x_out = LeakyReLU(b2(z2) + x_in).  z2 is conv2's raw output with b2's pending (scale,
+// shift) in aff2; x_in is read through its own pending table (the stack's first conv: raw + BatchNorm + LeakyReLU; a block's output:
+// identity).  The sum is MATERIALISED (dense, or as channels [0, C) of a wider concat buffer): the next block reads it twice.
+__global__ void res_add_act_kernel(const float* __restrict__ z2, const float* __restrict__ aff2, const float* __restrict__ x,
+                                   const float* __restrict__ x_aff, float* __restrict__ dst, int C, int HT, int dst_ctot, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ht = static_cast<int>(i % HT);
+    const long long q = i / HT;
+    const int c = static_cast<int>(q % C);
+    const long long clip = q / C;
+    const float s = fmaf(z2[i], aff2[3 * c], aff2[3 * c + 1]) + affine_act(x[i], x_aff, c);
+    dst[(clip * dst_ctot + c) * HT + ht] = s > 0.f ? s : s * kSlope;
 }
 
 // masked temporal mean with a pending affine on nothing (the last head conv has no BatchNorm): reuse head_pool_kernel.

@@ -528,8 +528,8 @@ class PitchClassNet(LightningModule):
         ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream().cuda_stream
-            if self.training and (self.resblock or self.pc2p_mem or self.p2pc_conv or self.stay_sixth or self.denseblock):
-                raise NotImplementedError("training a --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth / --denseblock net is not built on the HIP path "
+            if self.training and (self.pc2p_mem or self.p2pc_conv or self.stay_sixth or self.denseblock):
+                raise NotImplementedError("training a --pc2p_mem / --p2pc_conv / --stay_sixth / --denseblock net is not built on the HIP path "
                                           "(inference only)")
             if self.training:
                 # BatchNorm with batch statistics; with autograd enabled the call becomes one autograd node whose backward

@@ -182,6 +182,31 @@ def test_three_layer_net_gradients(n_filters, seed):
     assert tight[0][0] < 3e-4 and rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
 
 
+@pytest.mark.parametrize("num_layers,n_filters,conv_layers,batch,frames,seed", [(2, 4, 2, 2, 52, 2), (1, 4, 2, 2, 52, 1), (3, 1, 1, 2, 96, 0),
+                                                                                  (2, 4, 3, 3, 40, 4)])
+def test_resblock_net_gradients(num_layers, n_filters, conv_layers, batch, frames, seed):
+    """--resblock (models.py:181-187, 218-224, 402-454): every stack is conv + BN + LReLU followed by conv_layers blocks
+    x <- LReLU(x + b2(conv2(LReLU(b1(conv1(x)))))).  The backward splits the gradient behind the activation into the skip copy and the
+    b2 -> conv2 -> b1 -> conv1 branch and adds them again in conv1's data gradient.  (2, 4, 3, ...) is the reference fixture's shape
+    (tests/golden/pcnet_resblock_T28.npz).  Seeds: kink-free picks of tests/tools/deep_grad_scan.py (RESBLOCK=1)."""
+    opt = Namespace(conv_layers=conv_layers, n_filters=n_filters, head_layers=2, time_pool_size=2, genre=True, max_pool=False, frames=5, resblock=True)
+    torch.manual_seed(5 + seed)
+    net = ake_amd.PitchClassNet(288, 12, num_layers, 7, opt)
+    assert net.resblock
+    sd32 = {k: v.clone() for k, v in net.state_dict().items()}
+    x, seq, labels = make_case(batch, frames, seed)
+    loss_ref, ref = reference_grads(sd32, x, seq, labels)
+    assert any(".b2.weight" in k for k in ref)
+    net = net.to(DEV).train()
+    out = net(x.to(DEV), seq.to(DEV))
+    loss = loss_fn(out[0], out[1], out[2], *(t.to(DEV) for t in labels))
+    assert abs(float(loss.detach()) - loss_ref) < 2e-5 * max(1.0, abs(loss_ref))
+    loss.backward()
+    rows = grad_errors(net, ref)
+    tight = [r for r in rows if r[1] != "model.0.pool_semi_b.weight"]      # (a cancelling sum at 1e-5 of the other gradients, see grad_errors)
+    assert tight[0][0] < 3e-4 and rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
+
+
 @pytest.mark.parametrize("with_seq", [True, False])
 def test_max_pool_gradients(gold_default, with_seq):
     """--max_pool (models.py:764-797): torch.max over the frames -- for every clip without seq_length, for clip 0 only with it (the

@@ -86,7 +86,8 @@ def test_equivariance_script_semantics_train_mode(gold_guard):
         assert np.abs(T[12 + s] - np.roll(T[12], -s)).max() <= 2e-5
 
 
-@pytest.mark.parametrize("cfg", [dict(num_layers=1), dict(num_layers=3), dict(head_layers=3), dict(n_filters=3)])
+@pytest.mark.parametrize("cfg", [dict(num_layers=1), dict(num_layers=3), dict(head_layers=3), dict(n_filters=3), dict(resblock=True),
+                                 dict(resblock=True, num_layers=3, n_filters=2, conv_layers=2), dict(resblock=True, num_layers=1)])
 def test_train_mode_other_configurations(cfg):
     opt = Namespace(conv_layers=3, n_filters=4, head_layers=2, time_pool_size=2, genre=True, max_pool=False, frames=5)
     num_layers = cfg.pop("num_layers", 2)

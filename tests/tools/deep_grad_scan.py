@@ -1,5 +1,5 @@
 """Scan seeds of the three-layer gradient test (tests/test_gpu_backward.py::test_three_layer_net_gradients): per-tensor error of the HIP
-backward vs float64 autograd through the oracle.  NF / SEEDS / FRAMES / BATCH from the environment; ROWS=1 prints every tensor."""
+backward vs float64 autograd through the oracle.  NF / SEEDS / FRAMES / BATCH / LAYERS / CONV_LAYERS / RESBLOCK from the environment; ROWS=1 prints every tensor."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,8 @@ import test_gpu_backward as tb
 
 nf = int(os.environ.get("NF", 4))
 for seed in range(int(os.environ.get("SEEDS", 3))):
-    opt = Namespace(conv_layers=2, n_filters=nf, head_layers=2, time_pool_size=2, genre=True, max_pool=False, frames=5)
+    opt = Namespace(conv_layers=int(os.environ.get("CONV_LAYERS", 2)), n_filters=nf, head_layers=2, time_pool_size=2, genre=True, max_pool=False, frames=5,
+                    resblock=bool(int(os.environ.get("RESBLOCK", 0))))
     torch.manual_seed(5 + seed)
     net = ake_amd.PitchClassNet(288, 12, int(os.environ.get("LAYERS", 3)), 7, opt)
     sd32 = {k: v.clone() for k, v in net.state_dict().items()}
