@@ -295,7 +295,10 @@ struct Tile {
 // waves covers up to W*MT*16 positions = R rows x J frame groups; input channels are staged in chunks that fit
 // the LDS budget.  Score = useful tile slots / issued, times the row-tile fill.
 struct MTile { int W, cin_chunk; };
-bool choose_tile(bool fullrows, int cin, int H, int KH, int T_out, int TB, int KU, int NT, int MT, Tile* t, MTile* mt_out) {
+int device_cus();
+
+// want_tiles > 1 (small batches): tilings with fewer (row, time) tiles than that lose score, so that the launch fills the chip.
+bool choose_tile(bool fullrows, int cin, int H, int KH, int T_out, int TB, int KU, int NT, int MT, Tile* t, MTile* mt_out, int want_tiles = 1) {
     const int cap = 8 * MT * 16;
     const int T4 = (T_out + TW - 1) / TW * TW;
     double best = -1;
@@ -323,7 +326,8 @@ bool choose_tile(bool fullrows, int cin, int H, int KH, int T_out, int TB, int K
             const double useful = static_cast<double>(H) * T_out / TB;
             const double issued = static_cast<double>(row_tiles) * n_tt_eff * W * MT * 16;
             const double halo = static_cast<double>(R) / R_in * TT / (TT + KU);
-            const double eff = useful / issued * (0.85 + 0.15 * halo) * (0.9 + 0.1 * W / 8.0);
+            double eff = useful / issued * (0.85 + 0.15 * halo) * (0.9 + 0.1 * W / 8.0);
+            if (want_tiles > 1) eff *= 0.3 + 0.7 * std::min(1.0, static_cast<double>((fullrows ? 1 : row_tiles) * n_tt_eff) / want_tiles);
             if (eff > best + 1e-9) {
                 best = eff;
                 bt = Tile{R, TT, Tp, fullrows ? 1 : row_tiles, n_tt_eff, W * 64, per_ch * chunk};
@@ -400,7 +404,9 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
     MTile mtile;
     static const int mt_env = std::getenv("AKE_MT") ? std::atoi(std::getenv("AKE_MT")) : 3;
     const int MT = (pc.ku == 8 && pc.nt == 1 && kind == 0) ? mt_env : 3;
-    AKE_REQUIRE(choose_tile(fullrows, pc.cin, H, pc.kh, a.T_out, pc.tb, pc.ku, pc.nt, MT, &t, &mtile), AKE_ERR_UNSUPPORTED,
+    const int cout_tiles = std::max(1, pc.ntiles / pc.nt);
+    const int want_tiles = (std::max(device_cus(), 1) + batch * cout_tiles - 1) / (batch * cout_tiles);      // 1 at the bench / training batch sizes
+    AKE_REQUIRE(choose_tile(fullrows, pc.cin, H, pc.kh, a.T_out, pc.tb, pc.ku, pc.nt, MT, &t, &mtile, want_tiles), AKE_ERR_UNSUPPORTED,
                 "conv %s: no tile fits LDS (cin=%d H=%d)", name, pc.cin, H);
     a.R = t.R; a.TT = t.TT; a.Tp = t.Tp; a.n_row_tiles = t.n_row_tiles; a.n_time_tiles = t.n_time_tiles;
     a.w = n->blob_dev + pc.f_off;

@@ -103,6 +103,13 @@ struct Bwd {
             };
             while (lds_of(R, TT) > kLdsBudget && kind == 0 && R > 1) --R;
             while (lds_of(R, TT) > kLdsBudget && TT > 4) TT -= 4;
+            // small batches (the reference trains with 8 clips per step): shorter time tiles and one workgroup per group of 8 input
+            // channels, until the launch has about one workgroup per CU
+            const int cin_all = src.c0 + src.c1;
+            const int n_cus = std::max(device_cus(), 1);
+            auto tiles_of = [&](int R_, int TT_) { return ((a.H_out + R_ - 1) / R_) * ((a.T_out + TT_ - 1) / TT_); };
+            const int c_groups = static_cast<long long>(B) * tiles_of(R, TT) < n_cus ? (cin_all + 7) / 8 : 1;
+            while (static_cast<long long>(B) * tiles_of(R, TT) * c_groups < n_cus && TT > 16) TT = std::max(16, (TT / 2 + 3) / 4 * 4);
             AKE_REQUIRE(lds_of(R, TT) <= 160 * 1024, AKE_ERR_UNSUPPORTED, "wgrad %s: tile does not fit LDS", name);
             a.R = R; a.TT = TT; a.Tp = (TT + pc.kw - 1 + 3) / 4 * 4;
             a.n_row_tiles = (a.H_out + R - 1) / R;
@@ -111,7 +118,8 @@ struct Bwd {
             // workgroups per clip: 4 at training batch sizes (fewer atomics), more for small batches so that the chip still fills
             const int wgs_per_clip = std::min(tiles, std::max(4, (512 + B - 1) / B));
             wa.rt_per_block = std::max(1, (tiles + wgs_per_clip - 1) / wgs_per_clip);
-            dim3 grid((tiles + wa.rt_per_block - 1) / wa.rt_per_block, 1, B), block(512);
+            wa.c_per_block = c_groups > 1 ? 8 : cin_all;
+            dim3 grid((tiles + wa.rt_per_block - 1) / wa.rt_per_block, c_groups, B), block(512);
             const size_t lds = lds_of(R, TT);
             // partial sums per workgroup + an ordered reduction when the scratch buffer holds them (see WgradArgs::partial)
             const long long n_w = static_cast<long long>(co_n) * (src.c0 + src.c1) * KK;
@@ -417,8 +425,12 @@ struct Bwd {
                 AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(semi_bwd_weight_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(cap)));
                 semi_attr.mark();
             }
-            hipLaunchKernelGGL(semi_bwd_weight_kernel, dim3((P / 3 + kSemiRows - 1) / kSemiRows, B, (C * C + 63) / 64), dim3(256), lds, s, g, x, x_aff,
-                               grad_of(m + "pool_semi.weight"), static_cast<long long>(n->grad_floats), C, P, Tn);
+            // rows per workgroup: kSemiRows at training batch sizes (few atomics), down to one row per wave when the batch is small
+            const int S = P / 3, pair_groups = (C * C + 63) / 64;
+            const int want = (std::max(device_cus(), 1) + B * pair_groups - 1) / (B * pair_groups);     // workgroups per clip that fill the chip
+            const int rows = std::min(kSemiRows, std::max(4, (S + want - 1) / want));
+            hipLaunchKernelGGL(semi_bwd_weight_kernel, dim3((S + rows - 1) / rows, B, pair_groups), dim3(256), lds, s, g, x, x_aff,
+                               grad_of(m + "pool_semi.weight"), static_cast<long long>(n->grad_floats), C, P, Tn, rows);
         }
         if (ga_x) {
             const long long total = static_cast<long long>(B) * C * P * Tn;

@@ -343,14 +343,14 @@ __global__ void semi_bwd_data_kernel(const float* __restrict__ dz, const float* 
 }
 
 // weight: dW[co][ci][dy][dx] += sum_{s,t} dz[co][s][t] * act(x[ci][3s+dy][(t+dx-1) mod T])
-// Workgroup = (clip, group of kSemiRows output rows), 256 threads = 4 waves; wave w takes rows w, w+4, ...: it stages the
+// Workgroup = (clip, group of rows_per_wg <= kSemiRows output rows: fewer per workgroup at small batches, so that the chip fills), 256 threads = 4 waves; wave w takes rows w, w+4, ...: it stages the
 // dz row of every output channel and the three activated input rows of every input channel in its own LDS slice (with
 // the circular time halo), then lane (co, ci) accumulates its 9 taps over the frames.  One atomic per weight and workgroup.
 constexpr int kSemiRows = 48;
 
 __global__ __launch_bounds__(256) void semi_bwd_weight_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                               const float* __restrict__ x_aff, gfx_t* __restrict__ dW, long long slot_stride, int C,
-                                                              int H, int T) {
+                                                              int H, int T, int rows_per_wg) {
     extern __shared__ float semi_lds[];
     const int clip = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -365,8 +365,8 @@ __global__ __launch_bounds__(256) void semi_bwd_weight_kernel(const float* __res
     float acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.f;
-    const int s_end = min(S, static_cast<int>(blockIdx.x + 1) * kSemiRows);
-    for (int srow = blockIdx.x * kSemiRows + wave; srow < s_end; srow += 4) {
+    const int s_end = min(S, static_cast<int>(blockIdx.x + 1) * rows_per_wg);
+    for (int srow = blockIdx.x * rows_per_wg + wave; srow < s_end; srow += 4) {
         for (int i = lane; i < C * T; i += 64) {
             const int c = i / T, t = i - c * T;
             ldz[i] = dz[((static_cast<long long>(clip) * C + c) * S + srow) * T + t];
@@ -458,6 +458,7 @@ struct WgradArgs {
     long long slot_stride;    // floats between gradient slots
     int KH, KW;
     int rt_per_block;         // row tiles per workgroup
+    int c_per_block;          // input channels per workgroup (cin: gridDim.y == 1; waves per workgroup: blockIdx.y walks the channel groups)
     int dbg_noflush;          // timing experiments only (AKE_WGRAD_NOFLUSH): skip the atomics
     // nullable: every workgroup stores its partial dW as plain floats at partial[(blockIdx.z * gridDim.x + blockIdx.x) * partial_stride + ...]
     // and wgrad_partial_reduce_kernel adds them up in workgroup order (deterministic; one atomic per weight instead of one per weight
@@ -526,8 +527,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs wa) {
     }
     const int tile0 = blockIdx.x * wa.rt_per_block;
 
-    for (int c_lo = 0; c_lo < cin; c_lo += nw) {
-        const int cc = cin - c_lo < nw ? cin - c_lo : nw;
+    // small batches: blockIdx.y walks the groups of nw input channels (c_per_block = nw), otherwise one workgroup loops over all of them
+    const int c_begin = blockIdx.y * wa.c_per_block;
+    const int c_end = c_begin + wa.c_per_block < cin ? c_begin + wa.c_per_block : cin;
+    for (int c_lo = c_begin; c_lo < c_end; c_lo += nw) {
+        const int cc = c_end - c_lo < nw ? c_end - c_lo : nw;
         f32x4 acc[MTC][NTK];
 #pragma unroll
         for (int m = 0; m < MTC; ++m)

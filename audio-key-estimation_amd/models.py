@@ -321,7 +321,9 @@ class PitchClassNet(LightningModule):
         self._flat = None            # one float32 device buffer holding every float state_dict entry (layout: ake_pcnet_grad_offset)
         self._flat_grad = None       # same layout; every p.grad is a view of it
         self._attached = False       # parameters/buffers are views of _flat
-        self._dirty = 0              # bumped by the raw-pointer writers (fused Adam, running statistics)
+        self._dirty = 0              # bumped by the raw-pointer writers of the weights (fused Adam)
+        self._stats_dirty = 0        # ... of the running statistics: only the eval-mode packs fold them, so a training forward need not repack
+        self._h_stats_stamp = 0
 
     # ------------------------------------------------------------------ device handle
     def _float_state(self):
@@ -402,7 +404,8 @@ class PitchClassNet(LightningModule):
             elif not self._attached:
                 pass
             stamp = (self._dirty,) + tuple((v._version, v.data_ptr()) for v in state)
-            if stamp == self._h_stamp:
+            # (the reference trains with 8 clips per step: repacking after every step's running-statistics update cost 0.35 ms of 3.7)
+            if stamp == self._h_stamp and (self.training or self._stats_dirty == self._h_stats_stamp):
                 return
             if not self._attached and self._h_stamp is not None:      # staged copy of foreign-dtype parameters
                 with torch.no_grad():
@@ -411,6 +414,7 @@ class PitchClassNet(LightningModule):
             _lib.check(L.ake_pcnet_load_from_device_f32(self._h, self._flat.data_ptr(), torch.cuda.current_stream().cuda_stream),
                        "ake_pcnet_load_from_device_f32")
             self._h_stamp = stamp
+            self._h_stats_stamp = self._stats_dirty
 
     def _grads_in_place(self):
         """True when every p.grad is (or can be made) a view of the flat gradient buffer; prepares it for accumulation."""
@@ -600,7 +604,7 @@ class PitchClassNet(LightningModule):
                 _lib.check(L.ake_pcnet_update_running_stats_f32(self._h, stats.data_ptr(), self._flat.data_ptr(), 0.1,
                                                                 torch.cuda.current_stream().cuda_stream), "ake_pcnet_update_running_stats_f32")
         if self._attached:
-            self._dirty += 1                                   # eval-mode packs fold the running statistics
+            self._stats_dirty += 1                             # eval-mode packs fold the running statistics: repacked at the next eval forward
             with torch.no_grad():
                 torch._foreach_add_(self._nbt_tensors(), 1)
         else:

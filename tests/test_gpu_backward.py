@@ -109,7 +109,7 @@ def test_default_net_gradients_tight(gold_default, batch, frames, seed):
     assert not bad, bad[:6]
 
 
-@pytest.mark.parametrize("batch,frames,seed", [(4, 52, 4), (2, 76, 3)])
+@pytest.mark.parametrize("batch,frames,seed", [(4, 40, 3), (2, 76, 5)])
 def test_default_net_gradients_kinked(gold_default, batch, frames, seed):
     rows = _run_default(gold_default, batch, frames, seed)
     assert rows[0][0] < 5e-2, rows[:5]
@@ -316,7 +316,7 @@ def _local_loss(key, tonic, genre, key_labels, tonic_idx, genre_idx, ns):
 
 # flip-free (shape, seed) pairs picked with tests/tools/local_grad_scan.py (no time pooling: twice the pre-activations of the default
 # net per frame, so kink flips are more frequent); (1, 300) is past the 64 KB LDS form of the semitone weight-gradient kernel
-@pytest.mark.parametrize("batch,frames,seed", [(3, 120, 5), (2, 150, 3), (1, 300, 0)])
+@pytest.mark.parametrize("batch,frames,seed", [(3, 120, 5), (2, 150, 3), (1, 300, 5)])
 def test_local_net_gradients(gold_default, batch, frames, seed):
     """--local training: train-mode forward with per-frame outputs, backward through the sliding-window max
     (gradient to the first maximum of each window, as nn.MaxPool2d), against float64 autograd through the oracle's --local forward

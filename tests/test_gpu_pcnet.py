@@ -309,8 +309,11 @@ def test_resblock_against_reference_fixture(gold_resblock):
     ref = pcnet_oracle.pcnet_forward(golden_state_dict(gold_resblock, torch.float64), x2.double(), seq2)
     for a, b in zip(net(x2.to(DEV), seq2.to(DEV)), ref):
         assert rel_err(a.cpu(), b) < TOL
-    with pytest.raises(NotImplementedError):
-        net.train()(x, seq)
+    # train mode (batch statistics; gradients: tests/test_gpu_backward.py::test_resblock_net_gradients)
+    ref_t = pcnet_oracle.pcnet_forward(golden_state_dict(gold_resblock, torch.float64), x2.double(), seq2, training=True)
+    with torch.no_grad():
+        for a, b in zip(net.train()(x2.to(DEV), seq2.to(DEV)), ref_t):
+            assert rel_err(a.cpu(), b) < TOL
     with pytest.raises(ake_amd._lib.AkeError, match="not tapped"):
         net.eval()(x, seq); net.tap("model.1.p2p.layer.5")
 

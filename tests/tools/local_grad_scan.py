@@ -12,7 +12,8 @@ from test_gpu_backward import _local_loss, grad_errors
 
 gold = np.load(os.path.join(ROOT, "tests/golden/pcnet_default.npz"), allow_pickle=False)
 DEV = "cuda:0"
-CASES = [(3, 120, sd_) for sd_ in range(8)] + [(2, 150, sd_) for sd_ in range(6)] + [(1, 300, 0), (2, 90, 1)]
+CASES = ([tuple(int(v) for v in c.split("x")) for c in os.environ["CASES"].split(",")] if os.environ.get("CASES") else
+         [(3, 120, sd_) for sd_ in range(8)] + [(2, 150, sd_) for sd_ in range(6)] + [(1, 300, 0), (2, 90, 1)])
 for batch, frames, seed in CASES:
     opt = Namespace(**json.loads(str(gold["opt"])))
     opt.local = True
