@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
 mkdir -p build
 HEADERS="common.h cqt_fused.h pcnet_kernels.h pcnet_bwd_kernels.h pcnet_backward.h ../../include/ake_hip.h"
 pids=()
-for f in common.cpp cqt.hip pcnet.hip pipeline.hip optim.hip audio.hip; do
+for f in common.cpp cqt.hip pcnet.hip pipeline.hip optim.hip audio.hip loss.hip; do
   obj=build/${f%.*}.o
   stale=0
   [ -f "$obj" ] || stale=1
@@ -23,5 +23,5 @@ for f in common.cpp cqt.hip pcnet.hip pipeline.hip optim.hip audio.hip; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC build/common.o build/cqt.o build/pcnet.o build/pipeline.o build/optim.o build/audio.o -o $OUT
+$HIPCC --offload-arch=gfx950 -shared -fPIC build/common.o build/cqt.o build/pcnet.o build/pipeline.o build/optim.o build/audio.o build/loss.o -o $OUT
 echo "built $(realpath $OUT)"

@@ -13,6 +13,7 @@ a CPU tensor, it raises -- there is no fallback path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 import torch.nn.functional as F
@@ -241,6 +242,53 @@ class _TrainStep(torch.autograd.Function):
             off = net._grad_offsets()[name]
             grads.append(flat[off:off + shape.numel()].view(shape).to(dtype))
         return (None, None, None) + tuple(grads)
+
+
+class _FusedGeneralStep(torch.autograd.Function):
+    """general_step's loss, its gradient w.r.t. the network outputs and the nine metrics in ONE launch (ake_general_step_f32) instead of
+    ~110 torch kernels forward and ~50 in autograd's backward (models.py:826-905, 1065-1116).  Returns a float32 tensor of 10 scalars in
+    general_step's order; only element 0 (the loss) carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, key_out, tonic_out, genre_out, key_labels, tonic_labels, genre_labels, key_signature_id, weights, use_cos):
+        dev = key_out.device
+        B = key_out.shape[0]
+
+        def onehot(t):
+            t = t.to(dev)
+            if t.dtype not in (torch.float32, torch.int64):
+                t = t.long() if not t.is_floating_point() else t.float()
+            return t.contiguous(), int(t.dtype == torch.int64)
+
+        key, tonic = key_out.detach().contiguous(), tonic_out.detach().contiguous()
+        genre = genre_out.detach().contiguous() if genre_out is not None else None
+        kl = key_labels.to(device=dev, dtype=torch.float32).contiguous()
+        tl, tl64 = onehot(tonic_labels)
+        sl, sl64 = onehot(key_signature_id)
+        gl, gl64 = onehot(genre_labels) if genre is not None else (None, 0)
+        need_grad = any(ctx.needs_input_grad[:3])
+        scal = torch.empty(10, dtype=torch.float32, device=dev)
+        grads = torch.empty((B, 35), dtype=torch.float32, device=dev) if need_grad else None
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().ake_general_step_f32(
+                key.data_ptr(), tonic.data_ptr(), ptr(genre), kl.data_ptr(), tl.data_ptr(), tl64, ptr(gl), gl64, sl.data_ptr(), sl64, B,
+                weights[0], weights[1], weights[2], int(bool(use_cos)), scal.data_ptr(),
+                grads.data_ptr() if need_grad else None, grads.data_ptr() + 4 * B * 12 if need_grad else None,
+                grads.data_ptr() + 4 * B * 24 if need_grad and genre is not None else None, torch.cuda.current_stream().cuda_stream),
+                "ake_general_step_f32")
+        ctx.grads, ctx.B, ctx.has_genre = grads, B, genre is not None
+        return scal
+
+    @staticmethod
+    def backward(ctx, g):
+        flat = ctx.grads.view(-1)
+        B = ctx.B
+        g0 = g[0]
+        d_key = flat[:B * 12].view(B, 12) * g0
+        d_tonic = flat[B * 12:B * 24].view(B, 12) * g0
+        d_genre = flat[B * 24:B * 35].view(B, 11) * g0 if ctx.has_genre else None
+        return d_key, d_tonic, d_genre, None, None, None, None, None, None
 
 
 def _opt_get(opt, name, default):
@@ -746,6 +794,16 @@ class PitchClassNet(LightningModule):
             return self._general_step_local(batch)
         mel = batch["mel"]
         key_signature_id = batch["key_signature_id"]
+        out = self.forward(mel, batch["seq_length"] if _opt_get(opt, "frames", 5) > 0 else None)
+        key_out, tonic_out = out[0], out[1]
+        dev = key_out.device
+        if (key_out.is_cuda and key_out.dtype == torch.float32 and type(self).mirex_score is PitchClassNet.mirex_score
+                and os.environ.get("AKE_FUSED_LOSS", "1") != "0"):
+            # the device path: one launch for the loss, its gradient and the metrics (a subclass that overrides mirex_score keeps the torch ops)
+            weights = (float(_opt_get(opt, "key_weight", 1.0)), float(_opt_get(opt, "tonic_weight", 1.0)), float(_opt_get(opt, "genre_weight", 0.1)))
+            vals = _FusedGeneralStep.apply(key_out, tonic_out, out[2] if self.genre else None, batch["key_labels"], batch["tonic_labels"],
+                                           batch["genre"] if self.genre else None, key_signature_id, weights, _opt_get(opt, "use_cos", False))
+            return tuple(vals.unbind(0))
         key_labels = batch["key_labels"].to(mel.dtype if mel.is_floating_point() else torch.float32)
         tonic_labels = batch["tonic_labels"].long()
         tonic_idx = torch.argmax(tonic_labels, dim=1)
@@ -753,9 +811,6 @@ class PitchClassNet(LightningModule):
             genre_labels = batch["genre"].long()
             genre_idx = torch.argmax(genre_labels, dim=1)
             genre_mask = genre_labels.sum(dim=1) == 1                                        # models.py:839
-        out = self.forward(mel, batch["seq_length"] if _opt_get(opt, "frames", 5) > 0 else None)
-        key_out, tonic_out = out[0], out[1]
-        dev = key_out.device
         key_labels, tonic_idx = key_labels.to(dev), tonic_idx.to(dev)
         loss = _opt_get(opt, "key_weight", 1.0) * F.binary_cross_entropy(key_out, key_labels.to(key_out.dtype)) \
             + _opt_get(opt, "tonic_weight", 1.0) * F.cross_entropy(tonic_out, tonic_idx)      # models.py:878-889

@@ -231,6 +231,12 @@ def train_main(args):
         optim.grad_scale = D.all_reduce_gradients(net)
         optim.step()
 
+    # device / host spin-up as in the inference line (--spinup-seconds; untimed, not part of W): the first ~50 steps of a fresh process run
+    # 20-60 % slower than the steady state (measured: 20 timed steps after 5 warm-up steps 11.0-15.1 ms, 150 after 30: 9.12 +- 0.01 ms)
+    # (a step holds a collective: every rank runs the same NUMBER of spin-up steps, 100 per 0.5 s asked for)
+    n_spin = int(round(200 * args.spinup_seconds))
+    for i in range(n_spin):
+        step(i)
     for i in range(max(args.warmup, 1)):
         step(i)
     D.barrier()
@@ -259,7 +265,7 @@ def train_main(args):
                  "dropped), their weight gradient as split bf16 x 3, everything else f32 MFMA", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[3]: {B} clips per GPU (288x76 log-CQT resident), default PitchClassNet, local BatchNorm, "
                                f"one all-reduce of the flat gradient buffer per step, fused Adam lr 3e-4",
-                   "clips_per_gpu": B, "parallelism": f"data-parallel x{world}"},
+                   "clips_per_gpu": B, "parallelism": f"data-parallel x{world}", "spinup_steps": n_spin},
         "train_fp32_frac_of_peak": round(3 * 2.0 * NET_MACS_PER_CLIP * value / world / (PEAK_FP32_TFLOPS * 1e12), 4),
         "kernel_ms_per_step": kernel_ms}))
 

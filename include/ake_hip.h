@@ -230,6 +230,19 @@ int ake_adam_step_f32(float* params_dev, const float* grads_dev, float* exp_avg_
                       const unsigned char* trainable_dev, size_t count, float lr, float beta1, float beta2, float eps,
                       float weight_decay, int step, float grad_scale, ake_stream_t stream);
 
+/* Everything PitchClassNet.general_step computes behind the forward, in one launch (replaces models.py:826-905: label argmax / genre
+ * mask, key_weight * BCE(key) + tonic_weight * CE(tonic) + genre_weight * CE(genre rows whose one-hot label sums to 1; dropped when there
+ * is none) [+ 1 - mean cosine(key, key_labels) with use_cos], and models.py:1065-1116: the MIREX categories over the 21-row key-signature
+ * table, utils/key_signatures.py:19-42).  One-hot label tensors are float32 or int64 (the *_i64 flags); genre_* nullable (--genre off).
+ * scalars_out_dev[10] = loss, accuracy, mirex_score, correct, fifths, relative, parallel, other, accuracy_tonic, accuracy_genre
+ * (general_step's return order).  d_*_dev (all or none): dloss/d(key_out | tonic_out | genre_out), what loss.backward() hands to
+ * ake_pcnet_backward_f32. */
+int ake_general_step_f32(const float* key_out_dev, const float* tonic_out_dev, const float* genre_out_dev, const float* key_labels_dev,
+                         const void* tonic_labels_dev, int tonic_labels_i64, const void* genre_labels_dev, int genre_labels_i64,
+                         const void* key_signature_id_dev, int key_signature_i64, int batch, float key_weight, float tonic_weight,
+                         float genre_weight, int use_cos, float* scalars_out_dev, float* d_key_dev, float* d_tonic_dev, float* d_genre_dev,
+                         ake_stream_t stream);
+
 /* Debug tap: copy an intermediate activation of the LAST forward call out of the workspace.
  * name is the reference module path whose output it is (e.g. "model.1.p2p.layer.8"). */
 int ake_pcnet_tap_info(const ake_pcnet* net, const char* name, int batch, int frames, int64_t shape[4]);

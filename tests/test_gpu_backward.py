@@ -376,7 +376,7 @@ def test_local_training_step_runs_and_learns(gold_default):
         d = net.training_step(batch, 0)
         d["loss"].backward()
         optim.step()
-        losses.append(float(d["loss"]))
+        losses.append(float(d["loss"].detach()))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.05, losses
     with pytest.raises(NotImplementedError, match="--local and --genre"):
         opt2 = Namespace(**json.loads(str(gold_default["opt"])))
