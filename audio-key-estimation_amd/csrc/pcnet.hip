@@ -2113,8 +2113,9 @@ struct Fwd {
             if (c.pc2p_mem) {   // models.py:376-377: no concat, the summed up_sixth map is added to the pitch stream
                 const long long total = static_cast<long long>(B) * cp * P * Ti;
                 ake::ProfScope ps("pc2p_mem_kernel", s);
+                // (training: psix is raw, its up_sixth_b table sits behind the pitch stream's identity rows; the sum itself is final)
                 hipLaunchKernelGGL(pc2p_mem_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, p_cur, psix, b.pin[i], cp,
-                                   d.prev_pc / cp, P, Ti, total);
+                                   d.prev_pc / cp, P, Ti, total, train ? b.aff_p2pin[i] + 3 * d.prev_p : nullptr);
                 sdesc = Src{b.pin[i], cp, nullptr, 0, 0};
             }
             const float* in_aff = train ? b.aff_p2pin[i] : nullptr;
@@ -2500,8 +2501,8 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     AKE_REQUIRE(n && mel && key_out && d_key && d_tonic && grads_out, AKE_ERR_INVALID, "pcnet backward: null argument");
     AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
     AKE_REQUIRE(!n->cfg.genre || d_genre, AKE_ERR_INVALID, "pcnet backward: genre head enabled but d_genre is null");
-    AKE_REQUIRE(!(n->cfg.pc2p_mem || n->cfg.p2pc_conv || n->cfg.stay_sixth || n->cfg.denseblock), AKE_ERR_UNSUPPORTED,
-                "pcnet: training a --pc2p_mem / --p2pc_conv / --stay_sixth / --denseblock net is not built");
+    AKE_REQUIRE(!(n->cfg.p2pc_conv || n->cfg.stay_sixth || n->cfg.denseblock), AKE_ERR_UNSUPPORTED,
+                "pcnet: training a --p2pc_conv / --stay_sixth / --denseblock net is not built");
     Buffers b;
     int rc = plan_buffers(n, batch, batch, frames, workspace, &b, true);
     if (rc) return rc;
@@ -2568,8 +2569,8 @@ int ake_pcnet_forward_frames_major_f32(const ake_pcnet* n, const float* mel_fm, 
 int ake_pcnet_forward_train_f32(const ake_pcnet* n, const float* mel, int batch, int frames, const int64_t* seq_length,
                                 float* key_out, float* tonic_out, float* genre_out, float* bn_stats_out, void* workspace,
                                 size_t ws_bytes, ake_stream_t stream) {
-    AKE_REQUIRE(!n || !(n->cfg.pc2p_mem || n->cfg.p2pc_conv || n->cfg.stay_sixth || n->cfg.denseblock), AKE_ERR_UNSUPPORTED,
-                "pcnet: training a --pc2p_mem / --p2pc_conv / --stay_sixth / --denseblock net is not built (inference only)");
+    AKE_REQUIRE(!n || !(n->cfg.p2pc_conv || n->cfg.stay_sixth || n->cfg.denseblock), AKE_ERR_UNSUPPORTED,
+                "pcnet: training a --p2pc_conv / --stay_sixth / --denseblock net is not built (inference only)");
     return forward_impl(n, true, mel, batch, frames, seq_length, key_out, tonic_out, genre_out, bn_stats_out, workspace, ws_bytes, stream);
 }
 

@@ -344,15 +344,22 @@ struct Bwd {
                 const long long total = static_cast<long long>(B) * dl.out_p * P * ((Tl / tp) + (Tl % tp ? 1 : 0));
                 ake::ProfScope ps("time_pool_bwd_kernel", s);
                 hipLaunchKernelGGL(time_pool_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_pin[li + 1], zp.back(),
-                                   b.aff_pst[li].back(), g_p, dl.out_p, P, Tl, tp, dn.prev_p + dn.prev_pc, 0, total, 1);
+                                   b.aff_pst[li].back(), g_p, dl.out_p, P, Tl, tp, c.pc2p_mem ? dn.prev_p : dn.prev_p + dn.prev_pc, 0, total, 1);
             }
             // ---- pitch convs; input = (pitch stream | psix repeated) ----
-            Src pin{li == 1 ? mel : b.ppool[li - 1], dl.prev_p, b.psix[li], dl.prev_pc, 36};
+            // (--pc2p_mem, models.py:145-166: the stack read the pitch stream + the summed up_sixth map, kept in b.pin by the forward)
+            Src pin = c.pc2p_mem ? Src{b.pin[li], dl.prev_p, nullptr, 0, 0} : Src{li == 1 ? mel : b.ppool[li - 1], dl.prev_p, b.psix[li], dl.prev_pc, 36};
+            const int pin_ch = c.pc2p_mem ? dl.prev_p : dl.prev_p + dl.prev_pc;
             if ((rc = stack_backward(n->p2p_t[li], n->p2p_d[li], m + "p2p.layer.", false, 0, pin, b.aff_p2pin[li], zp, b.aff_pst[li], P, Tl, g_p, g_p2,
-                                     b.g_pin[li], dl.prev_p + dl.prev_pc, "conv_wgrad_kernel/p2p", "conv_mfma_kernel/p2p_dgrad")))
+                                     b.g_pin[li], pin_ch, "conv_wgrad_kernel/p2p", "conv_mfma_kernel/p2p_dgrad")))
                 return rc;
             // ---- repeat (x P/36) backward, then up_sixth ----
-            {
+            if (c.pc2p_mem) {
+                const long long total = static_cast<long long>(B) * dl.prev_pc * 36 * Tl;
+                ake::ProfScope ps("pc2p_mem_bwd_kernel", s);
+                hipLaunchKernelGGL(pc2p_mem_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_pin[li], b.g_psix[li],
+                                   dl.prev_p, dl.prev_pc / dl.prev_p, P, Tl, total);
+            } else {
                 const long long total = static_cast<long long>(B) * dl.prev_pc * 36 * Tl;
                 ake::ProfScope ps("repeat_sum_kernel", s);
                 hipLaunchKernelGGL(repeat_sum_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_pin[li], b.g_psix[li],

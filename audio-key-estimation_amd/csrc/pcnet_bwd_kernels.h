@@ -237,6 +237,24 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     if (threadIdx.x == 0) grad_add(grad_slot(out, slot_stride) + c, r[0] + r[1] + r[2] + r[3]);
 }
 
+// ---- --pc2p_mem (models.py:145-166) backward: the pitch stream's gradient passes through unchanged; every channel of the activated
+// up_sixth map that was summed into pitch channel c = cpc / ratio collects the rows r with r / (P / 36) == k of that channel's gradient.
+__global__ void pc2p_mem_bwd_kernel(const float* __restrict__ g_pin, float* __restrict__ g_psix, int cp, int ratio, int P, int T, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;      // (clip, cpc, k, t)
+    if (i >= total) return;
+    const int t = static_cast<int>(i % T);
+    long long q = i / T;
+    const int k = static_cast<int>(q % 36);
+    q /= 36;
+    const int cpc = static_cast<int>(q % (cp * ratio));
+    const long long clip = q / (cp * ratio);
+    const int n = P / 36;
+    const float* s = g_pin + ((clip * cp + cpc / ratio) * P + static_cast<long long>(k) * n) * T + t;
+    float acc = 0.f;
+    for (int j = 0; j < n; ++j) acc += s[static_cast<long long>(j) * T];
+    g_psix[i] = acc;
+}
+
 // ---- --resblock: the activation behind the residual add -----------------------------------------------------------------
 // x_out = LeakyReLU(s), s = b2(z2) + x_in (sign(x_out) = sign(s)): g <- g * LeakyReLU'(s) is the gradient of BOTH summands; the copy in
 // g_skip travels down the skip connection while g goes through b2 / conv2 / b1 / conv1.

@@ -2520,8 +2520,9 @@ __global__ __launch_bounds__(512) void layer0_mfma_kernel(Layer0Args a) {
 // --pc2p_mem (PitchClass2Pitch_MemoryVariant, models.py:145-166): the up_sixth map is summed over groups of its channels and ADDED to
 // the pitch stream instead of being concatenated to it.  The reference reshapes the P rows to (36, P / 36): row r takes
 // third-semitone index r / (P / 36) -- eight consecutive rows share one -- kept as it is.
+// psix_aff (training, nullable): psix is up_sixth's RAW output, its BatchNorm + LeakyReLU is applied while loading.
 __global__ void pc2p_mem_kernel(const float* __restrict__ p, const float* __restrict__ psix, float* __restrict__ out, int cp, int ratio, int P, int T,
-                                long long total) {
+                                long long total, const float* __restrict__ psix_aff) {
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;      // (clip, c, row, t)
     if (i >= total) return;
     const int t = static_cast<int>(i % T);
@@ -2533,7 +2534,15 @@ __global__ void pc2p_mem_kernel(const float* __restrict__ p, const float* __rest
     const int k = r / (P / 36);
     const float* s = psix + (((clip * cp + c) * ratio) * 36 + k) * T + t;
     float acc = p[i];
-    for (int g = 0; g < ratio; ++g) acc += s[static_cast<long long>(g) * 36 * T];
+    for (int g = 0; g < ratio; ++g) {
+        float v = s[static_cast<long long>(g) * 36 * T];
+        if (psix_aff) {
+            const float* a3 = psix_aff + 3 * (c * ratio + g);
+            const float y = fmaf(v, a3[0], a3[1]);
+            v = y > 0.f ? y : y * a3[2];
+        }
+        acc += v;
+    }
     out[i] = acc;
 }
 

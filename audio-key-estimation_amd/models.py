@@ -260,8 +260,9 @@ class _FusedGeneralStep(torch.autograd.Function):
                 t = t.long() if not t.is_floating_point() else t.float()
             return t.contiguous(), int(t.dtype == torch.int64)
 
-        key, tonic = key_out.detach().contiguous(), tonic_out.detach().contiguous()
-        genre = genre_out.detach().contiguous() if genre_out is not None else None
+        # (float64 outputs -- the reference's dtype, train_model.py:106 -- are the kernels' float32 values cast up: the cast back is exact)
+        key, tonic = key_out.detach().float().contiguous(), tonic_out.detach().float().contiguous()
+        genre = genre_out.detach().float().contiguous() if genre_out is not None else None
         kl = key_labels.to(device=dev, dtype=torch.float32).contiguous()
         tl, tl64 = onehot(tonic_labels)
         sl, sl64 = onehot(key_signature_id)
@@ -277,17 +278,17 @@ class _FusedGeneralStep(torch.autograd.Function):
                 grads.data_ptr() if need_grad else None, grads.data_ptr() + 4 * B * 12 if need_grad else None,
                 grads.data_ptr() + 4 * B * 24 if need_grad and genre is not None else None, torch.cuda.current_stream().cuda_stream),
                 "ake_general_step_f32")
-        ctx.grads, ctx.B, ctx.has_genre = grads, B, genre is not None
+        ctx.grads, ctx.B, ctx.has_genre, ctx.out_dtype = grads, B, genre is not None, key_out.dtype
         return scal
 
     @staticmethod
     def backward(ctx, g):
-        flat = ctx.grads.view(-1)
         B = ctx.B
         g0 = g[0]
-        d_key = flat[:B * 12].view(B, 12) * g0
-        d_tonic = flat[B * 12:B * 24].view(B, 12) * g0
-        d_genre = flat[B * 24:B * 35].view(B, 11) * g0 if ctx.has_genre else None
+        scaled = (ctx.grads * g0).to(ctx.out_dtype).view(-1)             # one multiply (+ one cast) for the three gradients
+        d_key = scaled[:B * 12].view(B, 12)
+        d_tonic = scaled[B * 12:B * 24].view(B, 12)
+        d_genre = scaled[B * 24:B * 35].view(B, 11) if ctx.has_genre else None
         return d_key, d_tonic, d_genre, None, None, None, None, None, None
 
 
@@ -580,8 +581,8 @@ class PitchClassNet(LightningModule):
         ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream().cuda_stream
-            if self.training and (self.pc2p_mem or self.p2pc_conv or self.stay_sixth or self.denseblock):
-                raise NotImplementedError("training a --pc2p_mem / --p2pc_conv / --stay_sixth / --denseblock net is not built on the HIP path "
+            if self.training and (self.p2pc_conv or self.stay_sixth or self.denseblock):
+                raise NotImplementedError("training a --p2pc_conv / --stay_sixth / --denseblock net is not built on the HIP path "
                                           "(inference only)")
             if self.training:
                 # BatchNorm with batch statistics; with autograd enabled the call becomes one autograd node whose backward
@@ -797,7 +798,7 @@ class PitchClassNet(LightningModule):
         out = self.forward(mel, batch["seq_length"] if _opt_get(opt, "frames", 5) > 0 else None)
         key_out, tonic_out = out[0], out[1]
         dev = key_out.device
-        if (key_out.is_cuda and key_out.dtype == torch.float32 and type(self).mirex_score is PitchClassNet.mirex_score
+        if (key_out.is_cuda and key_out.dtype in (torch.float32, torch.float64) and type(self).mirex_score is PitchClassNet.mirex_score
                 and os.environ.get("AKE_FUSED_LOSS", "1") != "0"):
             # the device path: one launch for the loss, its gradient and the metrics (a subclass that overrides mirex_score keeps the torch ops)
             weights = (float(_opt_get(opt, "key_weight", 1.0)), float(_opt_get(opt, "tonic_weight", 1.0)), float(_opt_get(opt, "genre_weight", 0.1)))

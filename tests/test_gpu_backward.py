@@ -207,6 +207,29 @@ def test_resblock_net_gradients(num_layers, n_filters, conv_layers, batch, frame
     assert tight[0][0] < 3e-4 and rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
 
 
+@pytest.mark.parametrize("num_layers,n_filters,conv_layers,frames,seed", [(2, 4, 3, 52, 1), (3, 2, 2, 96, 0)])
+def test_pc2p_mem_net_gradients(num_layers, n_filters, conv_layers, frames, seed):
+    """--pc2p_mem (PitchClass2Pitch_MemoryVariant, models.py:145-166, 376-377): the activated up_sixth map, summed over its channel groups,
+    is ADDED to the pitch stream (row r takes third-semitone index r // (P / 36), the reference's reshape) instead of being concatenated.
+    Backward: the stack's input gradient goes to the pitch stream unchanged (an inner layer's time pool, num_layers = 3) and, summed over
+    the rows that shared an entry, to every up_sixth channel of the group.  Seeds: kink-free picks of deep_grad_scan.py (PC2P_MEM=1)."""
+    opt = Namespace(conv_layers=conv_layers, n_filters=n_filters, head_layers=2, time_pool_size=2, genre=True, max_pool=False, frames=5, pc2p_mem=True)
+    torch.manual_seed(5 + seed)
+    net = ake_amd.PitchClassNet(288, 12, num_layers, 7, opt)
+    assert net.pc2p_mem
+    sd32 = {k: v.clone() for k, v in net.state_dict().items()}
+    x, seq, labels = make_case(2, frames, seed)
+    loss_ref, ref = reference_grads(sd32, x, seq, labels)
+    net = net.to(DEV).train()
+    out = net(x.to(DEV), seq.to(DEV))
+    loss = loss_fn(out[0], out[1], out[2], *(t.to(DEV) for t in labels))
+    assert abs(float(loss.detach()) - loss_ref) < 2e-5 * max(1.0, abs(loss_ref))
+    loss.backward()
+    rows = grad_errors(net, ref)
+    tight = [r for r in rows if r[1] != "model.0.pool_semi_b.weight"]
+    assert tight[0][0] < 3e-4 and rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
+
+
 @pytest.mark.parametrize("with_seq", [True, False])
 def test_max_pool_gradients(gold_default, with_seq):
     """--max_pool (models.py:764-797): torch.max over the frames -- for every clip without seq_length, for clip 0 only with it (the

@@ -117,7 +117,8 @@ def test_random_batches_against_oracles_and_autograd(batch, with_genre, use_cos,
         assert scal[9] == 0
 
 
-def test_general_step_takes_the_device_path_and_matches_the_torch_ops(gold_default):
+@pytest.mark.parametrize("mel_dtype", [torch.float32, torch.float64])
+def test_general_step_takes_the_device_path_and_matches_the_torch_ops(gold_default, mel_dtype):
     """PitchClassNet.general_step on the GPU goes through the kernel; the same step with the torch ops (a subclass overriding
     mirex_score keeps them) returns the same ten values and the same parameter gradients."""
     import json
@@ -132,7 +133,7 @@ def test_general_step_takes_the_device_path_and_matches_the_torch_ops(gold_defau
     g = torch.Generator().manual_seed(3)
     B, T = 6, 40
     key_id = torch.randint(0, 24, (B,), generator=g)
-    batch = {"mel": (torch.rand((B, 1, 288, T), generator=g) * 2.5).to(DEV), "seq_length": torch.tensor([T, T - 3, T, T - 9, T, T]),
+    batch = {"mel": (torch.rand((B, 1, 288, T), generator=g) * 2.5).to(DEV).to(mel_dtype), "seq_length": torch.tensor([T, T - 3, T, T - 9, T, T]),
              "key_labels": ake_amd.KEY_SIGNATURE_MAP[key_id % 21], "tonic_labels": F.one_hot(key_id % 12, 12).float(),
              "key_signature_id": F.one_hot(key_id, 24).float(), "genre": F.one_hot(torch.randint(0, 11, (B,), generator=g), 11)}
     batch["genre"][2] = 0
@@ -142,6 +143,7 @@ def test_general_step_takes_the_device_path_and_matches_the_torch_ops(gold_defau
         net.load_state_dict(golden_state_dict(gold_default), strict=True)
         net = net.to(DEV).train()
         vals = net.general_step(batch, 0, "train")
+        assert (vals[0].grad_fn is not None) and (("FusedGeneralStep" in type(vals[0].grad_fn.next_functions[0][0]).__name__) == (cls is ake_amd.PitchClassNet))
         vals[0].backward()
         res.append(([float(v.detach()) for v in vals], torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()))
     (va, ga), (vb, gb) = res

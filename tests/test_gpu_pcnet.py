@@ -335,8 +335,11 @@ def test_pc2p_mem_against_reference_fixture(gold_pc2pmem):
     ref = pcnet_oracle.pcnet_forward(golden_state_dict(gold_pc2pmem, torch.float64), x2[idx].double(), seq2[idx])
     for a, b in zip(got, ref):
         assert rel_err(a[idx].cpu(), b) < TOL
-    with pytest.raises(NotImplementedError):
-        net.train()(x, seq)
+    # train mode (batch statistics; gradients: tests/test_gpu_backward.py::test_pc2p_mem_net_gradients)
+    ref_t = pcnet_oracle.pcnet_forward(golden_state_dict(gold_pc2pmem, torch.float64), x2[:6].double(), seq2[:6], training=True)
+    with torch.no_grad():
+        for a, b in zip(net.train()(x2[:6].to(DEV), seq2[:6].to(DEV)), ref_t):
+            assert rel_err(a.cpu(), b) < TOL
 
 
 def test_p2pc_conv_against_reference_fixture(gold_p2pcconv):

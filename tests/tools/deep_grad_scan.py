@@ -11,7 +11,8 @@ import test_gpu_backward as tb
 nf = int(os.environ.get("NF", 4))
 for seed in range(int(os.environ.get("SEEDS", 3))):
     opt = Namespace(conv_layers=int(os.environ.get("CONV_LAYERS", 2)), n_filters=nf, head_layers=2, time_pool_size=2, genre=True, max_pool=False, frames=5,
-                    resblock=bool(int(os.environ.get("RESBLOCK", 0))))
+                    resblock=bool(int(os.environ.get("RESBLOCK", 0))), pc2p_mem=bool(int(os.environ.get("PC2P_MEM", 0))),
+                    p2pc_conv=bool(int(os.environ.get("P2PC_CONV", 0))), stay_sixth=bool(int(os.environ.get("STAY_SIXTH", 0))))
     torch.manual_seed(5 + seed)
     net = ake_amd.PitchClassNet(288, 12, int(os.environ.get("LAYERS", 3)), 7, opt)
     sd32 = {k: v.clone() for k, v in net.state_dict().items()}
