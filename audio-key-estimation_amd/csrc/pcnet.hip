@@ -818,6 +818,7 @@ struct Buffers {           // workspace carve
     double* stats = nullptr;           // [kStatSlots][bn_channels][2]
     float* bstats = nullptr;           // [bn_channels][3] batch mean, biased variance, element count
     std::vector<float*> semi_raw, aff_semi, aff_cat, aff_p2pin;
+    std::vector<float*> foldc_raw, aff_foldc, g_foldc;                // --p2pc_conv training: raw fold-conv output [B][C][12][T], pool.bn's table, its gradient
     // every convolution keeps its own raw output in training mode (the backward pass needs all of them)
     std::vector<std::vector<float*>> pst, aff_pst, pcst, aff_pcst;   // [layer][conv]
     std::vector<float*> hst[3], aff_hst[3];                            // [head][hidden conv]
@@ -888,7 +889,8 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
         b->wg_partial = cv.take<float>(b->wg_partial_floats);
         b->bstats = cv.take<float>(static_cast<size_t>(n->bn_channels) * 3);
         b->coef = cv.take<float>(static_cast<size_t>(n->bn_channels) * 4);
-        for (auto* v : {&b->semi_raw, &b->aff_semi, &b->aff_cat, &b->aff_p2pin, &b->g_pc, &b->g_cat, &b->g_semi, &b->g_p, &b->g_pin, &b->g_psix})
+        for (auto* v : {&b->semi_raw, &b->aff_semi, &b->aff_cat, &b->aff_p2pin, &b->g_pc, &b->g_cat, &b->g_semi, &b->g_p, &b->g_pin, &b->g_psix,
+                        &b->foldc_raw, &b->aff_foldc, &b->g_foldc})
             v->assign(L + 1, nullptr);
         b->pst.assign(L, {}); b->aff_pst.assign(L, {}); b->pcst.assign(L, {}); b->aff_pcst.assign(L, {});
         for (int i = 0; i < L; ++i) {
@@ -897,6 +899,11 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
             const int cs = i == 0 ? 1 : d.out_p, pc_out = i == 0 ? c.n_filters : d.out_pc;
             b->semi_raw[i] = cv.take<float>(B * cs * (P / 3) * Ti);
             b->g_semi[i] = cv.take<float>(B * cs * (P / 3) * Ti);
+            if (c.p2pc_conv) {
+                b->foldc_raw[i] = cv.take<float>(B * cs * 12 * Ti);
+                b->g_foldc[i] = cv.take<float>(B * cs * 12 * Ti);
+                b->aff_foldc[i] = cv.take<float>(3 * cs);
+            }
             b->aff_semi[i] = cv.take<float>(3 * cs);
             // --resblock: [conv0, (conv1 (2C), conv2, block output) per block] (res_stack_train); gradients: g, skip copy, 2C hidden map
             const int n_st = c.resblock ? 1 + 3 * c.conv_layers : c.conv_layers;
@@ -1861,7 +1868,23 @@ struct Fwd {
         }
         finalize_bn(bn, static_cast<double>(B) * (P / 3) * Tn, b.aff_semi[layer]);
         const long long total = static_cast<long long>(B) * pc.cin * 12 * Tn;
-        {
+        if (n->cfg.p2pc_conv) {   // models.py:108-133: the fold is a learned convolution over the octaves + BatchNorm (batch statistics) + LeakyReLU
+            const PackedConv& fc = n->foldc_t[layer];
+            const int bnf = bn_of("model." + std::to_string(layer) + ".pool.bn");
+            AKE_REQUIRE(pc.cin <= 64, AKE_ERR_UNSUPPORTED, "p2pc_conv training: %d channels", pc.cin);
+            {
+                ake::ProfScope ps("fold_conv_kernel", s);
+                hipLaunchKernelGGL(fold_conv_train_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.semi_raw[layer],
+                                   b.aff_semi[layer], n->blob_dev + fc.w_off, n->blob_dev + fc.b_off, b.foldc_raw[layer],
+                                   b.stats + 2 * n->bns[bnf].ch_off, 2 * n->bn_channels, pc.cin, P / 36, Tn, total);
+            }
+            finalize_bn(bnf, static_cast<double>(B) * 12 * Tn, b.aff_foldc[layer]);
+            {   // the folded channels are materialised as final activations: every reader of the concat buffer takes them as they are
+                ake::ProfScope ps("apply_affine_kernel", s);
+                hipLaunchKernelGGL(apply_affine_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.foldc_raw[layer],
+                                   b.aff_foldc[layer], dst, pc.cin, static_cast<long long>(12) * Tn, ctot, coff, total);
+            }
+        } else {
             ake::ProfScope ps("fold_affine_kernel", s);
             hipLaunchKernelGGL(fold_affine_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.semi_raw[layer],
                                b.aff_semi[layer], dst, pc.cin, P / 36, Tn, ctot, coff, total);
@@ -2002,7 +2025,9 @@ struct Fwd {
         int rc;
         if (!train && L > 1 && layer0_fused(mel, B)) return AKE_OK;
         AKE_REQUIRE(!mel_fm, AKE_ERR_UNSUPPORTED, "pcnet: this configuration does not take the frames-major input (ake_pcnet_accepts_frames_major)");
-        if (c.stay_sixth && L > 1) {   // models.py:366-367: the activated semitone map is the pitch stream from here on; its fold feeds pc2pc
+        if (c.stay_sixth && L > 1 && train) {   // training: the RAW semitone map (semi_raw[0]) + its pending table are the pitch stream
+            if ((rc = semi(0, mel, nullptr, B, P, T0, b.fold0, 1, 0, nullptr))) return rc;
+        } else if (c.stay_sixth && L > 1) {   // models.py:366-367: the activated semitone map is the pitch stream from here on; its fold feeds pc2pc
             if ((rc = semi_map(0, mel, B, P, T0, b.p0, false))) return rc;
             if ((rc = fold_maps(0, b.p0, 1, P / 3, B, T0, b.fold0, 1, 0))) return rc;
         } else if (c.denseblock) {   // the fold is channel 0 of the block's feature buffer (L == 1: fold0 itself, else layer 1's concat buffer)
@@ -2055,7 +2080,8 @@ struct Fwd {
         const int L = c.num_layers, tp = c.time_pool_size;
         const int P = c.stay_sixth ? c.pitches / 3 : c.pitches;  // rows of the pitch stream (--stay_sixth: semitones)
         int rc;
-        const float* p_cur = c.stay_sixth ? b.p0 + static_cast<size_t>(c0) * P * b.Tl[0] : mel;     // pitch stream [B][cp][P][T], always a final activation
+        // pitch stream [B][cp][P][T]: a final activation, except --stay_sixth in training (layer 0's raw semitone map + aff_semi[0])
+        const float* p_cur = c.stay_sixth ? (train ? b.semi_raw[0] : b.p0 + static_cast<size_t>(c0) * P * b.Tl[0]) : mel;
         int cp = 1;
         const float* pc_cur = nullptr;
         for (int i = 1; i < L; ++i) {
@@ -2109,6 +2135,11 @@ struct Fwd {
                                        static_cast<long long>(ctot) * 12 * Ti, b.pcd[i], per_clip, total);
                 }
                 sdesc = Src{p_cur, cp, b.pcd[i], d.prev_pc, 12};
+                if (train) {   // the stack's input table: the pitch stream's rows, then the pitch classes' (they were copied raw)
+                    if (i == 1) AKE_HIP_CHECK(hipMemcpyAsync(b.aff_p2pin[i], b.aff_semi[0], sizeof(float) * 3 * cp, hipMemcpyDeviceToDevice, s));
+                    else identity(b.aff_p2pin[i], cp);
+                    AKE_HIP_CHECK(hipMemcpyAsync(b.aff_p2pin[i] + 3 * cp, b.aff_cat[i], sizeof(float) * 3 * d.prev_pc, hipMemcpyDeviceToDevice, s));
+                }
             }
             if (c.pc2p_mem) {   // models.py:376-377: no concat, the summed up_sixth map is added to the pitch stream
                 const long long total = static_cast<long long>(B) * cp * P * Ti;
@@ -2189,6 +2220,12 @@ struct Fwd {
             if (fused_fold) {
             } else if (fused_semi) {
                 if ((rc = run_fold_max(out, d.out_p, P / 3, B, Ti, cat, ctot, d.prev_pc, s))) return rc;
+            } else if (c.stay_sixth && train) {   // ... through the last conv's pending BatchNorm + LeakyReLU
+                const long long total = static_cast<long long>(B) * d.out_p * 12 * Ti;
+                ake::ProfScope ps("fold_affine_kernel", s);
+                hipLaunchKernelGGL(fold_affine_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, out, out_aff, cat, d.out_p, P / 12, Ti,
+                                   ctot, d.prev_pc, total);
+                identity(b.aff_cat[i] + 3 * d.prev_pc, d.out_p);
             } else if (c.stay_sixth) {   // models.py:391: the stack's output is folded as it is (no semitone conv)
                 if ((rc = fold_maps(i, out, d.out_p, P, B, Ti, cat, ctot, d.prev_pc))) return rc;
             } else if ((rc = semi(i, out, out_aff, B, P, Ti, cat, ctot, d.prev_pc, train ? b.aff_cat[i] + 3 * d.prev_pc : nullptr))) return rc;
@@ -2501,8 +2538,8 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     AKE_REQUIRE(n && mel && key_out && d_key && d_tonic && grads_out, AKE_ERR_INVALID, "pcnet backward: null argument");
     AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
     AKE_REQUIRE(!n->cfg.genre || d_genre, AKE_ERR_INVALID, "pcnet backward: genre head enabled but d_genre is null");
-    AKE_REQUIRE(!(n->cfg.p2pc_conv || n->cfg.stay_sixth || n->cfg.denseblock), AKE_ERR_UNSUPPORTED,
-                "pcnet: training a --p2pc_conv / --stay_sixth / --denseblock net is not built");
+    AKE_REQUIRE(!(n->cfg.denseblock || (n->cfg.p2pc_conv && n->cfg.stay_sixth)), AKE_ERR_UNSUPPORTED,
+                "pcnet: training a --denseblock (or --p2pc_conv --stay_sixth) net is not built");
     Buffers b;
     int rc = plan_buffers(n, batch, batch, frames, workspace, &b, true);
     if (rc) return rc;
@@ -2569,8 +2606,8 @@ int ake_pcnet_forward_frames_major_f32(const ake_pcnet* n, const float* mel_fm, 
 int ake_pcnet_forward_train_f32(const ake_pcnet* n, const float* mel, int batch, int frames, const int64_t* seq_length,
                                 float* key_out, float* tonic_out, float* genre_out, float* bn_stats_out, void* workspace,
                                 size_t ws_bytes, ake_stream_t stream) {
-    AKE_REQUIRE(!n || !(n->cfg.p2pc_conv || n->cfg.stay_sixth || n->cfg.denseblock), AKE_ERR_UNSUPPORTED,
-                "pcnet: training a --p2pc_conv / --stay_sixth / --denseblock net is not built (inference only)");
+    AKE_REQUIRE(!n || !(n->cfg.denseblock || (n->cfg.p2pc_conv && n->cfg.stay_sixth)), AKE_ERR_UNSUPPORTED,
+                "pcnet: training a --denseblock (or --p2pc_conv --stay_sixth) net is not built (inference only)");
     return forward_impl(n, true, mel, batch, frames, seq_length, key_out, tonic_out, genre_out, bn_stats_out, workspace, ws_bytes, stream);
 }
 

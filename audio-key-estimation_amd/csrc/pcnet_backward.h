@@ -325,6 +325,7 @@ struct Bwd {
         for (int li = L - 1; li >= 1; --li) {
             const LayerDims& dl = n->dims[li];
             const int Tl = b.Tl[li];
+            const int Pp = c.stay_sixth ? P / 3 : P;              // rows of the pitch stream (--stay_sixth: semitone resolution)
             const int ctot = dl.prev_pc + dl.out_p;
             const bool inner = li < L - 1;
             const std::string m = "model." + std::to_string(li) + ".";
@@ -338,23 +339,34 @@ struct Bwd {
             const std::vector<float*>& zp = b.pst[li];
             float* g_p = b.g_p[li];
             float* g_p2 = b.g_p[li] + static_cast<size_t>(B) * dl.out_p * P * Tl;
-            if ((rc = semi_backward(li, zp.back(), b.aff_pst[li].back(), b.g_cat[li], ctot, dl.prev_pc, g_p))) return rc;
+            if (c.stay_sixth) {   // models.py:391: the stack's output (semitone resolution) was folded as it is
+                const long long total = static_cast<long long>(B) * dl.out_p * 12 * Tl;
+                ake::ProfScope ps("fold_bwd_kernel", s);
+                hipLaunchKernelGGL(fold_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_cat[li], zp.back(),
+                                   b.aff_pst[li].back(), g_p, dl.out_p, Pp / 12, Tl, ctot, dl.prev_pc, total);
+            } else if ((rc = semi_backward(li, zp.back(), b.aff_pst[li].back(), b.g_cat[li], ctot, dl.prev_pc, g_p))) return rc;
             if (inner) {   // second consumer of an inner layer's pitch stream: its time-pooled copy is the next layer's pitch input (models.py:395)
                 const LayerDims& dn = n->dims[li + 1];
-                const long long total = static_cast<long long>(B) * dl.out_p * P * ((Tl / tp) + (Tl % tp ? 1 : 0));
+                const long long total = static_cast<long long>(B) * dl.out_p * Pp * ((Tl / tp) + (Tl % tp ? 1 : 0));
                 ake::ProfScope ps("time_pool_bwd_kernel", s);
                 hipLaunchKernelGGL(time_pool_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_pin[li + 1], zp.back(),
-                                   b.aff_pst[li].back(), g_p, dl.out_p, P, Tl, tp, c.pc2p_mem ? dn.prev_p : dn.prev_p + dn.prev_pc, 0, total, 1);
+                                   b.aff_pst[li].back(), g_p, dl.out_p, Pp, Tl, tp, c.pc2p_mem ? dn.prev_p : dn.prev_p + dn.prev_pc, 0, total, 1);
             }
             // ---- pitch convs; input = (pitch stream | psix repeated) ----
             // (--pc2p_mem, models.py:145-166: the stack read the pitch stream + the summed up_sixth map, kept in b.pin by the forward)
             Src pin = c.pc2p_mem ? Src{b.pin[li], dl.prev_p, nullptr, 0, 0} : Src{li == 1 ? mel : b.ppool[li - 1], dl.prev_p, b.psix[li], dl.prev_pc, 36};
+            if (c.stay_sixth) pin = Src{li == 1 ? b.semi_raw[0] : b.ppool[li - 1], dl.prev_p, b.pcd[li], dl.prev_pc, 12};   // (table: aff_p2pin, set by the forward)
             const int pin_ch = c.pc2p_mem ? dl.prev_p : dl.prev_p + dl.prev_pc;
-            if ((rc = stack_backward(n->p2p_t[li], n->p2p_d[li], m + "p2p.layer.", false, 0, pin, b.aff_p2pin[li], zp, b.aff_pst[li], P, Tl, g_p, g_p2,
+            if ((rc = stack_backward(n->p2p_t[li], n->p2p_d[li], m + "p2p.layer.", false, 0, pin, b.aff_p2pin[li], zp, b.aff_pst[li], Pp, Tl, g_p, g_p2,
                                      b.g_pin[li], pin_ch, "conv_wgrad_kernel/p2p", "conv_mfma_kernel/p2p_dgrad")))
                 return rc;
             // ---- repeat (x P/36) backward, then up_sixth ----
-            if (c.pc2p_mem) {
+            if (c.stay_sixth) {   // no up_sixth: the pitch classes were repeated as they are
+                const long long total = static_cast<long long>(B) * dl.prev_pc * 12 * Tl;
+                ake::ProfScope ps("repeat_sum_kernel", s);
+                hipLaunchKernelGGL(repeat_sum_add_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_pin[li], b.g_cat[li],
+                                   dl.prev_p + dl.prev_pc, dl.prev_p, dl.prev_pc, Pp, Tl, ctot, total);
+            } else if (c.pc2p_mem) {
                 const long long total = static_cast<long long>(B) * dl.prev_pc * 36 * Tl;
                 ake::ProfScope ps("pc2p_mem_bwd_kernel", s);
                 hipLaunchKernelGGL(pc2p_mem_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_pin[li], b.g_psix[li],
@@ -365,18 +377,20 @@ struct Bwd {
                 hipLaunchKernelGGL(repeat_sum_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_pin[li], b.g_psix[li],
                                    dl.prev_p + dl.prev_pc, dl.prev_p, dl.prev_pc, P, Tl, total);
             }
-            bn_block_backward(m + "up_sixth_b", b.g_psix[li], b.psix[li], b.aff_p2pin[li] + 3 * dl.prev_p, dl.prev_pc, 0, 36 * Tl);
-            {
-                ake::ProfScope ps("up_sixth_bwd_weight_kernel", s);
-                hipLaunchKernelGGL(up_sixth_bwd_weight_kernel, dim3(dl.prev_pc * dl.prev_pc * 3, B), dim3(64), 0, s, b.g_psix[li], b.cat[li],
-                                   static_cast<long long>(ctot) * 12 * Tl, b.aff_cat[li], grad_of(m + "up_sixth.weight"),
-                                   static_cast<long long>(n->grad_floats), dl.prev_pc, Tl);
-            }
-            {
-                const long long total = static_cast<long long>(B) * dl.prev_pc * 12 * Tl;
-                ake::ProfScope ps("up_sixth_bwd_data_kernel", s);
-                hipLaunchKernelGGL(up_sixth_bwd_data_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_psix[li],
-                                   raw_of(m + "up_sixth.weight"), b.g_cat[li], ctot, dl.prev_pc, Tl, total);
+            if (!c.stay_sixth) {
+                bn_block_backward(m + "up_sixth_b", b.g_psix[li], b.psix[li], b.aff_p2pin[li] + 3 * dl.prev_p, dl.prev_pc, 0, 36 * Tl);
+                {
+                    ake::ProfScope ps("up_sixth_bwd_weight_kernel", s);
+                    hipLaunchKernelGGL(up_sixth_bwd_weight_kernel, dim3(dl.prev_pc * dl.prev_pc * 3, B), dim3(64), 0, s, b.g_psix[li], b.cat[li],
+                                       static_cast<long long>(ctot) * 12 * Tl, b.aff_cat[li], grad_of(m + "up_sixth.weight"),
+                                       static_cast<long long>(n->grad_floats), dl.prev_pc, Tl);
+                }
+                {
+                    const long long total = static_cast<long long>(B) * dl.prev_pc * 12 * Tl;
+                    ake::ProfScope ps("up_sixth_bwd_data_kernel", s);
+                    hipLaunchKernelGGL(up_sixth_bwd_data_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_psix[li],
+                                       raw_of(m + "up_sixth.weight"), b.g_cat[li], ctot, dl.prev_pc, Tl, total);
+                }
             }
             if (li >= 2) {   // channels [0, prev_pc) of the concat buffer = the time-pooled pitch classes of the layer below (models.py:394)
                 const LayerDims& dp = n->dims[li - 1];
@@ -405,21 +419,48 @@ struct Bwd {
                                      aff0, 12, T0, g0, g02, b.g_fold0, 1, "conv_wgrad_kernel/pc2pc0", "conv_mfma_kernel/pc2pc0_dgrad")))
                 return rc;
         }
-        return semi_backward(0, mel, nullptr, b.g_fold0, 1, 0, nullptr);
+        // --stay_sixth: layer 0's activated semitone map is also layer 1's pitch stream (channels [0, 1) of its stack's input gradient)
+        return semi_backward(0, mel, nullptr, b.g_fold0, 1, 0, nullptr, c.stay_sixth ? b.g_pin[1] : nullptr, n->dims[1].prev_p + n->dims[1].prev_pc);
     }
 
     // pool_semi(layer) + BatchNorm + LeakyReLU + octave fold, backward.  gfold: channel slice [g_coff, g_coff + C) of a [B][g_ctot][12][T]
     // gradient.  x / x_aff: the pitch tensor the semitone conv read.  ga_x (nullable): receives dL/d(act(x)).
-    int semi_backward(int layer, const float* x, const float* x_aff, const float* gfold, int g_ctot, int g_coff, float* ga_x) {
+    int semi_backward(int layer, const float* x, const float* x_aff, const float* gfold, int g_ctot, int g_coff, float* ga_x,
+                      const float* extra_g = nullptr, int extra_ctot = 0) {
         const PackedConv& pc = n->semi_t[layer];
         const int C = pc.cin, P = n->cfg.pitches, Tn = b.Tl[layer];
         const std::string m = "model." + std::to_string(layer) + ".";
         float* g = b.g_semi[layer];
-        {
+        if (n->cfg.p2pc_conv) {   // models.py:108-133: the fold is a convolution over the octaves + pool.bn + LeakyReLU
+            const long long per_clip = static_cast<long long>(C) * 12 * Tn, total = per_clip * B;
+            float* gf = b.g_foldc[layer];
+            {   // the slice of the concat gradient that belongs to the folded channels, dense
+                ake::ProfScope ps("slice_channels_kernel", s);
+                hipLaunchKernelGGL(slice_channels_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s,
+                                   gfold + static_cast<long long>(g_coff) * 12 * Tn, static_cast<long long>(g_ctot) * 12 * Tn, gf, per_clip, total);
+            }
+            bn_block_backward(m + "pool.bn", gf, b.foldc_raw[layer], b.aff_foldc[layer], C, 0, 12 * Tn);
+            {
+                ake::ProfScope ps("fold_conv_bwd_weight_kernel", s);
+                hipLaunchKernelGGL(fold_conv_bwd_weight_kernel, dim3(C * C * (P / 36), B), dim3(64), 0, s, gf, b.semi_raw[layer], b.aff_semi[layer],
+                                   grad_of(m + "pool.conv.weight"), static_cast<long long>(n->grad_floats), C, P / 36, Tn);
+            }
+            {
+                const long long tot = static_cast<long long>(B) * C * (P / 3) * Tn;
+                ake::ProfScope ps("fold_conv_bwd_data_kernel", s);
+                hipLaunchKernelGGL(fold_conv_bwd_data_kernel, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, gf,
+                                   raw_of(m + "pool.conv.weight"), g, C, P / 36, Tn, tot);
+            }
+        } else {
             const long long total = static_cast<long long>(B) * C * 12 * Tn;
             ake::ProfScope ps("fold_bwd_kernel", s);
             hipLaunchKernelGGL(fold_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, gfold, b.semi_raw[layer],
                                b.aff_semi[layer], g, C, P / 36, Tn, g_ctot, g_coff, total);
+        }
+        if (extra_g) {   // a second consumer of the activated semitone map: add its gradient (channels [0, C) of a wider tensor)
+            const long long HT = static_cast<long long>(P / 3) * Tn, total = static_cast<long long>(B) * C * HT;
+            ake::ProfScope ps("add_slice_kernel", s);
+            hipLaunchKernelGGL(add_slice_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, g, extra_g, C, HT, extra_ctot, total);
         }
         bn_block_backward(m + "pool_semi_b", g, b.semi_raw[layer], b.aff_semi[layer], C, 0, (P / 3) * Tn);
         {

@@ -255,6 +255,38 @@ __global__ void pc2p_mem_bwd_kernel(const float* __restrict__ g_pin, float* __re
     g_psix[i] = acc;
 }
 
+// ---- --p2pc_conv (models.py:108-133) backward: the octave-fold convolution, w[co][ci][o], dz [clip][C][12][T] --------------------
+// weight: dW[co][ci][o] += sum_{p,t} dz[co][p][t] * act(x[ci][12 o + p][t])          grid (C*C*n_oct, B)
+__global__ __launch_bounds__(64) void fold_conv_bwd_weight_kernel(const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ x_aff,
+                                                                  gfx_t* __restrict__ dW, long long slot_stride, int C, int n_oct, int T) {
+    const int widx = blockIdx.x;                 // (co, ci, o)
+    const int clip = blockIdx.y;
+    const int o = widx % n_oct, ci = (widx / n_oct) % C, co = widx / (n_oct * C);
+    const float* d = dz + (static_cast<long long>(clip) * C + co) * 12 * T;
+    const float* xs = x + ((static_cast<long long>(clip) * C + ci) * 12 * n_oct + 12 * o) * T;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < 12 * T; i += 64) acc = fmaf(d[i], affine_act(xs[i], x_aff, ci), acc);
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) acc += __shfl_xor(acc, k);
+    if (threadIdx.x == 0) grad_add(grad_slot(dW, slot_stride) + widx, acc);
+}
+// data: ga[ci][12 o + p][t] = sum_co dz[co][p][t] * w[co][ci][o]      (writes every element of ga)
+__global__ void fold_conv_bwd_data_kernel(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ ga, int C, int n_oct, int T,
+                                          long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;      // (clip, ci, row, t)
+    if (i >= total) return;
+    const int t = static_cast<int>(i % T);
+    long long q = i / T;
+    const int row = static_cast<int>(q % (12 * n_oct));
+    q /= 12 * n_oct;
+    const int ci = static_cast<int>(q % C);
+    const long long clip = q / C;
+    const int o = row / 12, p = row - 12 * o;
+    float acc = 0.f;
+    for (int co = 0; co < C; ++co) acc = fmaf(dz[((clip * C + co) * 12 + p) * T + t], w[(co * C + ci) * n_oct + o], acc);
+    ga[i] = acc;
+}
+
 // ---- --resblock: the activation behind the residual add -----------------------------------------------------------------
 // x_out = LeakyReLU(s), s = b2(z2) + x_in (sign(x_out) = sign(s)): g <- g * LeakyReLU'(s) is the gradient of BOTH summands; the copy in
 // g_skip travels down the skip connection while g goes through b2 / conv2 / b1 / conv1.
@@ -335,6 +367,36 @@ __global__ void repeat_sum_kernel(const float* __restrict__ gin, float* __restri
     float acc = 0.f;
     for (int o = 0; o < P / 36; ++o) acc += s[static_cast<long long>(o) * 36 * T];
     gps[i] = acc;
+}
+
+// --stay_sixth (models.py:322-323, 379-383): the pitch classes themselves were repeated over the octaves of the semitone-resolution pitch
+// stream -- their gradient, summed over the octaves, joins what the pitch-class stack left in channels [0, C) of the concat gradient.
+__global__ void repeat_sum_add_kernel(const float* __restrict__ gin, float* __restrict__ gcat, int cin_tot, int cp, int C, int H, int T, int g_ctot,
+                                      long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;      // (clip, c, pitch class, t)
+    if (i >= total) return;
+    const int t = static_cast<int>(i % T);
+    long long q = i / T;
+    const int r = static_cast<int>(q % 12);
+    q /= 12;
+    const int c = static_cast<int>(q % C);
+    const long long clip = q / C;
+    const float* s = gin + ((clip * cin_tot + cp + c) * H + r) * T + t;
+    float acc = 0.f;
+    for (int o = 0; o < H / 12; ++o) acc += s[static_cast<long long>(o) * 12 * T];
+    gcat[((clip * g_ctot + c) * 12 + r) * T + t] += acc;
+}
+
+// dst[clip][c][i] += src[clip][c (of src_ctot)][i]: a second consumer's gradient joins a dense one (--stay_sixth: layer 0's semitone map is
+// also layer 1's pitch stream)
+__global__ void add_slice_kernel(float* __restrict__ dst, const float* __restrict__ src, int C, long long HT, int src_ctot, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long ht = i % HT;
+    const long long q = i / HT;
+    const int c = static_cast<int>(q % C);
+    const long long clip = q / C;
+    dst[i] += src[(clip * src_ctot + c) * HT + ht];
 }
 
 // ---- semitone conv (3x3, stride (3,1), frames circular) backward ----------------------------------------------------

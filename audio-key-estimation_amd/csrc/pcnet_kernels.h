@@ -2716,6 +2716,49 @@ __global__ void up_sixth_train_kernel(const float* __restrict__ src, long long s
                                   static_cast<unsigned long long>(sh[k]));
 }
 
+// --p2pc_conv in training mode (Pitch2PitchClassConv, models.py:108-133): the octave-fold convolution (kernel (n_oct, 1), dilation
+// (12, 1)) over the RAW semitone maps [clip][C][12 * n_oct][T], whose pending BatchNorm + LeakyReLU is applied while loading; raw output
+// [clip][C][12][T] (dense) + the statistics of pool.bn.  w: the reference layout [co][ci][n_oct].
+__global__ void fold_conv_train_kernel(const float* __restrict__ src, const float* __restrict__ in_aff, const float* __restrict__ w,
+                                       const float* __restrict__ bias, float* __restrict__ dst, double* __restrict__ stats, int stats_stride, int C,
+                                       int n_oct, int T, long long total) {
+    __shared__ long long sh[2 * 128];                              // fixed point: the order of the threads' adds does not matter
+    for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) sh[k] = 0;
+    __syncthreads();
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;      // (clip, co, p, t)
+    if (i < total) {
+        const int t = static_cast<int>(i % T);
+        long long r = i / T;
+        const int p = static_cast<int>(r % 12); r /= 12;
+        const int co = static_cast<int>(r % C);
+        const long long clip = r / C;
+        const float* s = src + (clip * C * 12 * n_oct + p) * T + t;
+        float acc = bias[co];
+        for (int ci = 0; ci < C; ++ci)
+            for (int o = 0; o < n_oct; ++o)
+                acc = fmaf(affine_act(s[(static_cast<long long>(ci) * 12 * n_oct + 12 * o) * T], in_aff, ci), w[(co * C + ci) * n_oct + o], acc);
+        dst[i] = acc;
+        fx_add(&sh[2 * co], acc, kFxStat);
+        fx_add(&sh[2 * co + 1], static_cast<double>(acc) * acc, kFxStat);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * C; k += blockDim.x)
+        if (sh[k] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(stats + static_cast<size_t>(blockIdx.x & (kStatSlots - 1)) * stats_stride + k),
+                                  static_cast<unsigned long long>(sh[k]));
+}
+
+// dst[clip][coff + c][ht] (of dst_ctot channels) = LeakyReLU(BatchNorm(src[clip][c][ht])) with the pending table `aff`
+__global__ void apply_affine_kernel(const float* __restrict__ src, const float* __restrict__ aff, float* __restrict__ dst, int C, long long HT,
+                                    int dst_ctot, int dst_coff, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long ht = i % HT;
+    const long long q = i / HT;
+    const int c = static_cast<int>(q % C);
+    const long long clip = q / C;
+    dst[(clip * dst_ctot + dst_coff + c) * HT + ht] = affine_act(src[i], aff, c);
+}
+
 // time pooling with a pending affine on the input
 __global__ void time_pool_affine_kernel(const float* __restrict__ src, const float* __restrict__ aff, float* __restrict__ dst, int C,
                                         int H, int T, int tp, int dst_ctot, int dst_coff, long long total) {

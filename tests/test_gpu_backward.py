@@ -207,16 +207,24 @@ def test_resblock_net_gradients(num_layers, n_filters, conv_layers, batch, frame
     assert tight[0][0] < 3e-4 and rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
 
 
-@pytest.mark.parametrize("num_layers,n_filters,conv_layers,frames,seed", [(2, 4, 3, 52, 1), (3, 2, 2, 96, 0)])
-def test_pc2p_mem_net_gradients(num_layers, n_filters, conv_layers, frames, seed):
+@pytest.mark.parametrize("flag,num_layers,n_filters,conv_layers,frames,seed", [("pc2p_mem", 2, 4, 3, 52, 1), ("pc2p_mem", 3, 2, 2, 96, 0),
+                                                                               ("stay_sixth", 2, 4, 3, 52, 1), ("stay_sixth", 3, 2, 2, 96, 0),
+                                                                               ("p2pc_conv", 2, 4, 3, 52, 3), ("p2pc_conv", 3, 2, 2, 96, 0)])
+def test_variant_net_gradients(flag, num_layers, n_filters, conv_layers, frames, seed):
     """--pc2p_mem (PitchClass2Pitch_MemoryVariant, models.py:145-166, 376-377): the activated up_sixth map, summed over its channel groups,
     is ADDED to the pitch stream (row r takes third-semitone index r // (P / 36), the reference's reshape) instead of being concatenated.
     Backward: the stack's input gradient goes to the pitch stream unchanged (an inner layer's time pool, num_layers = 3) and, summed over
-    the rows that shared an entry, to every up_sixth channel of the group.  Seeds: kink-free picks of deep_grad_scan.py (PC2P_MEM=1)."""
-    opt = Namespace(conv_layers=conv_layers, n_filters=n_filters, head_layers=2, time_pool_size=2, genre=True, max_pool=False, frames=5, pc2p_mem=True)
+    the rows that shared an entry, to every up_sixth channel of the group.
+    --stay_sixth (models.py:322-323, 336, 366-367, 379-391): layer 0's activated semitone map is the 96-row pitch stream (two consumers:
+    its fold and layer 1's pitch convs), later layers have no up_sixth / pool_semi, repeat the pitch classes themselves and fold the
+    stack's output directly.
+    --p2pc_conv (Pitch2PitchClassConv, models.py:108-133): the octave fold is a learned convolution over the octaves + BatchNorm (pool.bn)
+    + LeakyReLU instead of the max; backward through pool.bn, the convolution's weight and data gradients, then pool_semi_b as before.
+    Seeds: kink-free picks of tests/tools/deep_grad_scan.py (PC2P_MEM=1 / STAY_SIXTH=1 / P2PC_CONV=1)."""
+    opt = Namespace(conv_layers=conv_layers, n_filters=n_filters, head_layers=2, time_pool_size=2, genre=True, max_pool=False, frames=5, **{flag: True})
     torch.manual_seed(5 + seed)
     net = ake_amd.PitchClassNet(288, 12, num_layers, 7, opt)
-    assert net.pc2p_mem
+    assert getattr(net, flag)
     sd32 = {k: v.clone() for k, v in net.state_dict().items()}
     x, seq, labels = make_case(2, frames, seed)
     loss_ref, ref = reference_grads(sd32, x, seq, labels)
@@ -226,7 +234,9 @@ def test_pc2p_mem_net_gradients(num_layers, n_filters, conv_layers, frames, seed
     assert abs(float(loss.detach()) - loss_ref) < 2e-5 * max(1.0, abs(loss_ref))
     loss.backward()
     rows = grad_errors(net, ref)
-    tight = [r for r in rows if r[1] != "model.0.pool_semi_b.weight"]
+    # gamma of a BatchNorm whose (positively homogeneous) output feeds a convolution + BatchNorm: the loss does not depend on it, its
+    # gradient is a cancelling sum at 1e-5 of the others (see grad_errors) -- layer 0's pool_semi_b and, with --p2pc_conv, pool.bn
+    tight = [r for r in rows if r[1] not in ("model.0.pool_semi_b.weight", "model.0.pool.bn.weight")]
     assert tight[0][0] < 3e-4 and rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
 
 

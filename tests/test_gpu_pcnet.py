@@ -357,8 +357,11 @@ def test_p2pc_conv_against_reference_fixture(gold_p2pcconv):
     ref = pcnet_oracle.pcnet_forward(golden_state_dict(gold_p2pcconv, torch.float64), x2.double(), seq2)
     for a, b in zip(net(x2.to(DEV), seq2.to(DEV)), ref):
         assert rel_err(a.cpu(), b) < TOL
-    with pytest.raises(NotImplementedError):
-        net.train()(x, seq)
+    # train mode (batch statistics; gradients: tests/test_gpu_backward.py::test_variant_net_gradients)
+    ref_t = pcnet_oracle.pcnet_forward(golden_state_dict(gold_p2pcconv, torch.float64), x2.double(), seq2, training=True)
+    with torch.no_grad():
+        for a, b in zip(net.train()(x2.to(DEV), seq2.to(DEV)), ref_t):
+            assert rel_err(a.cpu(), b) < TOL
 
 
 def test_stay_sixth_against_reference_fixture(gold_staysixth):
@@ -378,8 +381,11 @@ def test_stay_sixth_against_reference_fixture(gold_staysixth):
     ref = pcnet_oracle.pcnet_forward(golden_state_dict(gold_staysixth, torch.float64), x2[idx].double(), seq2[idx])
     for a, b in zip(got, ref):
         assert rel_err(a[idx].cpu(), b) < TOL
-    with pytest.raises(NotImplementedError):
-        net.train()(x, seq)
+    # train mode (batch statistics; gradients: tests/test_gpu_backward.py::test_variant_net_gradients)
+    ref_t = pcnet_oracle.pcnet_forward(golden_state_dict(gold_staysixth, torch.float64), x2[:6].double(), seq2[:6], training=True)
+    with torch.no_grad():
+        for a, b in zip(net.train()(x2[:6].to(DEV), seq2[:6].to(DEV)), ref_t):
+            assert rel_err(a.cpu(), b) < TOL
 
 
 def test_denseblock_against_reference_fixture(gold_denseblock):
