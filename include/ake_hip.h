@@ -123,10 +123,10 @@ typedef struct ake_pcnet_config {
     int resblock;       /* opt.resblock (models.py:181-187, 218-224, 402-454): 1 builds the residual-block stacks (inference and training) */
     int denseblock;     /* opt.denseblock (models.py:188-189, 225-226, 456-648): 1 builds the DenseNet-style stacks (pre-activation BatchNorm applied on
                          * load, 1-wide bottlenecks, features concatenated in place); not combinable with the other variants; inference only */
-    int stay_sixth;     /* opt.stay_sixth (models.py:322-323, 336, 366-367): 1 keeps the pitch stream at semitone resolution after layer 0; inference only */
+    int stay_sixth;     /* opt.stay_sixth (models.py:322-323, 336, 366-367): 1 keeps the pitch stream at semitone resolution after layer 0 */
     int only_semitones;
-    int p2pc_conv;      /* opt.p2pc_conv (models.py:108-133): 1 folds the octaves with a learned dilated conv + BN + LeakyReLU instead of the max; inference only */
-    int pc2p_mem;       /* opt.pc2p_mem (models.py:145-166): 1 adds the summed up_sixth map to the pitch stream instead of concatenating; inference only */
+    int p2pc_conv;      /* opt.p2pc_conv (models.py:108-133): 1 folds the octaves with a learned dilated conv + BN + LeakyReLU instead of the max */
+    int pc2p_mem;       /* opt.pc2p_mem (models.py:145-166): 1 adds the summed up_sixth map to the pitch stream instead of concatenating */
     /* opt.local (sliding-window key tracking, models.py:720-722): 0 = off, else the heads' pooling window
      * W = opt.frames * opt.loc_window_size - head_layers * (kernel_size - 1).  The layers then do not pool over time
      * (models.py:348, 394: time_pool_size is ignored) and the forward is ake_pcnet_forward_local_f32.  Inference only. */
@@ -213,7 +213,7 @@ int ake_pcnet_forward_train_f32(const ake_pcnet* net, const float* mel_dev, int 
  * accumulate != 0 adds to grads_out_dev instead of overwriting it (accumulate_grad_batches, train_model.py:118).
  * For a --local net d_* and key_out carry the per-frame shapes of the local forward (the sliding-window max routes each frame's
  * gradient to the first maximum of its window, as nn.MaxPool2d does).
- * Any num_layers, --resblock included; --pc2p_mem / --p2pc_conv / --stay_sixth / --denseblock: AKE_ERR_UNSUPPORTED. */
+ * Any num_layers; --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth train too; --denseblock: AKE_ERR_UNSUPPORTED. */
 size_t ake_pcnet_grad_floats(const ake_pcnet* net);
 int64_t ake_pcnet_grad_offset(const ake_pcnet* net, const char* name);
 int ake_pcnet_backward_f32(const ake_pcnet* net, const float* mel_dev, int batch, int frames, const int64_t* seq_length_dev,
