@@ -716,7 +716,7 @@ bool pc_f16x3_ok(const PackedConv& pt, int T_in, bool same_time) {
     if (off || pt.bf_off < 0 || pt.cin > 16) return false;
     const int T_out = same_time ? T_in : T_in - pt.kw + 1;
     if (T_out < 1) return false;
-    const size_t lds = (static_cast<size_t>(2) * 12 * (T_out + 8) * 2 + 2 * 4 * (pt.cout / 16) * 2 * 64) * sizeof(uint4);
+    const size_t lds = (static_cast<size_t>(2) * 12 * (T_out + 8) * 2 + 2 * 4 * ((pt.cout + 15) / 16) * 2 * 64) * sizeof(uint4);
     return lds <= 150 * 1024;
 }
 
@@ -754,7 +754,7 @@ int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
     }
     a.stats = stats; a.stats_stride = stats_stride;
     AKE_REQUIRE(!f16x3 || (dst_nchw && !planes_out && !pc2), AKE_ERR_STATE, "conv %s: the f16 x 3 form writes NCHW f32", name);
-    const size_t lds = (static_cast<size_t>(2) * 12 * a.Tp * 2 + 2 * 4 * (pc.cout / 16) * 2 * 64) * sizeof(uint4);   // patch + weight ring
+    const size_t lds = (static_cast<size_t>(2) * 12 * a.Tp * 2 + 2 * 4 * ((pc.cout + 15) / 16) * 2 * 64) * sizeof(uint4);   // patch + weight ring
     AKE_REQUIRE(lds <= 150 * 1024, AKE_ERR_UNSUPPORTED, "conv %s: %d frames do not fit the bf16 kernel's LDS patch", name, T_in);
     static ake::DeviceOnce attr_set;
     if (attr_set.need()) {
@@ -770,7 +770,7 @@ int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
     const int waves = std::min(8, (tiles + 3) / 4);
     dim3 grid((tiles + waves * 4 - 1) / (waves * 4), pc2 ? 2 : 1, batch), block(waves * 64);
     ake::ProfScope ps(name, s);
-    if (f16x3 && pc.cout == 16) hipLaunchKernelGGL((conv_pc_bf16_kernel<1, false, true>), grid, block, lds, s, a);
+    if (f16x3 && pc.cout <= 16) hipLaunchKernelGGL((conv_pc_bf16_kernel<1, false, true>), grid, block, lds, s, a);
     else if (f16x3) hipLaunchKernelGGL((conv_pc_bf16_kernel<2, false, true>), grid, block, lds, s, a);
     else if (pc.cout == 16 && planes_out) hipLaunchKernelGGL((conv_pc_bf16_kernel<1, true>), grid, block, lds, s, a);
     else if (pc.cout == 16) hipLaunchKernelGGL((conv_pc_bf16_kernel<1, false>), grid, block, lds, s, a);
@@ -1505,6 +1505,19 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
         pc->bf_off = -1;
         if (pc_bf16_eligible(*pc)) { pc->bf_off = static_cast<long long>(count); count += static_cast<size_t>(pc->kh) * 4 * (pc->cout / 16) * 2 * 64 + 64; }
     }
+    // data gradients of the pitch-class stacks of layers >= 1 (16 gradient channels in, <= 32 out: the first conv's is 24 wide) on the same
+    // f16 x 3 kernel; the transposed + flipped weights are the data-gradient packs
+    std::vector<PackedConv*> tpd;
+    if (!n->raw_w_off.empty() && !n->cfg.resblock && !n->cfg.denseblock)
+        for (size_t i = 1; i < n->pc2pc_d.size(); ++i)
+            for (PackedConv& pc : n->pc2pc_d[i]) tpd.push_back(&pc);
+    for (PackedConv* pc : tpd) {
+        pc->bf_off = -1;
+        if (pc->kh == 12 && pc->kw == 7 && pc->cin == 16 && pc->cout <= 32) {
+            pc->bf_off = static_cast<long long>(count);
+            count += static_cast<size_t>(pc->kh) * 4 * ((pc->cout + 15) / 16) * 2 * 64 + 64;
+        }
+    }
     std::vector<PackedConv*> pcs;                             // pitch-class convolutions: the PitchClass2PitchClass stacks and the heads' first conv
     for (auto& layer : n->pc2pc)
         for (PackedConv& pc : layer) pcs.push_back(&pc);
@@ -1562,7 +1575,13 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
         if (pc->bf_off >= 0) {
             const int NT = pc->cout / 16;
             hipLaunchKernelGGL(pack_pc_f16x3_kernel, dim3((pc->kh * 4 * NT * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
-                               n->bf_frags_dev + pc->bf_off, pc->cin, pc->cout, pc->co, NT, pc->kh);
+                               n->bf_frags_dev + pc->bf_off, pc->cin, pc->cout, pc->co, NT, pc->kh, 0);
+        }
+    for (const PackedConv* pc : tpd)
+        if (pc->bf_off >= 0) {
+            const int NT = (pc->cout + 15) / 16;
+            hipLaunchKernelGGL(pack_pc_f16x3_kernel, dim3((pc->kh * 4 * NT * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
+                               n->bf_frags_dev + pc->bf_off, pc->cin, pc->cout, pc->co, NT, pc->kh, pc->kh - 1);
         }
     for (const TrainFrag& t : tfr)
         hipLaunchKernelGGL(pack_p2p_f16_raw_kernel, dim3((14 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + t.raw, n->bf_frags_dev + t.pc->bf_off, t.cin, t.cout, t.flip);

@@ -14,6 +14,7 @@ struct Bwd {
     hipStream_t s;
     gfx_t* grads;        // slot 0 of the workspace's gradient slots ([kGradSlots][grad_floats], fixed point); run() is followed by grad_reduce_kernel
     int B;
+    unsigned short* planes_scratch = nullptr;   // f16 hi / lo planes of a 16-channel gradient (set around the pitch-class stacks of layers >= 1)
 
     gfx_t* grad_of(const std::string& key) const { return grads + n->grad_off[n->spec_index.at(key)]; }
     const float* raw_of(const std::string& key) const { return n->blob_dev + n->raw_w_off[n->spec_index.at(key)]; }
@@ -159,6 +160,14 @@ struct Bwd {
         if (kind == 0 && !accumulate && dst_coff == 0 && dst_ctot == pd.cout && T_dz == T_in &&
             run_p2p_f16x3(n, pd.bf_off, Src{dz, pd.cin, nullptr, 0, 0}, nullptr, nullptr, B, H, T_dz, dst, pd.cout, nullptr, 0, s, "conv_p2p_f16x3_kernel/p2p_dgrad"))
             return AKE_OK;
+        // pitch-class stacks of layers >= 1 (same-size 12 x 7 convolutions, 16 gradient channels): the f16 x 3 form of conv_pc_bf16_kernel with
+        // the transposed + flipped weights (f32-equivalent products; the f32 MFMA kernel took 0.17 ms per convolution and 256 clips)
+        if (kind == 1 && same_time && planes_scratch && !accumulate && dst_coff == 0 && dst_ctot == pd.cout && T_dz == T_in && H == 12 &&
+            pc_f16x3_ok(pd, T_dz, true)) {
+            run_nchw_to_cl16_f16x2(dz, pd.cin, B, T_dz, nullptr, planes_scratch, s);
+            return run_pc_bf16(n, pd, planes_scratch, B, T_dz, true, false, dst, nullptr, s, "conv_pc_f16x3_kernel/pc2pc_dgrad", nullptr, nullptr, true,
+                               nullptr, 0);
+        }
         return run_conv(n, pd, kind == 0 ? 0 : 1, Src{dz, pd.cin, nullptr, 0, 0}, B, H, T_dz, true, false, dst, dst_ctot, dst_coff, s, name,
                         nullptr, nullptr, &g, accumulate);
     }
@@ -332,9 +341,12 @@ struct Bwd {
             float* gl = b.g_pc[li];
             float* gl2 = gl + static_cast<size_t>(B) * dl.out_pc * 12 * Tl;
             // pc2pc stack (input = concat buffer: pitch classes of the layer below | folded semitone maps)
-            if ((rc = stack_backward(n->pc2pc_t[li], n->pc2pc_d[li], m + "pc2pc.layer.", true, 1, Src{b.cat[li], ctot, nullptr, 0, 0}, b.aff_cat[li],
-                                     b.pcst[li], b.aff_pcst[li], 12, Tl, gl, gl2, b.g_cat[li], ctot, "conv_wgrad_kernel/pc2pc", "conv_mfma_kernel/pc2pc_dgrad")))
-                return rc;
+            // (the inference ping-pong buffer of the layer is idle in training: the gradient's f16 planes go there)
+            planes_scratch = (dl.out_pc == 16 && !c.resblock) ? reinterpret_cast<unsigned short*>(b.pcb[li]) : nullptr;
+            rc = stack_backward(n->pc2pc_t[li], n->pc2pc_d[li], m + "pc2pc.layer.", true, 1, Src{b.cat[li], ctot, nullptr, 0, 0}, b.aff_cat[li],
+                                b.pcst[li], b.aff_pcst[li], 12, Tl, gl, gl2, b.g_cat[li], ctot, "conv_wgrad_kernel/pc2pc", "conv_mfma_kernel/pc2pc_dgrad");
+            planes_scratch = nullptr;
+            if (rc) return rc;
             // channels [prev_pc, ctot) of g_cat: gradient of the folded semitone features -> pool_semi(li) -> pitch stream
             const std::vector<float*>& zp = b.pst[li];
             float* g_p = b.g_p[li];

@@ -1982,7 +1982,10 @@ __global__ void nchw_to_cl16_f16x2_kernel(const float* __restrict__ src, long lo
 
 // f16 hi / lo * 2^11 weight fragments of conv_pc_bf16_kernel<.., F16X3> (same order as pack_pc_bf16_kernel), every output channel scaled
 // into [2^13, 2^14); the cout inverse scales follow the fragments.  From the VALU-layout TRAINING pack [co group of CO][ci][KH][7][CO].
-__global__ void pack_pc_f16x3_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin, int cout, int CO, int NT, int KH) {
+// dy_rot: fragment row dy holds kernel row (dy + dy_rot) mod KH -- the data gradient of a convolution over 12 circular rows whose kernel
+// starts AT the output row (py = 0) starts 11 rows before it, i.e. (mod 12) one row after: rotating the rows by 11 lets the same
+// py = 0 kernel compute it.
+__global__ void pack_pc_f16x3_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin, int cout, int CO, int NT, int KH, int dy_rot) {
     __shared__ int smax[32];
     if (threadIdx.x < 32) smax[threadIdx.x] = 0;
     __syncthreads();
@@ -2004,7 +2007,7 @@ __global__ void pack_pc_f16x3_kernel(const float* __restrict__ w, uint4* __restr
     for (int e = 0; e < 8; ++e) {
         const int ci = c8 + e;
         float v = 0.f;
-        if (dx < 7 && ci < cin && co < cout) v = sc * w[((((co / CO) * cin + ci) * KH + dy) * 7 + dx) * CO + (co % CO)];
+        if (dx < 7 && ci < cin && co < cout) v = sc * w[((((co / CO) * cin + ci) * KH + (dy + dy_rot) % KH) * 7 + dx) * CO + (co % CO)];
         const _Float16 hv = static_cast<_Float16>(v);
         hi[e >> 1] |= static_cast<unsigned int>(__builtin_bit_cast(unsigned short, hv)) << (16 * (e & 1));
         lo[e >> 1] |= f16_bits((v - static_cast<float>(hv)) * kP2pLoScale) << (16 * (e & 1));
