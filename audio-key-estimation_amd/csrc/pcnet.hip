@@ -53,6 +53,7 @@ struct PackedConv {          // device-resident folded + packed convolution
     size_t f_off = 0;
     long long bf_off = -1;         // 16-byte offset of the bf16x3 fragments in ake_pcnet::bf_frags_dev (8 -> 8 channel 7x7 pitch convs), or -1
     long long l0_off = -1;         // ... of the layer-0 form (layer0_mfma_kernel: <= 4 channels, 12 x 7), or -1
+    long long bf_off2 = -1;        // ... of input channels [16, 32) of a 32-channel data-gradient pack (heads' first conv, f16 x 3), or -1
 };
 
 struct LayerDims {
@@ -721,10 +722,11 @@ bool pc_f16x3_ok(const PackedConv& pt, int T_in, bool same_time) {
 }
 
 // training: NCHW f32 (+ the producer's pending BatchNorm + LeakyReLU) -> f16 hi / lo * 2^11 planes [hi: batch * 12 * T * 16][lo: ...]
-void run_nchw_to_cl16_f16x2(const float* src, int C, int batch, int T, const float* aff, unsigned short* planes, hipStream_t s) {
+// (src_ctot > 0: src points at the first of C channels inside a tensor of src_ctot channels)
+void run_nchw_to_cl16_f16x2(const float* src, int C, int batch, int T, const float* aff, unsigned short* planes, hipStream_t s, int src_ctot = 0) {
     const long long npos = static_cast<long long>(batch) * 12 * T;
     ake::ProfScope ps("nchw_to_cl16_f16x2_kernel", s);
-    hipLaunchKernelGGL(nchw_to_cl16_f16x2_kernel, dim3(static_cast<unsigned>((npos + 255) / 256)), dim3(256), 0, s, src, static_cast<long long>(C) * 12 * T, C, T,
+    hipLaunchKernelGGL(nchw_to_cl16_f16x2_kernel, dim3(static_cast<unsigned>((npos + 255) / 256)), dim3(256), 0, s, src, static_cast<long long>(src_ctot > 0 ? src_ctot : C) * 12 * T, C, T,
                        aff, planes, planes + npos * 16, npos);
 }
 
@@ -776,6 +778,35 @@ int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
     else if (pc.cout == 16) hipLaunchKernelGGL((conv_pc_bf16_kernel<1, false>), grid, block, lds, s, a);
     else if (planes_out) hipLaunchKernelGGL((conv_pc_bf16_kernel<2, true>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((conv_pc_bf16_kernel<2, false>), grid, block, lds, s, a);
+    return AKE_OK;
+}
+
+// f16 x 3 data gradient of a "valid" head convolution (32 -> 16 channels seen from the gradient): full correlation (pad 6 on both sides,
+// T_out = T_dz + 6) of 16 gradient channels (planes) with one half of the transposed + flipped weights; dst [clip][16][12][T_out] (+)=.
+int run_pc_f16x3_full(const ake_pcnet* n, long long frag_off, int kh, const unsigned short* planes, int batch, int T_dz, float* dst, bool accumulate,
+                      hipStream_t s, const char* name) {
+    PcBfArgs a;
+    std::memset(&a, 0, sizeof(a));
+    const long long npos_in = static_cast<long long>(batch) * 12 * T_dz;
+    a.xh = planes; a.xl = planes + npos_in * 16;
+    a.bfrag = n->bf_frags_dev + frag_off; a.bias = nullptr;
+    a.T_in = T_dz; a.T_out = T_dz + 6; a.pad_l = 6; a.Tp = a.T_out + 8;
+    a.cout = 16; a.lrelu = 0; a.KH = kh; a.circular = kh == 12 ? 1 : 0;
+    AKE_REQUIRE(kh == 12 || kh == 1, AKE_ERR_STATE, "conv %s: kernel rows %d", name, kh);
+    a.dst = dst; a.dst_clip_stride = static_cast<long long>(16) * 12 * a.T_out; a.cl_stride = 16;
+    a.accumulate = accumulate ? 1 : 0;
+    const size_t lds = (static_cast<size_t>(2) * 12 * a.Tp * 2 + 2 * 4 * 2 * 64) * sizeof(uint4);
+    AKE_REQUIRE(lds <= 150 * 1024, AKE_ERR_UNSUPPORTED, "conv %s: %d frames do not fit the kernel's LDS patch", name, T_dz);
+    static ake::DeviceOnce attr_set;
+    if (attr_set.need()) {
+        AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_bf16_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set.mark();
+    }
+    const int tiles = (12 * a.T_out + 15) / 16;
+    const int waves = std::min(8, (tiles + 3) / 4);
+    dim3 grid((tiles + waves * 4 - 1) / (waves * 4), 1, batch), block(waves * 64);
+    ake::ProfScope ps(name, s);
+    hipLaunchKernelGGL((conv_pc_bf16_kernel<1, false, true>), grid, block, lds, s, a);
     return AKE_OK;
 }
 
@@ -1518,6 +1549,21 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
             count += static_cast<size_t>(pc->kh) * 4 * ((pc->cout + 15) / 16) * 2 * 64 + 64;
         }
     }
+    // ... and of the heads' first convolutions (32 gradient channels -> 16 features: two 16-channel halves, bf_off / bf_off2)
+    std::vector<PackedConv*> thd;
+    if (!n->raw_w_off.empty() && !n->cfg.resblock && !n->cfg.denseblock && n->cfg.head_layers == 2) {
+        if (!n->head_key_d.empty()) thd.push_back(&n->head_key_d[0]);
+        if (!n->head_tonic_d.empty()) thd.push_back(&n->head_tonic_d[0]);
+        if (!n->head_genre_d.empty()) thd.push_back(&n->head_genre_d[0]);
+    }
+    for (PackedConv* pc : thd) {
+        pc->bf_off = pc->bf_off2 = -1;
+        if ((pc->kh == 12 || pc->kh == 1) && pc->kw == 7 && pc->cin == 32 && pc->cout == 16) {
+            const size_t one = static_cast<size_t>(pc->kh) * 4 * 2 * 64 + 64;
+            pc->bf_off = static_cast<long long>(count); pc->bf_off2 = static_cast<long long>(count + one);
+            count += 2 * one;
+        }
+    }
     std::vector<PackedConv*> pcs;                             // pitch-class convolutions: the PitchClass2PitchClass stacks and the heads' first conv
     for (auto& layer : n->pc2pc)
         for (PackedConv& pc : layer) pcs.push_back(&pc);
@@ -1574,15 +1620,27 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
     for (const PackedConv* pc : tpc)
         if (pc->bf_off >= 0) {
             const int NT = pc->cout / 16;
+            hipLaunchKernelGGL(pc_weight_scale_kernel, dim3(pc->cout), dim3(256), 0, s, n->blob_dev + pc->w_off,
+                               reinterpret_cast<float*>(n->bf_frags_dev + pc->bf_off + pc->kh * 4 * NT * 2 * 64), pc->cin, pc->cout, pc->co, pc->kh);
             hipLaunchKernelGGL(pack_pc_f16x3_kernel, dim3((pc->kh * 4 * NT * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
-                               n->bf_frags_dev + pc->bf_off, pc->cin, pc->cout, pc->co, NT, pc->kh, 0);
+                               n->bf_frags_dev + pc->bf_off, pc->cin, pc->cout, pc->co, NT, pc->kh, 0, 0);
         }
     for (const PackedConv* pc : tpd)
         if (pc->bf_off >= 0) {
             const int NT = (pc->cout + 15) / 16;
+            hipLaunchKernelGGL(pc_weight_scale_kernel, dim3(pc->cout), dim3(256), 0, s, n->blob_dev + pc->w_off,
+                               reinterpret_cast<float*>(n->bf_frags_dev + pc->bf_off + pc->kh * 4 * NT * 2 * 64), pc->cin, pc->cout, pc->co, pc->kh);
             hipLaunchKernelGGL(pack_pc_f16x3_kernel, dim3((pc->kh * 4 * NT * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
-                               n->bf_frags_dev + pc->bf_off, pc->cin, pc->cout, pc->co, NT, pc->kh, pc->kh - 1);
+                               n->bf_frags_dev + pc->bf_off, pc->cin, pc->cout, pc->co, NT, pc->kh, pc->kh - 1, 0);
         }
+    for (const PackedConv* pc : thd)
+        if (pc->bf_off >= 0)
+            for (int half = 0; half < 2; ++half) {
+                hipLaunchKernelGGL(pc_weight_scale_kernel, dim3(pc->cout), dim3(256), 0, s, n->blob_dev + pc->w_off,
+                                   reinterpret_cast<float*>(n->bf_frags_dev + (half ? pc->bf_off2 : pc->bf_off) + pc->kh * 4 * 2 * 64), pc->cin, pc->cout, pc->co, pc->kh);
+                hipLaunchKernelGGL(pack_pc_f16x3_kernel, dim3((pc->kh * 4 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
+                                   n->bf_frags_dev + (half ? pc->bf_off2 : pc->bf_off), pc->cin, pc->cout, pc->co, 1, pc->kh, pc->kh - 1, 16 * half);
+            }
     for (const TrainFrag& t : tfr)
         hipLaunchKernelGGL(pack_p2p_f16_raw_kernel, dim3((14 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + t.raw, n->bf_frags_dev + t.pc->bf_off, t.cin, t.cout, t.flip);
     for (size_t i = 1; i < n->semi.size(); ++i)

@@ -168,6 +168,20 @@ struct Bwd {
             return run_pc_bf16(n, pd, planes_scratch, B, T_dz, true, false, dst, nullptr, s, "conv_pc_f16x3_kernel/pc2pc_dgrad", nullptr, nullptr, true,
                                nullptr, 0);
         }
+        // the heads' first convolutions (16 features -> 32 channels, "valid" in time): 32 gradient channels as two 16-channel halves on the same
+        // kernel, full correlation, the second half (and every head after the first) adding to the feature gradient
+        if (kind == 1 && !same_time && planes_scratch && pd.bf_off >= 0 && pd.bf_off2 >= 0 && pd.cin == 32 && pd.cout == 16 && dst_coff == 0 &&
+            dst_ctot == 16 && T_in == T_dz + 6 && H == 12) {
+            const long long half = static_cast<long long>(B) * 12 * T_dz * 16 * 2;       // one set of hi + lo planes
+            int rc2;
+            for (int hf = 0; hf < 2; ++hf) {
+                unsigned short* pl = planes_scratch + hf * half;
+                run_nchw_to_cl16_f16x2(dz + static_cast<long long>(hf) * 16 * 12 * T_dz, 16, B, T_dz, nullptr, pl, s, 32);
+                if ((rc2 = run_pc_f16x3_full(n, hf ? pd.bf_off2 : pd.bf_off, fwd.kh, pl, B, T_dz, dst, accumulate || hf == 1, s, "conv_pc_f16x3_kernel/head_dgrad")))
+                    return rc2;
+            }
+            return AKE_OK;
+        }
         return run_conv(n, pd, kind == 0 ? 0 : 1, Src{dz, pd.cin, nullptr, 0, 0}, B, H, T_dz, true, false, dst, dst_ctot, dst_coff, s, name,
                         nullptr, nullptr, &g, accumulate);
     }
@@ -287,6 +301,12 @@ struct Bwd {
         HeadRun heads[3] = {{&n->head_key_t, &n->head_key_d, 1, "key_classifier", true},
                             {&n->head_tonic_t, &n->head_tonic_d, 1, "tonic_classifier", true},
                             {&n->head_genre_t, &n->head_genre_d, 2, "genre_classifier", false}};
+        {   // scratch for the f16 planes of the heads' 32-channel gradients: the last layer's inference ping-pong buffer (idle in training)
+            const int T1 = Tf - (c.kernel_size - 1);
+            const size_t need = static_cast<size_t>(2) * B * 12 * T1 * 16 * 2 * sizeof(unsigned short);
+            const size_t have = static_cast<size_t>(B) * (i == 0 ? c.n_filters : d.out_pc) * 12 * Ti * sizeof(float);
+            planes_scratch = (L > 1 && fin == 16 && !c.resblock && !c.denseblock && T1 > 0 && need <= have) ? reinterpret_cast<unsigned short*>(b.pcb[i]) : nullptr;
+        }
         for (int h = 0; h < (c.genre ? 3 : 2); ++h) {
             const auto& ct = *heads[h].ct;
             const auto& cd = *heads[h].cd;
@@ -314,6 +334,7 @@ struct Bwd {
             }
         }
 
+        planes_scratch = nullptr;
         float* g_last = b.g_pc[i];                                   // ga w.r.t. the last pc2pc activation of the last layer
         float* g_last2 = b.g_pc[i] + static_cast<size_t>(B) * (i == 0 ? c.n_filters : d.out_pc) * 12 * Ti;
         if (L > 1) {

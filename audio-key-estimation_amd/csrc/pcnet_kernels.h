@@ -1390,6 +1390,7 @@ struct PcBfArgs {
     // of channel c at 2c, 2c + 1; or null
     double* stats;
     int stats_stride;
+    int accumulate;               // F16X3, NCHW output: dst += (a data gradient that arrives in two 16-channel halves, or from several heads)
 };
 
 // F16X3 (training mode; forward with BatchNorm-on-load planes and the data gradients): the planes and fragments hold f16 hi and
@@ -1544,7 +1545,8 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
                         oh[idx] = static_cast<unsigned short>(hb);
                         ol[idx] = static_cast<unsigned short>(bf16_bits(v - __uint_as_float(hb << 16)));
                     } else {
-                        a.dst[clip * a.dst_clip_stride + (static_cast<long long>(co) * H_out + y) * a.T_out + t] = v;
+                        float* const d = a.dst + clip * a.dst_clip_stride + (static_cast<long long>(co) * H_out + y) * a.T_out + t;
+                        *d = (F16X3 && a.accumulate) ? *d + v : v;
                     }
                 }
                 if (++t == a.T_out) { t = 0; ++y; }
@@ -1985,27 +1987,36 @@ __global__ void nchw_to_cl16_f16x2_kernel(const float* __restrict__ src, long lo
 // dy_rot: fragment row dy holds kernel row (dy + dy_rot) mod KH -- the data gradient of a convolution over 12 circular rows whose kernel
 // starts AT the output row (py = 0) starts 11 rows before it, i.e. (mod 12) one row after: rotating the rows by 11 lets the same
 // py = 0 kernel compute it.
-__global__ void pack_pc_f16x3_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin, int cout, int CO, int NT, int KH, int dy_rot) {
-    __shared__ int smax[32];
-    if (threadIdx.x < 32) smax[threadIdx.x] = 0;
+// Inverse power-of-two scale of every output channel of a pack [group][ci][dy][dx][CO] (f16_weight_scale of its largest |w|), written
+// behind the fragments pack_pc_f16x3_kernel fills afterwards.  One workgroup per output channel.
+__global__ __launch_bounds__(256) void pc_weight_scale_kernel(const float* __restrict__ w, float* __restrict__ inv_scale, int cin, int cout, int CO, int KH) {
+    __shared__ float red[4];
+    const int co = blockIdx.x;
+    const int g = co / CO, c = co - g * CO;
+    float m = 0.f;
+    for (int r = threadIdx.x; r < cin * KH * 7; r += blockDim.x) m = fmaxf(m, fabsf(w[(static_cast<long long>(g) * cin * KH * 7 + r) * CO + c]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    for (int k = threadIdx.x; k < cout * cin * KH * 7; k += blockDim.x) {
-        const int c = k % CO, r = k / CO;                    // r = ((g * cin + ci) * KH + dy) * 7 + dx
-        const int g = r / (cin * KH * 7);
-        atomicMax(&smax[g * CO + c], __float_as_int(fabsf(w[k])));
-    }
-    __syncthreads();
+    if (threadIdx.x == 0) inv_scale[co] = 1.f / f16_weight_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
+// ci_off: the fragments take input channels [ci_off, ci_off + 16) of the pack (a 32-channel data gradient runs as two halves).
+__global__ void pack_pc_f16x3_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin, int cout, int CO, int NT, int KH, int dy_rot,
+                                     int ci_off) {
+    // (the inverse channel scales behind the fragments were written by pc_weight_scale_kernel: every block of this kernel scanning all
+    // weights for the channel maxima cost 28 us per pack, 0.5 ms per training step)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= KH * 4 * NT * 64) return;
     const int lane = i & 63, nt = (i >> 6) % NT, ks = i / (64 * NT);
     const int dy = ks >> 2, p = ks & 3;
     const int co = nt * 16 + (lane & 15), qq = lane >> 4;
     const int dx = 2 * p + (qq >> 1), c8 = 8 * (qq & 1);
-    const float sc = co < cout ? f16_weight_scale(__int_as_float(smax[co])) : 1.f;
-    if (ks == 0 && qq == 0 && co < cout) reinterpret_cast<float*>(out + KH * 4 * NT * 2 * 64)[co] = 1.f / sc;
+    const float sc = co < cout ? 1.f / reinterpret_cast<const float*>(out + KH * 4 * NT * 2 * 64)[co] : 1.f;      // a power of two: exact
     unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
     for (int e = 0; e < 8; ++e) {
-        const int ci = c8 + e;
+        const int ci = ci_off + c8 + e;
         float v = 0.f;
         if (dx < 7 && ci < cin && co < cout) v = sc * w[((((co / CO) * cin + ci) * KH + (dy + dy_rot) % KH) * 7 + dx) * CO + (co % CO)];
         const _Float16 hv = static_cast<_Float16>(v);
