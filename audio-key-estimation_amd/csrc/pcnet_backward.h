@@ -69,6 +69,47 @@ struct Bwd {
             hipLaunchKernelGGL(conv_wgrad_p2p_bf16_kernel, grid, dim3(256), lds, s, w);
             return AKE_OK;
         }
+        // 12 x 7 pitch-class convolutions (the pitch-class stacks, the heads' first convs): split-bf16 MFMA, one workgroup per (clip, 16 x 16
+        // channel block), see conv_wgrad_pc_bf16_kernel
+        {
+            const int T_out = kind == 0 ? T_in : (same_time ? T_in : T_in - pc.kw + 1);
+            static const int wpc_min_cout = std::getenv("AKE_WPC_MIN_COUT") ? std::atoi(std::getenv("AKE_WPC_MIN_COUT")) : 1;
+            if (!wg_f32 && kind == 1 && pc.kh == 12 && pc.kw == 7 && H == 12 && src.c1 == 0 && T_out >= 1 && pc.cout >= wpc_min_cout) {
+                WgradPcArgs w;
+                std::memset(&w, 0, sizeof(w));
+                w.x = src.p0; w.x_clip_stride = static_cast<long long>(src.ctot0 > 0 ? src.ctot0 : src.c0) * 12 * T_in;
+                w.in_affine = in_aff; w.dz = dz; w.dz_clip_stride = static_cast<long long>(dz_ctot) * 12 * T_out; w.dz_coff = dz_coff;
+                w.cin = pc.cin; w.cout = pc.cout; w.T_in = T_in; w.T_out = T_out; w.pad = same_time ? pc.kw / 2 : 0;
+                const int ks_max = T_out > 32 ? 2 : 1;             // k-steps of 32 output frames per workgroup (segments of kWpSeg frames)
+                w.AP = ks_max == 1 ? 56 : 88;                      // >= 16 + 32 k-steps and 8 x odd: the 16 lanes of a fragment read hit 16 different LDS slots
+                w.ZP = ks_max == 1 ? 40 : 72;
+                w.n_co_blocks = (pc.cout + 15) / 16;
+                w.n_seg = (T_out + kWpSeg - 1) / kWpSeg;
+                w.dW = dW; w.slot_stride = static_cast<long long>(n->grad_floats);
+                const long long n_w = static_cast<long long>(pc.cout) * pc.cin * 84;
+                static const bool partial_off = std::getenv("AKE_WGRAD_ATOMIC") != nullptr;
+                const long long n_wg = static_cast<long long>(B) * w.n_seg;
+                const bool use_partial = !partial_off && b.wg_partial && n_wg * n_w <= static_cast<long long>(b.wg_partial_floats);
+                if (use_partial) { w.partial = b.wg_partial; w.partial_stride = n_w; }
+                const size_t lds = static_cast<size_t>(2) * 12 * 16 * (w.AP + w.ZP) * sizeof(unsigned short);
+                static ake::DeviceOnce attr_set;
+                if (attr_set.need()) {
+                    AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_pc_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                    attr_set.mark();
+                }
+                {
+                    const char* slash = std::strrchr(name, '/');
+                    const std::string pname = std::string("conv_wgrad_pc_bf16_kernel") + (slash ? slash : "");
+                    ake::ProfScope ps(pname.c_str(), s);
+                    hipLaunchKernelGGL(conv_wgrad_pc_bf16_kernel, dim3(w.n_seg * w.n_co_blocks, (pc.cin + 15) / 16, B), dim3(512), lds, s, w);
+                }
+                if (use_partial) {
+                    ake::ProfScope ps("wgrad_partial_reduce_kernel", s);
+                    hipLaunchKernelGGL(wgrad_partial_reduce_kernel, dim3(static_cast<unsigned>((n_w + 63) / 64)), dim3(1024), 0, s, b.wg_partial, static_cast<int>(n_wg), n_w, dW);
+                }
+                return AKE_OK;
+            }
+        }
         // the kernel's accumulator tiles cover <= 32 output channels: wider convolutions (deeper / wider nets) run as slices of 32
         for (int co0 = 0; co0 < pc.cout; co0 += 32) {
             const int co_n = std::min(32, pc.cout - co0);

@@ -865,4 +865,164 @@ __global__ __launch_bounds__(256) void conv_wgrad_p2p_bf16_kernel(WgradBfArgs a)
     }
 }
 
+// ---- weight gradient of the 12 x 7 pitch-class convolutions (rows circular, frames zero-padded) on bf16 MFMA with split operands ------
+//   dW[co][ci][dy][dx] = sum_{clip, y, t} dz[co][y][t] * act(x[ci][(y + dy) mod 12][t + dx - pad])
+// The f32 kernel (conv_wgrad_kernel<1|2, 6>) keeps one input channel per wave on the 16x16x4 f32 MFMA: 0.27 ms per convolution and 256
+// clips, 1.7 ms of a 8.3 ms training step for the pitch-class stack and the heads.  Here a workgroup owns (clip, 16 output channels, 16
+// input channels); for every kernel tap (dy, dx) the 16 x 16 block D[co][ci] is a GEMM over the clip's positions, K = the frames of one
+// row at a time (k-steps of 32 frames):
+//   A[m = co][k = t] = dz[co][y][t]                      (aligned 16-byte reads from the dz planes)
+//   B[k = t][n = ci] = a[ci][(y + dy) mod 12][t + dx - pad]
+// Wave w < 7 owns the tap column dx = w and keeps the 12 accumulator tiles of its dy; the time shift of B is resolved in registers: two
+// aligned 16-byte reads and, for odd shifts, four v_alignbit per plane (the shift is a compile-time constant of the wave's code path, so
+// even shifts are plain register picks).  Both operands are staged once per workgroup: raw f32 -> (pending BatchNorm + LeakyReLU for
+// the input) -> bf16 hi / lo planes in LDS, frames padded with zeros on both sides.  Three MFMAs per tile and k-step (hi*hi, lo*hi,
+// hi*lo).  The block's partial sums go to the clip's slot of the partial buffer (wgrad_partial_reduce_kernel adds the clips in a fixed
+// order) or, without one, to the gradient slots with one fixed-point atomic per weight.
+constexpr int kWpSeg = 64;                  // output frames per workgroup (two k-steps): longer rows run as segments, blockIdx.x = (segment, co block)
+
+struct WgradPcArgs {
+    const float* x;           // [clip][x_ctot][12][T_in] raw, first cin channels
+    long long x_clip_stride;
+    const float* in_affine;   // [cin][3] or null
+    const float* dz;          // [clip][dz_ctot][12][T_out], channels [dz_coff, dz_coff + cout)
+    long long dz_clip_stride;
+    int dz_coff, cin, cout, T_in, T_out, pad;
+    int AP, ZP;               // plane pitches (elements)
+    int n_co_blocks, n_seg;   // gridDim.x = n_seg * n_co_blocks
+    float* partial;           // nullable, see above
+    long long partial_stride;
+    gfx_t* dW;                // [cout][cin][12][7], slot 0
+    long long slot_stride;
+};
+
+typedef float f32x4p __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8p __attribute__((ext_vector_type(8)));
+
+// elements [R, R + 8) of the 16 bf16 in (c0 | c1)
+template <int R>
+__device__ __forceinline__ bf16x8p shifted8(const uint4& c0, const uint4& c1) {
+    const unsigned int w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    constexpr int m = R >> 1;
+    uint4 o;
+    if (R & 1) {
+        o.x = __builtin_amdgcn_alignbit(w[m + 1], w[m], 16);
+        o.y = __builtin_amdgcn_alignbit(w[m + 2], w[m + 1], 16);
+        o.z = __builtin_amdgcn_alignbit(w[m + 3], w[m + 2], 16);
+        o.w = __builtin_amdgcn_alignbit(w[(m + 4) & 7], w[m + 3], 16);
+    } else {
+        o.x = w[m]; o.y = w[m + 1]; o.z = w[m + 2]; o.w = w[m + 3];
+    }
+    return __builtin_bit_cast(bf16x8p, o);
+}
+
+template <int R>
+__device__ __forceinline__ void wgrad_pc_multiply(const WgradPcArgs& a, const unsigned short* aH, const unsigned short* aL, const unsigned short* zH,
+                                                  const unsigned short* zL, int base0, int ksteps, int r16, int q, f32x4p (&acc)[12]) {
+    // the shifted operand is built ONCE per (input row, k-step) and meets the 12 dz rows it pairs with (row = y + dy): two aligned reads
+    // per tile instead of four, the alignbits outside the tap loop
+    for (int row = 0; row < 12; ++row)
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const int o = (row * 16 + r16) * a.AP + base0 + 32 * ks + 8 * q;       // aligned start of the shifted window inside the plane row
+            const uint4 h0 = *reinterpret_cast<const uint4*>(aH + o);
+            const uint4 l0 = *reinterpret_cast<const uint4*>(aL + o);
+            uint4 h1 = h0, l1 = l0;
+            if (R != 0) { h1 = *reinterpret_cast<const uint4*>(aH + o + 8); l1 = *reinterpret_cast<const uint4*>(aL + o + 8); }
+            const bf16x8p bh = shifted8<R>(h0, h1), bl = shifted8<R>(l0, l1);
+#pragma unroll
+            for (int dy = 0; dy < 12; ++dy) {
+                int y = row - dy;
+                y += y < 0 ? 12 : 0;
+                const int zo = (y * 16 + r16) * a.ZP + 32 * ks + 8 * q;
+                const bf16x8p ah = __builtin_bit_cast(bf16x8p, *reinterpret_cast<const uint4*>(zH + zo));
+                const bf16x8p al = __builtin_bit_cast(bf16x8p, *reinterpret_cast<const uint4*>(zL + zo));
+                acc[dy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[dy], 0, 0, 0);
+                acc[dy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[dy], 0, 0, 0);
+                acc[dy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[dy], 0, 0, 0);
+            }
+        }
+}
+
+__global__ __launch_bounds__(512) void conv_wgrad_pc_bf16_kernel(WgradPcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short wp_lds[];
+    // planes: activated input [12 rows][16 ci][AP] (frame f at element f + 8, zeros around), dz [12 rows][16 co][ZP] (zeros behind T_out)
+    const int nA = 12 * 16 * a.AP, nZ = 12 * 16 * a.ZP;
+    unsigned short* const aH = wp_lds;
+    unsigned short* const aL = aH + nA;
+    unsigned short* const zH = aL + nA;
+    unsigned short* const zL = zH + nZ;
+    const int clip = blockIdx.z, ci0 = 16 * blockIdx.y;
+    const int seg = blockIdx.x / a.n_co_blocks, co0 = 16 * (blockIdx.x - seg * a.n_co_blocks);
+    const int t0 = kWpSeg * seg;                                   // first output frame of this workgroup
+    const int T_seg = a.T_out - t0 < kWpSeg ? a.T_out - t0 : kWpSeg;
+    const int ksteps = (T_seg + 31) / 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    for (int i = tid; i < (nA + nZ); i += 512) reinterpret_cast<unsigned int*>(wp_lds)[i] = 0u;      // (2 (nA + nZ) elements = nA + nZ dwords)
+    __syncthreads();
+    {   // stage the input: one (channel, row) line of T_in frames per 64 threads' pass
+        const float* xc = a.x + clip * a.x_clip_stride;
+        const int ncl = (a.cin - ci0 < 16 ? a.cin - ci0 : 16) * 12;
+        for (int line = wave; line < ncl; line += 8) {
+            const int c = line / 12, row = line - 12 * c;
+            const float* xr = xc + (static_cast<long long>(ci0 + c) * 12 + row) * a.T_in;
+            for (int e0 = lane; e0 < a.AP; e0 += 64) {             // plane element e0 <-> input frame t0 + e0 - 8
+                const int t = t0 + e0 - 8;
+                if (t < 0 || t >= a.T_in) continue;
+                const float v = affine_act(xr[t], a.in_affine, ci0 + c);
+                const unsigned int hb = bf16_bits(v);
+                const int e = (row * 16 + c) * a.AP + e0;
+                aH[e] = static_cast<unsigned short>(hb);
+                aL[e] = static_cast<unsigned short>(bf16_bits(v - __uint_as_float(hb << 16)));
+            }
+        }
+        const float* zc = a.dz + clip * a.dz_clip_stride + static_cast<long long>(a.dz_coff + co0) * 12 * a.T_out;
+        const int nzl = (a.cout - co0 < 16 ? a.cout - co0 : 16) * 12;
+        for (int line = wave; line < nzl; line += 8) {
+            const int c = line / 12, row = line - 12 * c;
+            const float* zr = zc + (static_cast<long long>(c) * 12 + row) * a.T_out;
+            for (int t = lane; t < T_seg; t += 64) {
+                const float v = zr[t0 + t];
+                const unsigned int hb = bf16_bits(v);
+                const int e = (row * 16 + c) * a.ZP + t;
+                zH[e] = static_cast<unsigned short>(hb);
+                zL[e] = static_cast<unsigned short>(bf16_bits(v - __uint_as_float(hb << 16)));
+            }
+        }
+    }
+    __syncthreads();
+    if (wave >= 7) return;                                         // (no barrier below)
+    const int dx = wave;
+    f32x4p acc[12];
+#pragma unroll
+    for (int dy = 0; dy < 12; ++dy) acc[dy] = f32x4p{0.f, 0.f, 0.f, 0.f};
+    const int shift = 8 + dx - a.pad;                              // element of frame (t + dx - pad) at t = 0
+    const int base0 = shift & ~7;
+    switch (shift & 7) {                                           // wave-uniform: every wave runs one specialisation
+        case 0: wgrad_pc_multiply<0>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc); break;
+        case 1: wgrad_pc_multiply<1>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc); break;
+        case 2: wgrad_pc_multiply<2>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc); break;
+        case 3: wgrad_pc_multiply<3>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc); break;
+        case 4: wgrad_pc_multiply<4>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc); break;
+        case 5: wgrad_pc_multiply<5>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc); break;
+        case 6: wgrad_pc_multiply<6>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc); break;
+        default: wgrad_pc_multiply<7>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc); break;
+    }
+    // flush: D[row = co 4q + i][col = ci r16] of tap (dy, dx)
+    gfx_t* const dWs = grad_slot(a.dW, a.slot_stride);
+    const int ci = ci0 + r16;
+#pragma unroll
+    for (int dy = 0; dy < 12; ++dy)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = co0 + 4 * q + i;
+            if (co < a.cout && ci < a.cin) {
+                const long long idx = ((static_cast<long long>(co) * a.cin + ci) * 12 + dy) * 7 + dx;
+                if (a.partial) a.partial[(static_cast<long long>(clip) * a.n_seg + seg) * a.partial_stride + idx] = acc[dy][i];
+                else grad_add(dWs + idx, acc[dy][i]);
+            }
+        }
+}
+
 }  // namespace ake_k
