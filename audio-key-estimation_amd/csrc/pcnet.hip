@@ -2517,6 +2517,24 @@ struct Fwd {
                     src = dst; src_aff = aff; hc = pe.cout; Tcur -= c.kernel_size - 1;
                     continue;
                 }
+                if (train && lastj && j > 0 && pe.cout == 1 && pe.kw == 7 && !n->raw_w_off.empty()) {   // cin -> 1: one workgroup per clip, f32 VALU
+                    static const bool off = std::getenv("AKE_HEAD_LAST_MFMA") != nullptr;
+                    const std::string wn = std::string(heads[h].nm) + "." + std::to_string(3 * j) + (heads[h].kind == 2 ? "" : ".conv2d");
+                    const auto wi = n->spec_index.find(wn + ".weight"), bi = n->spec_index.find(wn + ".bias");
+                    const size_t lds = (static_cast<size_t>(hc) * 12 * Tcur + static_cast<size_t>(hc) * pe.kh * 7) * sizeof(float);
+                    if (!off && wi != n->spec_index.end() && bi != n->spec_index.end() && lds <= 150 * 1024 && Tcur - 6 >= 1) {
+                        static ake::DeviceOnce hl_attr;
+                        if (hl_attr.need()) {
+                            AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head_last_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                            hl_attr.mark();
+                        }
+                        ake::ProfScope ps(h == 2 ? "conv_head_last_kernel/genre" : "conv_head_last_kernel", s);
+                        hipLaunchKernelGGL(conv_head_last_kernel, dim3(B), dim3(384), lds, s, src, src_aff, n->blob_dev + n->raw_w_off[wi->second],
+                                           n->blob_dev + n->raw_w_off[bi->second], dst, hc, pe.kh, heads[h].kind == 2 ? 0 : 1, Tcur, Tcur - 6);
+                        src = dst; src_aff = aff; hc = pe.cout; Tcur -= c.kernel_size - 1;
+                        continue;
+                    }
+                }
                 if ((rc = conv(pe, train ? (*heads[h].ct)[j] : pe, lastj ? "" : std::string(heads[h].nm) + "." + std::to_string(3 * j + 1),
                                heads[h].kind, Src{src, hc, nullptr, 0, 0}, src_aff, B, 12, Tcur, false, dst, pe.cout, 0, aff,
                                h == 2 ? "conv_mfma_kernel/genre_head" : "conv_mfma_kernel/head")))

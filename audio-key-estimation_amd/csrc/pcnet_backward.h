@@ -70,7 +70,7 @@ struct Bwd {
             return AKE_OK;
         }
         // 12 x 7 pitch-class convolutions (the pitch-class stacks, the heads' first convs): split-bf16 MFMA, one workgroup per (clip, 16 x 16
-        // channel block), see conv_wgrad_pc_bf16_kernel
+        // channel block), see conv_wgrad_pc_f16x3_kernel
         {
             const int T_out = kind == 0 ? T_in : (same_time ? T_in : T_in - pc.kw + 1);
             static const int wpc_min_cout = std::getenv("AKE_WPC_MIN_COUT") ? std::atoi(std::getenv("AKE_WPC_MIN_COUT")) : 1;
@@ -94,14 +94,14 @@ struct Bwd {
                 const size_t lds = static_cast<size_t>(2) * 12 * 16 * (w.AP + w.ZP) * sizeof(unsigned short);
                 static ake::DeviceOnce attr_set;
                 if (attr_set.need()) {
-                    AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_pc_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                    AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_pc_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
                     attr_set.mark();
                 }
                 {
                     const char* slash = std::strrchr(name, '/');
-                    const std::string pname = std::string("conv_wgrad_pc_bf16_kernel") + (slash ? slash : "");
+                    const std::string pname = std::string("conv_wgrad_pc_f16x3_kernel") + (slash ? slash : "");
                     ake::ProfScope ps(pname.c_str(), s);
-                    hipLaunchKernelGGL(conv_wgrad_pc_bf16_kernel, dim3(w.n_seg * w.n_co_blocks, (pc.cin + 15) / 16, B), dim3(512), lds, s, w);
+                    hipLaunchKernelGGL(conv_wgrad_pc_f16x3_kernel, dim3(w.n_seg * w.n_co_blocks, (pc.cin + 15) / 16, B), dim3(512), lds, s, w);
                 }
                 if (use_partial) {
                     ake::ProfScope ps("wgrad_partial_reduce_kernel", s);

@@ -865,7 +865,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_p2p_bf16_kernel(WgradBfArgs a)
     }
 }
 
-// ---- weight gradient of the 12 x 7 pitch-class convolutions (rows circular, frames zero-padded) on bf16 MFMA with split operands ------
+// ---- weight gradient of the 12 x 7 pitch-class convolutions (rows circular, frames zero-padded) on f16 MFMA with split operands -------
 //   dW[co][ci][dy][dx] = sum_{clip, y, t} dz[co][y][t] * act(x[ci][(y + dy) mod 12][t + dx - pad])
 // The f32 kernel (conv_wgrad_kernel<1|2, 6>) keeps one input channel per wave on the 16x16x4 f32 MFMA: 0.27 ms per convolution and 256
 // clips, 1.7 ms of a 8.3 ms training step for the pitch-class stack and the heads.  Here a workgroup owns (clip, 16 output channels, 16
@@ -876,8 +876,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_p2p_bf16_kernel(WgradBfArgs a)
 // Wave w < 7 owns the tap column dx = w and keeps the 12 accumulator tiles of its dy; the time shift of B is resolved in registers: two
 // aligned 16-byte reads and, for odd shifts, four v_alignbit per plane (the shift is a compile-time constant of the wave's code path, so
 // even shifts are plain register picks).  Both operands are staged once per workgroup: raw f32 -> (pending BatchNorm + LeakyReLU for
-// the input) -> bf16 hi / lo planes in LDS, frames padded with zeros on both sides.  Three MFMAs per tile and k-step (hi*hi, lo*hi,
-// hi*lo).  The block's partial sums go to the clip's slot of the partial buffer (wgrad_partial_reduce_kernel adds the clips in a fixed
+// the input) -> f16 hi / lo * 2^11 planes in LDS, frames padded with zeros on both sides; the gradient tile is first scaled by a power of
+// two that brings its largest magnitude into f16's upper range (gradients are 1e-3 .. 1e-9).  Three MFMAs per tile and k-step: hi*hi into
+// one accumulator, lo*hi + hi*lo into a second one folded in with 2^-11 (2^-22 of a product dropped: f32-equivalent; bf16 hi / lo planes,
+// 16 mantissa bits, left 3e-4 on the cancelling sum of a 1-channel layer whose input carries a DC offset).  The block's partial sums go to the clip's slot of the partial buffer (wgrad_partial_reduce_kernel adds the clips in a fixed
 // order) or, without one, to the gradient slots with one fixed-point atomic per weight.
 constexpr int kWpSeg = 64;                  // output frames per workgroup (two k-steps): longer rows run as segments, blockIdx.x = (segment, co block)
 
@@ -897,11 +899,11 @@ struct WgradPcArgs {
 };
 
 typedef float f32x4p __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8p __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8p __attribute__((ext_vector_type(8)));
 
-// elements [R, R + 8) of the 16 bf16 in (c0 | c1)
+// elements [R, R + 8) of the 16 halves in (c0 | c1)
 template <int R>
-__device__ __forceinline__ bf16x8p shifted8(const uint4& c0, const uint4& c1) {
+__device__ __forceinline__ f16x8p shifted8(const uint4& c0, const uint4& c1) {
     const unsigned int w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
     constexpr int m = R >> 1;
     uint4 o;
@@ -913,12 +915,12 @@ __device__ __forceinline__ bf16x8p shifted8(const uint4& c0, const uint4& c1) {
     } else {
         o.x = w[m]; o.y = w[m + 1]; o.z = w[m + 2]; o.w = w[m + 3];
     }
-    return __builtin_bit_cast(bf16x8p, o);
+    return __builtin_bit_cast(f16x8p, o);
 }
 
 template <int R>
 __device__ __forceinline__ void wgrad_pc_multiply(const WgradPcArgs& a, const unsigned short* aH, const unsigned short* aL, const unsigned short* zH,
-                                                  const unsigned short* zL, int base0, int ksteps, int r16, int q, f32x4p (&acc)[12]) {
+                                                  const unsigned short* zL, int base0, int ksteps, int r16, int q, f32x4p (&acc)[12], f32x4p (&accl)[12]) {
     // the shifted operand is built ONCE per (input row, k-step) and meets the 12 dz rows it pairs with (row = y + dy): two aligned reads
     // per tile instead of four, the alignbits outside the tap loop
     for (int row = 0; row < 12; ++row)
@@ -928,22 +930,22 @@ __device__ __forceinline__ void wgrad_pc_multiply(const WgradPcArgs& a, const un
             const uint4 l0 = *reinterpret_cast<const uint4*>(aL + o);
             uint4 h1 = h0, l1 = l0;
             if (R != 0) { h1 = *reinterpret_cast<const uint4*>(aH + o + 8); l1 = *reinterpret_cast<const uint4*>(aL + o + 8); }
-            const bf16x8p bh = shifted8<R>(h0, h1), bl = shifted8<R>(l0, l1);
+            const f16x8p bh = shifted8<R>(h0, h1), bl = shifted8<R>(l0, l1);
 #pragma unroll
             for (int dy = 0; dy < 12; ++dy) {
                 int y = row - dy;
                 y += y < 0 ? 12 : 0;
                 const int zo = (y * 16 + r16) * a.ZP + 32 * ks + 8 * q;
-                const bf16x8p ah = __builtin_bit_cast(bf16x8p, *reinterpret_cast<const uint4*>(zH + zo));
-                const bf16x8p al = __builtin_bit_cast(bf16x8p, *reinterpret_cast<const uint4*>(zL + zo));
-                acc[dy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[dy], 0, 0, 0);
-                acc[dy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[dy], 0, 0, 0);
-                acc[dy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[dy], 0, 0, 0);
+                const f16x8p ah = __builtin_bit_cast(f16x8p, *reinterpret_cast<const uint4*>(zH + zo));
+                const f16x8p al = __builtin_bit_cast(f16x8p, *reinterpret_cast<const uint4*>(zL + zo));
+                acc[dy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[dy], 0, 0, 0);
+                accl[dy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, accl[dy], 0, 0, 0);
+                accl[dy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, accl[dy], 0, 0, 0);
             }
         }
 }
 
-__global__ __launch_bounds__(512) void conv_wgrad_pc_bf16_kernel(WgradPcArgs a) {
+__global__ __launch_bounds__(512) void conv_wgrad_pc_f16x3_kernel(WgradPcArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short wp_lds[];
     // planes: activated input [12 rows][16 ci][AP] (frame f at element f + 8, zeros around), dz [12 rows][16 co][ZP] (zeros behind T_out)
     const int nA = 12 * 16 * a.AP, nZ = 12 * 16 * a.ZP;
@@ -959,8 +961,31 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_bf16_kernel(WgradPcArgs a) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, q = lane >> 4;
+    __shared__ float zmax_red[8];
+    f16_saturate_mode();
     for (int i = tid; i < (nA + nZ); i += 512) reinterpret_cast<unsigned int*>(wp_lds)[i] = 0u;      // (2 (nA + nZ) elements = nA + nZ dwords)
+    // the gradient tile's scale: a power of two that brings its largest magnitude to [2^13, 2^14) (gradients are tiny -- 1e-3 .. 1e-9 -- and
+    // f16 hi + lo * 2^11 holds 22 bits below the largest value whatever the scale)
+    const float* const zc = a.dz + clip * a.dz_clip_stride + static_cast<long long>(a.dz_coff + co0) * 12 * a.T_out;
+    const int nzl = (a.cout - co0 < 16 ? a.cout - co0 : 16) * 12;
+    {
+        float m = 0.f;
+        for (int line = wave; line < nzl; line += 8) {
+            const float* zr = zc + static_cast<long long>(line) * a.T_out + t0;      // line = (channel, row): rows of T_out frames follow each other
+            for (int t = lane; t < T_seg; t += 64) m = fmaxf(m, fabsf(zr[t]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) zmax_red[wave] = m;
+    }
     __syncthreads();
+    float zs;
+    {
+        float m = zmax_red[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, zmax_red[w]);
+        zs = f16_weight_scale(m);
+    }
     {   // stage the input: one (channel, row) line of T_in frames per 64 threads' pass
         const float* xc = a.x + clip * a.x_clip_stride;
         const int ncl = (a.cin - ci0 < 16 ? a.cin - ci0 : 16) * 12;
@@ -971,47 +996,46 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_bf16_kernel(WgradPcArgs a) 
                 const int t = t0 + e0 - 8;
                 if (t < 0 || t >= a.T_in) continue;
                 const float v = affine_act(xr[t], a.in_affine, ci0 + c);
-                const unsigned int hb = bf16_bits(v);
+                const _Float16 hv = static_cast<_Float16>(v);
                 const int e = (row * 16 + c) * a.AP + e0;
-                aH[e] = static_cast<unsigned short>(hb);
-                aL[e] = static_cast<unsigned short>(bf16_bits(v - __uint_as_float(hb << 16)));
+                aH[e] = __builtin_bit_cast(unsigned short, hv);
+                aL[e] = static_cast<unsigned short>(f16_bits((v - static_cast<float>(hv)) * kP2pLoScale));
             }
         }
-        const float* zc = a.dz + clip * a.dz_clip_stride + static_cast<long long>(a.dz_coff + co0) * 12 * a.T_out;
-        const int nzl = (a.cout - co0 < 16 ? a.cout - co0 : 16) * 12;
         for (int line = wave; line < nzl; line += 8) {
             const int c = line / 12, row = line - 12 * c;
             const float* zr = zc + (static_cast<long long>(c) * 12 + row) * a.T_out;
             for (int t = lane; t < T_seg; t += 64) {
-                const float v = zr[t0 + t];
-                const unsigned int hb = bf16_bits(v);
+                const float v = zr[t0 + t] * zs;
+                const _Float16 hv = static_cast<_Float16>(v);
                 const int e = (row * 16 + c) * a.ZP + t;
-                zH[e] = static_cast<unsigned short>(hb);
-                zL[e] = static_cast<unsigned short>(bf16_bits(v - __uint_as_float(hb << 16)));
+                zH[e] = __builtin_bit_cast(unsigned short, hv);
+                zL[e] = static_cast<unsigned short>(f16_bits((v - static_cast<float>(hv)) * kP2pLoScale));
             }
         }
     }
     __syncthreads();
     if (wave >= 7) return;                                         // (no barrier below)
     const int dx = wave;
-    f32x4p acc[12];
+    f32x4p acc[12], accl[12];
 #pragma unroll
-    for (int dy = 0; dy < 12; ++dy) acc[dy] = f32x4p{0.f, 0.f, 0.f, 0.f};
+    for (int dy = 0; dy < 12; ++dy) { acc[dy] = f32x4p{0.f, 0.f, 0.f, 0.f}; accl[dy] = f32x4p{0.f, 0.f, 0.f, 0.f}; }
     const int shift = 8 + dx - a.pad;                              // element of frame (t + dx - pad) at t = 0
     const int base0 = shift & ~7;
     switch (shift & 7) {                                           // wave-uniform: every wave runs one specialisation
-        case 0: wgrad_pc_multiply<0>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc); break;
-        case 1: wgrad_pc_multiply<1>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc); break;
-        case 2: wgrad_pc_multiply<2>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc); break;
-        case 3: wgrad_pc_multiply<3>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc); break;
-        case 4: wgrad_pc_multiply<4>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc); break;
-        case 5: wgrad_pc_multiply<5>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc); break;
-        case 6: wgrad_pc_multiply<6>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc); break;
-        default: wgrad_pc_multiply<7>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc); break;
+        case 0: wgrad_pc_multiply<0>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc, accl); break;
+        case 1: wgrad_pc_multiply<1>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc, accl); break;
+        case 2: wgrad_pc_multiply<2>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc, accl); break;
+        case 3: wgrad_pc_multiply<3>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc, accl); break;
+        case 4: wgrad_pc_multiply<4>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc, accl); break;
+        case 5: wgrad_pc_multiply<5>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc, accl); break;
+        case 6: wgrad_pc_multiply<6>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc, accl); break;
+        default: wgrad_pc_multiply<7>(a, aH, aL, zH, zL, base0, ksteps, r16, q, acc, accl); break;
     }
     // flush: D[row = co 4q + i][col = ci r16] of tap (dy, dx)
     gfx_t* const dWs = grad_slot(a.dW, a.slot_stride);
     const int ci = ci0 + r16;
+    const float inv_zs = 1.f / zs;
 #pragma unroll
     for (int dy = 0; dy < 12; ++dy)
 #pragma unroll
@@ -1019,8 +1043,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_bf16_kernel(WgradPcArgs a) 
             const int co = co0 + 4 * q + i;
             if (co < a.cout && ci < a.cin) {
                 const long long idx = ((static_cast<long long>(co) * a.cin + ci) * 12 + dy) * 7 + dx;
-                if (a.partial) a.partial[(static_cast<long long>(clip) * a.n_seg + seg) * a.partial_stride + idx] = acc[dy][i];
-                else grad_add(dWs + idx, acc[dy][i]);
+                const float v = fmaf(accl[dy][i], kP2pLoInv, acc[dy][i]) * inv_zs;
+                if (a.partial) a.partial[(static_cast<long long>(clip) * a.n_seg + seg) * a.partial_stride + idx] = v;
+                else grad_add(dWs + idx, v);
             }
         }
 }

@@ -2773,6 +2773,39 @@ __global__ void apply_affine_kernel(const float* __restrict__ src, const float* 
     dst[(clip * dst_ctot + dst_coff + c) * HT + ht] = affine_act(src[i], aff, c);
 }
 
+// The heads' LAST convolution in training mode (cin -> 1 channel, kh x 7, "valid" in time; key / tonic: 12 circular rows, genre: kh = 2 over
+// valid rows; models.py:36-47, 716-729): one output channel leaves 15 of 16 MFMA columns empty and the generic kernel walks its 32 input
+// channels in 16 LDS passes (0.085 ms per head and 256 clips, 0.1 ms at 8 clips).  Here one workgroup per clip stages the activated input
+// (pending BatchNorm + LeakyReLU applied) and the raw weights [ci][kh][7] in LDS; a thread owns one output position.  Exact f32.
+__global__ __launch_bounds__(384) void conv_head_last_kernel(const float* __restrict__ x, const float* __restrict__ x_aff, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ dst, int cin, int KH, int circular,
+                                                             int T_in, int T_out) {
+    extern __shared__ float hl_lds[];
+    float* const xs = hl_lds;                        // [cin][12][T_in]
+    float* const ws = hl_lds + cin * 12 * T_in;      // [cin][KH][7]
+    const int clip = blockIdx.x;
+    const float* xc = x + static_cast<long long>(clip) * cin * 12 * T_in;
+    for (int i = threadIdx.x; i < cin * 12 * T_in; i += blockDim.x) xs[i] = affine_act(xc[i], x_aff, i / (12 * T_in));
+    for (int i = threadIdx.x; i < cin * KH * 7; i += blockDim.x) ws[i] = w[i];
+    __syncthreads();
+    const int H_out = circular ? 12 : 12 - KH + 1;
+    const float b0 = bias ? bias[0] : 0.f;
+    for (int o = threadIdx.x; o < H_out * T_out; o += blockDim.x) {
+        const int y = o / T_out, t = o - y * T_out;
+        float acc = b0;
+        for (int ci = 0; ci < cin; ++ci)
+            for (int dy = 0; dy < KH; ++dy) {
+                int row = y + dy;
+                row -= row >= 12 ? 12 : 0;
+                const float* xr = xs + (ci * 12 + row) * T_in + t;
+                const float* wr = ws + (ci * KH + dy) * 7;
+#pragma unroll
+                for (int dx = 0; dx < 7; ++dx) acc = fmaf(xr[dx], wr[dx], acc);
+            }
+        dst[(static_cast<long long>(clip) * H_out + y) * T_out + t] = acc;
+    }
+}
+
 // time pooling with a pending affine on the input
 __global__ void time_pool_affine_kernel(const float* __restrict__ src, const float* __restrict__ aff, float* __restrict__ dst, int C,
                                         int H, int T, int tp, int dst_ctot, int dst_coff, long long total) {
