@@ -462,12 +462,21 @@ __global__ __launch_bounds__(256) void semi_bwd_weight_kernel(const float* __res
         if (pair < pairs) {
             const float* dr = ldz + co * T;
             const float* xr = lx + ci * 3 * Tp;
+            // sliding window over the frames: the three taps of a row share two of their three values with the previous frame (4 LDS reads per
+            // frame instead of 10; every accumulator still receives its products in frame order: bit-identical sums)
+            float x0[3], x1[3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) { x0[dy] = xr[dy * Tp]; x1[dy] = xr[dy * Tp + 1]; }
             for (int t = 0; t < T; ++t) {
                 const float d = dr[t];
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) acc[dy * 3 + dx] = fmaf(d, xr[dy * Tp + t + dx], acc[dy * 3 + dx]);
+                for (int dy = 0; dy < 3; ++dy) {
+                    const float x2 = xr[dy * Tp + t + 2];
+                    acc[dy * 3 + 0] = fmaf(d, x0[dy], acc[dy * 3 + 0]);
+                    acc[dy * 3 + 1] = fmaf(d, x1[dy], acc[dy * 3 + 1]);
+                    acc[dy * 3 + 2] = fmaf(d, x2, acc[dy * 3 + 2]);
+                    x0[dy] = x1[dy]; x1[dy] = x2;
+                }
             }
         }
     }
