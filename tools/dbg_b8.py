@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""One training forward + backward of the default net at the reference's batch size (8 clips, 76 frames): run with AKE_DEBUG=1 to print the
+tile geometry every generic convolution picks (choose_tile / want_tiles), see DESIGN.md section 5 "BASELINE configs[2]"."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from argparse import Namespace
 import torch, ake_amd
 opt = Namespace(conv_layers=3, n_filters=4, head_layers=2, time_pool_size=2, genre=True, max_pool=False, frames=5, octaves=8, lr=3e-4)
