@@ -555,10 +555,10 @@ struct Bwd {
                                grad_of(m + "pool_semi.weight"), static_cast<long long>(n->grad_floats), C, P, Tn, rows);
         }
         if (ga_x) {
-            const long long total = static_cast<long long>(B) * C * P * Tn;
+            const long long total = static_cast<long long>(B) * P * Tn;
             ake::ProfScope ps("semi_bwd_data_kernel", s);
-            hipLaunchKernelGGL(semi_bwd_data_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, g, raw_of(m + "pool_semi.weight"),
-                               ga_x, C, P, Tn, total);
+            hipLaunchKernelGGL(semi_bwd_data_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), sizeof(float) * C * C * 9, s, g,
+                               raw_of(m + "pool_semi.weight"), ga_x, C, P, Tn, total);
         }
         return AKE_OK;
     }

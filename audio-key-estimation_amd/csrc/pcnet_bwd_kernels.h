@@ -401,25 +401,41 @@ __global__ void add_slice_kernel(float* __restrict__ dst, const float* __restric
 
 // ---- semitone conv (3x3, stride (3,1), frames circular) backward ----------------------------------------------------
 // data: ga[ci][3s+dy][t] = sum_{co,dx} dz[co][s][(t - dx + 1) mod T] * w[co][ci][dy][dx]      (w in reference layout)
-__global__ void semi_bwd_data_kernel(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ ga, int C, int H, int T,
-                                     long long total) {
+// A thread owns one position (clip, row, frame) and up to 8 input channels at a time: the three dz values of an output channel are read once
+// for all of them (one thread per (channel, position) read every dz value 8 x 3 times through L2: 0.375 ms per step, latency-bound).  Every
+// output still adds its products in the order (co, dx): bit-identical to the per-channel form.   total = clips * H * T
+__global__ __launch_bounds__(256) void semi_bwd_data_kernel(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ ga, int C, int H,
+                                                            int T, long long total) {
+    extern __shared__ float sw_lds[];                              // the raw weights [co][ci][3][3]
+    for (int k = threadIdx.x; k < C * C * 9; k += blockDim.x) sw_lds[k] = w[k];
+    __syncthreads();
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int t = static_cast<int>(i % T);
-    long long q = i / T;
+    const long long q = i / T;
     const int r = static_cast<int>(q % H);
-    q /= H;
-    const int ci = static_cast<int>(q % C);
-    const long long clip = q / C;
+    const long long clip = q / H;
     const int s = r / 3, dy = r - 3 * s;
-    float acc = 0.f;
-    for (int co = 0; co < C; ++co) {
-        const float* drow = dz + ((clip * C + co) * (H / 3) + s) * T;
-        const float* wp = w + ((co * C + ci) * 3 + dy) * 3;
+    const int tp = wrap(t + 1, T), tm = wrap(t - 1, T);
+    for (int ci0 = 0; ci0 < C; ci0 += 8) {
+        const int nci = C - ci0 < 8 ? C - ci0 : 8;
+        float acc[8];
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) acc = fmaf(drow[wrap(t - dx + 1, T)], wp[dx], acc);
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int co = 0; co < C; ++co) {
+            const float* drow = dz + ((clip * C + co) * (H / 3) + s) * T;
+            const float d0 = drow[tp], d1 = drow[t], d2 = drow[tm];            // dx = 0, 1, 2 <-> frame t - dx + 1
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < nci) {
+                    const float* wp = sw_lds + ((co * C + ci0 + k) * 3 + dy) * 3;
+                    acc[k] = fmaf(d2, wp[2], fmaf(d1, wp[1], fmaf(d0, wp[0], acc[k])));
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < nci) ga[((clip * C + ci0 + k) * H + r) * T + t] = acc[k];
     }
-    ga[i] = acc;
 }
 
 // weight: dW[co][ci][dy][dx] += sum_{s,t} dz[co][s][t] * act(x[ci][3s+dy][(t+dx-1) mod T])
