@@ -455,6 +455,8 @@ __global__ __launch_bounds__(256) void semi_bwd_weight_kernel(const float* __res
     const int Tp = T + 2;
     float* ldz = semi_lds + wave * (C * T + 3 * C * Tp);      // [co][T]
     float* lx = ldz + C * T;                                  // [ci][3][T + 2]   (index 0 <-> frame -1)
+    const unsigned int magicT = 0xFFFFFFFFu / static_cast<unsigned int>(T) + 1u;        // floor(i / T) = umulhi(i, magic) for i < 2^16
+    const unsigned int magicTp = 0xFFFFFFFFu / static_cast<unsigned int>(Tp) + 1u;
     const int pairs = C * C;
     const int pair = blockIdx.z * 64 + lane;                  // wider layers (C > 8): blockIdx.z walks the (co, ci) pairs 64 at a time
     const int co = pair / C, ci = pair - co * C;
@@ -463,12 +465,14 @@ __global__ __launch_bounds__(256) void semi_bwd_weight_kernel(const float* __res
     for (int k = 0; k < 9; ++k) acc[k] = 0.f;
     const int s_end = min(S, static_cast<int>(blockIdx.x + 1) * rows_per_wg);
     for (int srow = blockIdx.x * rows_per_wg + wave; srow < s_end; srow += 4) {
+        // (index splits by multiply-high with precomputed reciprocals: two integer divisions per staged value were a third of the kernel)
         for (int i = lane; i < C * T; i += 64) {
-            const int c = i / T, t = i - c * T;
+            const int c = static_cast<int>(__umulhi(static_cast<unsigned int>(i), magicT)), t = i - c * T;
             ldz[i] = dz[((static_cast<long long>(clip) * C + c) * S + srow) * T + t];
         }
         for (int i = lane; i < 3 * C * Tp; i += 64) {
-            const int c = i / (3 * Tp), r = (i - c * 3 * Tp) / Tp, tj = i - c * 3 * Tp - r * Tp;
+            const int cr = static_cast<int>(__umulhi(static_cast<unsigned int>(i), magicTp));      // (c, r) = i / Tp
+            const int c = static_cast<int>(__umulhi(static_cast<unsigned int>(cr), 0x55555556u)), r = cr - 3 * c, tj = i - cr * Tp;
             int t = tj - 1;
             t += t < 0 ? T : 0;
             t -= t >= T ? T : 0;
