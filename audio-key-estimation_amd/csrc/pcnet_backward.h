@@ -31,11 +31,11 @@ struct Bwd {
         dim3 grid(l.C, B);
         {
             ake::ProfScope ps("act_bwd_stats_kernel", s);
-            hipLaunchKernelGGL(act_bwd_stats_kernel, grid, dim3(256), 0, s, g, z, aff, bst, st2, ctot, coff, HT);
+            hipLaunchKernelGGL(act_bwd_stats_kernel, grid, dim3(256), 0, s, g, z, aff, bst, st2, static_cast<long long>(3) * n->bn_channels, ctot, coff, HT);
         }
         {
             ake::ProfScope ps("bn_bwd_coef_kernel", s);
-            hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((l.C + 63) / 64), dim3(64), 0, s, st2, bst, n->blob_dev + l.gamma_off, coef,
+            hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((l.C + 63) / 64), dim3(64), 0, s, st2, static_cast<long long>(3) * n->bn_channels, bst, n->blob_dev + l.gamma_off, coef,
                                grad_of(bn_name + ".weight"), grad_of(bn_name + ".bias"), l.C);
         }
         {
