@@ -625,7 +625,7 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
 // 7 x 7 circular pitch convolution with f32-equivalent products (conv_p2p_f16x3_kernel): train-mode forward (in_aff, bias, statistics)
 // and data gradient (none of them).  false when the shape does not qualify: the caller then runs conv_mfma_kernel.
 bool run_p2p_f16x3(const ake_pcnet* n, long long frag_off, const Src& src, const float* in_aff, const float* bias, int batch, int H, int T, float* dst,
-                   int cout, double* stats, int stats_stride, hipStream_t s, const char* name) {
+                   int cout, double* stats, int stats_stride, hipStream_t s, const char* name, const unsigned int* in_amax = nullptr) {
     static const bool off = std::getenv("AKE_P2P_TRAIN_F32") != nullptr;
     if (off || frag_off < 0 || T < 2 || (T & 1) || src.c0 < 1 || src.c0 + src.c1 > 8 || cout > 8 || src.ctot0 != 0) return false;
     P2pTrArgs a;
@@ -647,7 +647,7 @@ bool run_p2p_f16x3(const ake_pcnet* n, long long frag_off, const Src& src, const
     a.p = src.p0; a.c0 = src.c0; a.u = src.p1 ? src.p1 : src.p0; a.c1 = src.p1 ? src.c1 : 0; a.h1 = src.h1 > 0 ? src.h1 : 1;
     a.in_aff = in_aff; a.bfrag = n->bf_frags_dev + frag_off; a.bias = bias;
     a.dst = dst; a.dst_clip_stride = clip_stride; a.cout = cout;
-    a.stats = stats; a.stats_stride = stats_stride;
+    a.stats = stats; a.stats_stride = stats_stride; a.in_amax = in_amax;
     static ake::DeviceOnce attr_set;
     if (attr_set.need()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
@@ -723,17 +723,21 @@ bool pc_f16x3_ok(const PackedConv& pt, int T_in, bool same_time) {
 
 // training: NCHW f32 (+ the producer's pending BatchNorm + LeakyReLU) -> f16 hi / lo * 2^11 planes [hi: batch * 12 * T * 16][lo: ...]
 // (src_ctot > 0: src points at the first of C channels inside a tensor of src_ctot channels)
-void run_nchw_to_cl16_f16x2(const float* src, int C, int batch, int T, const float* aff, unsigned short* planes, hipStream_t s, int src_ctot = 0) {
+// amax (data gradients): the bits of the tensor's largest |value|; the planes then hold value * f16_weight_scale(max) and the convolution
+// that reads them (PcBfArgs::in_amax) divides it out again
+void run_nchw_to_cl16_f16x2(const float* src, int C, int batch, int T, const float* aff, unsigned short* planes, hipStream_t s, int src_ctot = 0,
+                            const unsigned int* amax = nullptr) {
     const long long npos = static_cast<long long>(batch) * 12 * T;
     ake::ProfScope ps("nchw_to_cl16_f16x2_kernel", s);
     hipLaunchKernelGGL(nchw_to_cl16_f16x2_kernel, dim3(static_cast<unsigned>((npos + 255) / 256)), dim3(256), 0, s, src, static_cast<long long>(src_ctot > 0 ? src_ctot : C) * 12 * T, C, T,
-                       aff, planes, planes + npos * 16, npos);
+                       aff, planes, planes + npos * 16, npos, amax);
 }
 
 // pitch-class convolution on bf16 MFMA (conv_pc_bf16_kernel): channels-last planes in; planes (cout == 16) or NCHW f32 out
 int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* planes_in, int batch, int T_in, bool same_time, bool lrelu,
                 float* dst_nchw, unsigned short* planes_out, hipStream_t s, const char* name, const PackedConv* pc2 = nullptr,
-                unsigned short* planes_out2 = nullptr, bool f16x3 = false, double* stats = nullptr, int stats_stride = 0) {
+                unsigned short* planes_out2 = nullptr, bool f16x3 = false, double* stats = nullptr, int stats_stride = 0,
+                const unsigned int* in_amax = nullptr) {
     PcBfArgs a;
     std::memset(&a, 0, sizeof(a));
     const long long npos_in = static_cast<long long>(batch) * 12 * T_in;
@@ -754,7 +758,7 @@ int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
         a.bfrag2 = n->bf_frags_dev + pc2->bf_off; a.bias2 = n->blob_dev + pc2->b_off;
         a.oh2 = planes_out2; a.ol2 = planes_out2 + static_cast<long long>(batch) * H_out * a.T_out * pc.cout;
     }
-    a.stats = stats; a.stats_stride = stats_stride;
+    a.stats = stats; a.stats_stride = stats_stride; a.in_amax = in_amax;
     AKE_REQUIRE(!f16x3 || (dst_nchw && !planes_out && !pc2), AKE_ERR_STATE, "conv %s: the f16 x 3 form writes NCHW f32", name);
     const size_t lds = (static_cast<size_t>(2) * 12 * a.Tp * 2 + 2 * 4 * ((pc.cout + 15) / 16) * 2 * 64) * sizeof(uint4);   // patch + weight ring
     AKE_REQUIRE(lds <= 150 * 1024, AKE_ERR_UNSUPPORTED, "conv %s: %d frames do not fit the bf16 kernel's LDS patch", name, T_in);
@@ -784,7 +788,7 @@ int run_pc_bf16(const ake_pcnet* n, const PackedConv& pc, const unsigned short* 
 // f16 x 3 data gradient of a "valid" head convolution (32 -> 16 channels seen from the gradient): full correlation (pad 6 on both sides,
 // T_out = T_dz + 6) of 16 gradient channels (planes) with one half of the transposed + flipped weights; dst [clip][16][12][T_out] (+)=.
 int run_pc_f16x3_full(const ake_pcnet* n, long long frag_off, int kh, const unsigned short* planes, int batch, int T_dz, float* dst, bool accumulate,
-                      hipStream_t s, const char* name) {
+                      hipStream_t s, const char* name, const unsigned int* in_amax = nullptr) {
     PcBfArgs a;
     std::memset(&a, 0, sizeof(a));
     const long long npos_in = static_cast<long long>(batch) * 12 * T_dz;
@@ -794,7 +798,7 @@ int run_pc_f16x3_full(const ake_pcnet* n, long long frag_off, int kh, const unsi
     a.cout = 16; a.lrelu = 0; a.KH = kh; a.circular = kh == 12 ? 1 : 0;
     AKE_REQUIRE(kh == 12 || kh == 1, AKE_ERR_STATE, "conv %s: kernel rows %d", name, kh);
     a.dst = dst; a.dst_clip_stride = static_cast<long long>(16) * 12 * a.T_out; a.cl_stride = 16;
-    a.accumulate = accumulate ? 1 : 0;
+    a.accumulate = accumulate ? 1 : 0; a.in_amax = in_amax;
     const size_t lds = (static_cast<size_t>(2) * 12 * a.Tp * 2 + 2 * 4 * 2 * 64) * sizeof(uint4);
     AKE_REQUIRE(lds <= 150 * 1024, AKE_ERR_UNSUPPORTED, "conv %s: %d frames do not fit the kernel's LDS patch", name, T_dz);
     static ake::DeviceOnce attr_set;
@@ -854,7 +858,7 @@ struct Buffers {           // workspace carve
     std::vector<std::vector<float*>> pst, aff_pst, pcst, aff_pcst;   // [layer][conv]
     std::vector<float*> hst[3], aff_hst[3];                            // [head][hidden conv]
     // backward
-    double* stats2 = nullptr;          // [bn_channels][3]  (sum g1, sum g1*zhat, sum (z - mean))
+    double* stats2 = nullptr;          // [bn_channels][3]  (sum g1, sum g1*zhat, sum (z - mean)); then one 8-byte cell per BatchNorm layer: the bits of max |dz| (dz_amax)
     gfx_t* gslots = nullptr;           // [kGradSlots][grad_floats] partial weight gradients (backward), 64-bit fixed point
     float* wg_partial = nullptr;       // per-workgroup partial weight gradients of one convolution (conv_wgrad_kernel), reduced in order
     size_t wg_partial_floats = 0;
@@ -914,7 +918,7 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
     if (c.genre) { b->hid_g = cv.take<float>(2 * hid); b->map_g = cv.take<float>(B * 12 * b->Tf); }
     if (train) {
         b->stats = cv.take<double>(static_cast<size_t>(n->bn_channels) * 2 * kStatSlots);
-        b->stats2 = cv.take<double>(static_cast<size_t>(n->bn_channels) * 3 * kBwdStatSlots);       // [slot][bn_channels][3]
+        b->stats2 = cv.take<double>(static_cast<size_t>(n->bn_channels) * 3 * kBwdStatSlots + n->bns.size());       // [slot][bn_channels][3], [bn layer] max |dz| bits
         b->gslots = cv.take<gfx_t>(static_cast<size_t>(kGradSlots) * n->grad_floats);
         b->wg_partial_floats = static_cast<size_t>(B) * 98304;                         // 384 KB per clip: e.g. two workgroups per clip x the 43 K weights of a head conv
         b->wg_partial = cv.take<float>(b->wg_partial_floats);
@@ -2641,7 +2645,7 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     AKE_REQUIRE(workspace && ws_bytes >= b.bytes, AKE_ERR_WORKSPACE, "pcnet backward: workspace %zu < %zu bytes", ws_bytes, b.bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
     AKE_HIP_CHECK(hipMemsetAsync(b.gslots, 0, sizeof(gfx_t) * n->grad_floats * kGradSlots, s));
-    AKE_HIP_CHECK(hipMemsetAsync(b.stats2, 0, sizeof(double) * 3 * n->bn_channels * kBwdStatSlots, s));
+    AKE_HIP_CHECK(hipMemsetAsync(b.stats2, 0, sizeof(double) * (static_cast<size_t>(3) * n->bn_channels * kBwdStatSlots + n->bns.size()), s));
     Bwd bw{n, b, s, b.gslots, batch};
     rc = bw.run(mel, seq_length, d_key, d_tonic, d_genre, key_out);
     if (rc) return rc;

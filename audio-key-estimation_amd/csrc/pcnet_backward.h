@@ -15,6 +15,11 @@ struct Bwd {
     gfx_t* grads;        // slot 0 of the workspace's gradient slots ([kGradSlots][grad_floats], fixed point); run() is followed by grad_reduce_kernel
     int B;
     unsigned short* planes_scratch = nullptr;   // f16 hi / lo planes of a 16-channel gradient (set around the pitch-class stacks of layers >= 1)
+    // the tensor bn_block_backward last turned into dz, and the cell that holds the bits of its largest |dz| (the f16 x 3 data gradients
+    // scale dz by a power of two taken from it before the hi / lo split)
+    const float* amax_of = nullptr;
+    const unsigned int* amax_cell = nullptr;
+    const unsigned int* amax_for(const float* dz) const { return dz == amax_of ? amax_cell : nullptr; }
 
     gfx_t* grad_of(const std::string& key) const { return grads + n->grad_off[n->spec_index.at(key)]; }
     const float* raw_of(const std::string& key) const { return n->blob_dev + n->raw_w_off[n->spec_index.at(key)]; }
@@ -38,10 +43,12 @@ struct Bwd {
             hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((l.C + 63) / 64), dim3(64), 0, s, st2, static_cast<long long>(3) * n->bn_channels, bst, n->blob_dev + l.gamma_off, coef,
                                grad_of(bn_name + ".weight"), grad_of(bn_name + ".bias"), l.C);
         }
+        unsigned int* cell = reinterpret_cast<unsigned int*>(b.stats2 + static_cast<size_t>(3) * n->bn_channels * kBwdStatSlots + bn);
         {
             ake::ProfScope ps("bn_bwd_apply_kernel", s);
-            hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, g, z, coef, ctot, coff, HT);
+            hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, g, z, coef, ctot, coff, HT, cell);
         }
+        amax_of = g; amax_cell = cell;
     }
 
     // weight gradient of one convolution: dW += corr(act(input), dz)
@@ -199,15 +206,16 @@ struct Bwd {
         g.T_out = T_in;
         g.H_out = H;
         if (kind == 0 && !accumulate && dst_coff == 0 && dst_ctot == pd.cout && T_dz == T_in &&
-            run_p2p_f16x3(n, pd.bf_off, Src{dz, pd.cin, nullptr, 0, 0}, nullptr, nullptr, B, H, T_dz, dst, pd.cout, nullptr, 0, s, "conv_p2p_f16x3_kernel/p2p_dgrad"))
+            run_p2p_f16x3(n, pd.bf_off, Src{dz, pd.cin, nullptr, 0, 0}, nullptr, nullptr, B, H, T_dz, dst, pd.cout, nullptr, 0, s, "conv_p2p_f16x3_kernel/p2p_dgrad",
+                          amax_for(dz)))
             return AKE_OK;
         // pitch-class stacks of layers >= 1 (same-size 12 x 7 convolutions, 16 gradient channels): the f16 x 3 form of conv_pc_bf16_kernel with
         // the transposed + flipped weights (f32-equivalent products; the f32 MFMA kernel took 0.17 ms per convolution and 256 clips)
         if (kind == 1 && same_time && planes_scratch && !accumulate && dst_coff == 0 && dst_ctot == pd.cout && T_dz == T_in && H == 12 &&
             pc_f16x3_ok(pd, T_dz, true)) {
-            run_nchw_to_cl16_f16x2(dz, pd.cin, B, T_dz, nullptr, planes_scratch, s);
+            run_nchw_to_cl16_f16x2(dz, pd.cin, B, T_dz, nullptr, planes_scratch, s, 0, amax_for(dz));
             return run_pc_bf16(n, pd, planes_scratch, B, T_dz, true, false, dst, nullptr, s, "conv_pc_f16x3_kernel/pc2pc_dgrad", nullptr, nullptr, true,
-                               nullptr, 0);
+                               nullptr, 0, amax_for(dz));
         }
         // the heads' first convolutions (16 features -> 32 channels, "valid" in time): 32 gradient channels as two 16-channel halves on the same
         // kernel, full correlation, the second half (and every head after the first) adding to the feature gradient
@@ -217,8 +225,9 @@ struct Bwd {
             int rc2;
             for (int hf = 0; hf < 2; ++hf) {
                 unsigned short* pl = planes_scratch + hf * half;
-                run_nchw_to_cl16_f16x2(dz + static_cast<long long>(hf) * 16 * 12 * T_dz, 16, B, T_dz, nullptr, pl, s, 32);
-                if ((rc2 = run_pc_f16x3_full(n, hf ? pd.bf_off2 : pd.bf_off, fwd.kh, pl, B, T_dz, dst, accumulate || hf == 1, s, "conv_pc_f16x3_kernel/head_dgrad")))
+                run_nchw_to_cl16_f16x2(dz + static_cast<long long>(hf) * 16 * 12 * T_dz, 16, B, T_dz, nullptr, pl, s, 32, amax_for(dz));
+                if ((rc2 = run_pc_f16x3_full(n, hf ? pd.bf_off2 : pd.bf_off, fwd.kh, pl, B, T_dz, dst, accumulate || hf == 1, s, "conv_pc_f16x3_kernel/head_dgrad",
+                                             amax_for(dz))))
                     return rc2;
             }
             return AKE_OK;

@@ -209,13 +209,17 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ stats2, long long 
     grad_add(d_beta + c, static_cast<float>(S1));
 }
 
-// dz = c0*g1 + c1*(z - mean) + c2 in place on g; same layout / grid as act_bwd_stats_kernel
+// dz = c0*g1 + c1*(z - mean) + c2 in place on g; same layout / grid as act_bwd_stats_kernel.
+// amax (nullable): the bits of the largest |dz| of the whole tensor (atomicMax on the bit pattern of a non-negative float: order-independent,
+// so the step stays bit-reproducible).  The f16 x 3 data-gradient kernels that read this dz scale it by a power of two taken from it before
+// the hi / lo split (at 256 clips x 76 frames most dz are 1e-6..1e-9, f16's subnormal range).
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ z,
-                                                           const float* __restrict__ coef, int ctot, int coff, int HT) {
+                                                           const float* __restrict__ coef, int ctot, int coff, int HT, unsigned int* __restrict__ amax) {
     const int c = blockIdx.x, clip = blockIdx.y;
     const long long base = (static_cast<long long>(clip) * ctot + coff + c) * HT;
     const float c0 = coef[4 * c], c1 = coef[4 * c + 1], c2 = coef[4 * c + 2], mu = coef[4 * c + 3];
     const bool vec = (HT & 3) == 0 && (base & 3) == 0 && ((reinterpret_cast<unsigned long long>(g) | reinterpret_cast<unsigned long long>(z)) & 15) == 0;
+    float m = 0.f;
     if (vec) {
         float4* g4 = reinterpret_cast<float4*>(g + base);
         const float4* z4 = reinterpret_cast<const float4*>(z + base);
@@ -224,11 +228,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
             const float4 zv = z4[i];
             gv.x = fmaf(gv.x, c0, fmaf(zv.x - mu, c1, c2)); gv.y = fmaf(gv.y, c0, fmaf(zv.y - mu, c1, c2));
             gv.z = fmaf(gv.z, c0, fmaf(zv.z - mu, c1, c2)); gv.w = fmaf(gv.w, c0, fmaf(zv.w - mu, c1, c2));
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(gv.x), fabsf(gv.y))), fmaxf(fabsf(gv.z), fabsf(gv.w)));
             g4[i] = gv;
         }
-        return;
+    } else {
+        for (int i = threadIdx.x; i < HT; i += 256) {
+            const float v = fmaf(g[base + i], c0, fmaf(z[base + i] - mu, c1, c2));
+            m = fmaxf(m, fabsf(v));
+            g[base + i] = v;
+        }
     }
-    for (int i = threadIdx.x; i < HT; i += 256) g[base + i] = fmaf(g[base + i], c0, fmaf(z[base + i] - mu, c1, c2));
+    if (!amax) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f && m < INFINITY) atomicMax(amax, __float_as_uint(m));
 }
 
 // sum over (clip, positions) of one channel slice -> bias gradient of a convolution without BatchNorm

@@ -1190,6 +1190,7 @@ struct P2pTrArgs {
     double* stats;                // [kStatSlots][stats_stride]: (sum, sum of squares) of channel c at 2c, 2c + 1 (fixed point), or null
     int stats_stride;
     int H, T, R, J, Tp, n_row_tiles, n_tiles, plane_pos;
+    const unsigned int* in_amax;  // data gradient (in_aff == null): bits of the largest |dz|; dz is staged times f16_weight_scale(max), divided out in the epilogue
 };
 
 __global__ __launch_bounds__(512) void conv_p2p_f16x3_kernel(P2pTrArgs a) {
@@ -1239,6 +1240,11 @@ __global__ __launch_bounds__(512) void conv_p2p_f16x3_kernel(P2pTrArgs a) {
         const bool on = a.in_aff != nullptr && c < ctot;
         asc[c] = on ? a.in_aff[3 * c] : 1.f; ash[c] = on ? a.in_aff[3 * c + 1] : 0.f; ang[c] = on ? a.in_aff[3 * c + 2] : 1.f;
     }
+    const float in_mul = (a.in_amax && !a.in_aff) ? f16_weight_scale(__uint_as_float(*a.in_amax)) : 1.f;
+    if (in_mul != 1.f) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c) asc[c] = in_mul;
+    }
     auto write_lds = [&](int buf) {
         uint4* const wH = lds4 + (2 * buf) * a.plane_pos;
         uint4* const wL = wH + a.plane_pos;
@@ -1277,7 +1283,7 @@ __global__ __launch_bounds__(512) void conv_p2p_f16x3_kernel(P2pTrArgs a) {
     }
     const int tau = r16 >> 3, co = r16 & 7;
     const float bias = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
-    const float iscale = reinterpret_cast<const float*>(a.bfrag + kP2pFragScale)[co];
+    const float iscale = reinterpret_cast<const float*>(a.bfrag + kP2pFragScale)[co] / in_mul;
     uint4* const stage = lds4 + 4 * a.plane_pos + wave * (MT * kP2pPsStage);
     typedef float f32x4c __attribute__((ext_vector_type(4)));
     long long prev_base = 0;
@@ -1391,6 +1397,7 @@ struct PcBfArgs {
     double* stats;
     int stats_stride;
     int accumulate;               // F16X3, NCHW output: dst += (a data gradient that arrives in two 16-channel halves, or from several heads)
+    const unsigned int* in_amax;  // F16X3 data gradients: the input planes hold value * f16_weight_scale(*in_amax) (nchw_to_cl16_f16x2_kernel); or null
 };
 
 // F16X3 (training mode; forward with BatchNorm-on-load planes and the data gradients): the planes and fragments hold f16 hi and
@@ -1525,7 +1532,8 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
         const int co = nt * 16 + r16;
         const float* const bptr = second ? a.bias2 : a.bias;
         const float bias = (co < a.cout && bptr) ? bptr[co] : 0.f;
-        const float iscale = (F16X3 && co < a.cout) ? reinterpret_cast<const float*>(bfr + a.KH * 4 * NT * 2 * 64)[co] : 1.f;
+        float iscale = (F16X3 && co < a.cout) ? reinterpret_cast<const float*>(bfr + a.KH * 4 * NT * 2 * 64)[co] : 1.f;
+        if (F16X3 && a.in_amax) iscale /= f16_weight_scale(__uint_as_float(*a.in_amax));        // (powers of two: exact)
         float st1 = 0.f, st2 = 0.f;
         unsigned short* const oh = second ? a.oh2 : a.oh;
         unsigned short* const ol = second ? a.ol2 : a.ol;
@@ -1953,10 +1961,14 @@ __global__ void nchw_to_cl16_kernel(const float* __restrict__ src, long long src
 
 // training: NCHW f32 [clip][C][12][T] (C <= 16), with the pending BatchNorm + LeakyReLU of its producer applied (aff: [C][3] scale, shift,
 // negative slope; or null) -> channels-last planes [clip][12][T][16] of f16 hi and f16 lo * 2^11 (conv_pc_bf16_kernel<.., F16X3>)
+// amax (nullable, data gradients): bits of the tensor's largest |value|; every value is multiplied by f16_weight_scale(max) (a power of two:
+// exact) so that gradients of 1e-6..1e-9 use f16's normal range; the reading convolution divides it out (PcBfArgs::in_amax).
 __global__ void nchw_to_cl16_f16x2_kernel(const float* __restrict__ src, long long src_clip_stride, int C, int T, const float* __restrict__ aff,
-                                          unsigned short* __restrict__ xh, unsigned short* __restrict__ xl, long long npos) {
+                                          unsigned short* __restrict__ xh, unsigned short* __restrict__ xl, long long npos,
+                                          const unsigned int* __restrict__ amax) {
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;      // (clip, row, t)
     if (i >= npos) return;
+    const float mul = amax ? f16_weight_scale(__uint_as_float(*amax)) : 1.f;
     const int t = static_cast<int>(i % T);
     const long long r = i / T;
     const int y = static_cast<int>(r % 12);
@@ -1969,7 +1981,7 @@ __global__ void nchw_to_cl16_f16x2_kernel(const float* __restrict__ src, long lo
     for (int c = 0; c < 16; ++c) {
         float v = 0.f;
         if (c < C) {
-            v = s[static_cast<long long>(c) * 12 * T];
+            v = s[static_cast<long long>(c) * 12 * T] * mul;
             if (aff) { v = fmaf(v, aff[3 * c], aff[3 * c + 1]); v = v > 0.f ? v : v * aff[3 * c + 2]; }
         }
         const _Float16 h = static_cast<_Float16>(v);

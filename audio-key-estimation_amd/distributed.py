@@ -12,12 +12,25 @@ import torch
 import torch.distributed as dist
 
 
+def _forced() -> bool:
+    """AKE_FORCE_PROCESS_GROUP=1: build the process group and run every collective even with ONE rank.  A one-rank RCCL communicator
+    still goes through communicator init, the dtype / bucket checks, ProcessGroupNCCL's stream + event ordering and a real
+    ncclAllReduce / ncclBroadcast / ncclAllGather launch -- the only way to exercise the `nccl` branches on a one-GPU box
+    (tests/test_gpu_rccl.py).  A failure raises: there is no fallback to gloo or to skipping the collective."""
+    return os.environ.get("AKE_FORCE_PROCESS_GROUP", "0") == "1"
+
+
+def _active() -> bool:
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _forced())
+
+
 def init_from_env(backend: str | None = None):
-    """(rank, world, local_rank); initialises the default group when launched under torch.distributed.run."""
+    """(rank, world, local_rank); initialises the default group when launched under torch.distributed.run (or, with
+    AKE_FORCE_PROCESS_GROUP=1, also for a single rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -37,7 +50,7 @@ def shard_range(n_items: int, rank: int, world: int):
 
 def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor | None:
     """Concatenate each rank's (rows_r, C) block in rank order; every rank gets the (n_total, C) result."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return local
     world = dist.get_world_size()
     sizes = [shard_range(n_total, r, world) for r in range(world)]
@@ -50,7 +63,7 @@ def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor | None:
 
 
 def max_over_ranks(value: float, device=None) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -58,7 +71,7 @@ def max_over_ranks(value: float, device=None) -> float:
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()
 
 
@@ -66,7 +79,7 @@ def barrier():
 
 def broadcast_parameters(net, src: int = 0):
     """Identical weights on every rank by construction: rank ``src``'s float state (one flat buffer on the device) wins."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return
     if next(net.parameters()).device.type == "cuda":
         flat, _ = net.flat_parameters()
@@ -96,10 +109,13 @@ def _all_reduce_sum(t: torch.Tensor):
 def all_reduce_gradients(net) -> float:
     """SUM the gradients over the ranks and return the factor that turns the sum into the mean (1/world).
 
-    With the parameters in the module's flat device buffer this is ONE collective on ONE 668 KB bucket (default net),
-    issued on the compute stream right after the last weight-gradient kernel -- at that size the ring is latency-bound, so
-    fewer calls beat overlap.  BatchNorm stays local to each rank (torch DDP's default), see DESIGN.md."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    With the parameters in the module's flat device buffer this is ONE collective on ONE 668 KB bucket (default net), called
+    right after the last weight-gradient kernel was enqueued.  torch's ProcessGroupNCCL runs it on its OWN stream: it records an
+    event on the caller's current stream, makes the collective stream wait for it, and (synchronous op) makes the current stream
+    wait for the collective's end event before returning -- so the Adam kernel enqueued next on the compute stream sees the reduced
+    buffer without any host synchronisation.  At 668 KB the ring is latency-bound, so one call beats bucketing / overlap.
+    BatchNorm stays local to each rank (torch DDP's default), see DESIGN.md."""
+    if not _active():
         return 1.0
     world = dist.get_world_size()
     if getattr(net, "_attached", False) and net._grads_in_place():

@@ -52,7 +52,8 @@ T_FRAMES = 1 + N_SAMPLES // HOP           # 76
 P = 36 * OCTAVES
 # SURVEY.md section 8d / DESIGN.md "Measurement"
 CQT_BYTES_PER_CLIP = N_SAMPLES * 4 + P * T_FRAMES * 4                  # 1 410 552
-P2P_MACS_PER_CLIP = (5 * 8 + 8 * 8 + 8 * 8) * 49 * P * T_FRAMES        # 180 166 656 (three 7x7 convs: 5->8, 8->8, 8->8)
+P2P_MACS_PER_CLIP = (5 * 8 + 8 * 8 + 8 * 8) * 49 * P * T_FRAMES        # 180 182 016 (three 7x7 convs: 5->8, 8->8, 8->8)
+assert P2P_MACS_PER_CLIP == 180_182_016
 PEAK_BF16_TFLOPS = 2500.0
 NET_MACS_PER_CLIP = 277_395_712
 PEAK_FP32_TFLOPS = 157.3
@@ -224,6 +225,9 @@ def train_main(args):
     optim = net.configure_optimizers()[0][0]
     net.train()
     net.trainer = ake_amd.Trainer(accumulate_grad_batches=1)
+    parity = None
+    if not args.no_parity:
+        parity = train_parity(net, sd, batch, rank)                     # step 0, outside the timed region (weights untouched: no optimizer step)
 
     def step(i):
         optim.zero_grad()
@@ -266,8 +270,55 @@ def train_main(args):
         "config": {"workload": f"BASELINE configs[3]: {B} clips per GPU (288x76 log-CQT resident), default PitchClassNet, local BatchNorm, "
                                f"one all-reduce of the flat gradient buffer per step, fused Adam lr 3e-4",
                    "clips_per_gpu": B, "parallelism": f"data-parallel x{world}", "spinup_steps": n_spin},
-        "train_fp32_frac_of_peak": round(3 * 2.0 * NET_MACS_PER_CLIP * value / world / (PEAK_FP32_TFLOPS * 1e12), 4),
+        # fwd + data gradient + weight gradient = 3 x the forward's MACs, algorithmic, against the dense f16 / bf16 MFMA peak the kernels
+        # multiply on (NOT the 157 TF f32 peak: VERDICT r2 item 7); every algorithmic MAC costs 3 MFMA products in these kernel families
+        # (f16 hi + lo x 3, split bf16 x 3), so the matrix pipe's own ceiling for this formulation is a third of the peak
+        "train_algorithmic_tflops": round(3 * 2.0 * NET_MACS_PER_CLIP * value / world / 1e12, 2),
+        "train_frac_of_mfma_peak": round(3 * 2.0 * NET_MACS_PER_CLIP * value / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+        "mfma_products_per_mac": 3,
+        "collective_backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
+        "parity": parity,
         "kernel_ms_per_step": kernel_ms}))
+
+
+def train_parity(net, sd, batch, rank):
+    """Step-0 check of the training line, outside the timed region: the train-mode forward's three outputs and the
+    general_step loss of THIS rank-0 batch against the float64 oracle forward (batch statistics) + the numpy loss restatement, and a
+    gradient sanity (finite, non-zero, the same bits when the step is repeated).  Asserted: outputs 2e-4, loss 2e-5."""
+    from oracle import loss_oracle, pcnet_oracle
+    for p in net.parameters():
+        p.grad = None
+    d = net.training_step(batch, 0)
+    d["loss"].backward()
+    g1 = torch.cat([p.grad.detach().flatten() for p in net.parameters()]).clone()
+    for p in net.parameters():
+        p.grad = None
+    net.training_step(batch, 0)["loss"].backward()
+    g2 = torch.cat([p.grad.detach().flatten() for p in net.parameters()])
+    with torch.no_grad():
+        out = net(batch["mel"], batch["seq_length"])
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0, "training step: gradients are not finite / all zero"
+    assert torch.equal(g1, g2), "training step: two backward passes of the same batch differ (the step must be bit-reproducible)"
+    if rank != 0:
+        return None
+    t0 = time.perf_counter()
+    sd64 = pcnet_oracle.to_dtype(sd, torch.float64)
+    with torch.no_grad():
+        ref = pcnet_oracle.pcnet_forward(sd64, batch["mel"].double().cpu(), batch["seq_length"].cpu(), training=True)
+    loss_ref = loss_oracle.general_step_loss(ref[0].numpy(), ref[1].numpy(), ref[2].numpy(), batch["key_labels"].cpu().numpy(),
+                                             batch["tonic_labels"].cpu().numpy(), batch["genre"].cpu().numpy())
+    errs = {n: float((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-6)) for n, a, b in zip(("key", "tonic", "genre"), out, ref)}
+    loss = float(d["loss"].detach())
+    res = {"max_rel_err": round(max(errs.values()), 8), "per_output": {k: round(v, 8) for k, v in errs.items()}, "tolerance": 2e-4,
+           "loss": round(loss, 7), "loss_oracle": round(loss_ref, 7), "loss_rel_err": round(abs(loss - loss_ref) / max(1.0, abs(loss_ref)), 9),
+           "grad_abs_max": float(g1.abs().max()), "backward_bit_reproducible": True, "clips": int(batch["mel"].shape[0]),
+           "oracle_seconds": round(time.perf_counter() - t0, 1),
+           "against": "float64 oracle forward in train mode (batch statistics; pinned on the reference) + numpy restatement of general_step's loss, "
+                      "the whole rank-0 batch at step 0, outside the timed region; gradients at this batch size vs float64 autograd: "
+                      "tests/test_gpu_train_scale.py"}
+    assert res["max_rel_err"] < 2e-4 and res["loss_rel_err"] < 2e-5, f"training parity vs the oracle: {res}"
+    return res
 
 
 def parity_and_mirex(rows, audio_last, first_clip, world, B):
