@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libake_hip.so")
+if os.environ.get("AKE_USE_DIAG_LIB") == "1":      # kernel experiments only (tools/, tests/tools/): the -DAKE_DIAG build, `AKE_DIAG=1 csrc/build.sh`
+    LIB_PATH = os.path.join(_HERE, "libake_hip_diag.so")
 
 AKE_OK = 0
 
@@ -25,7 +27,7 @@ class CqtConfig(C.Structure):
 class PcnetConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("pitches", "pitch_classes", "num_layers", "kernel_size", "conv_layers", "n_filters",
                                        "head_layers", "time_pool_size", "genre", "max_pool", "resblock", "denseblock",
-                                       "stay_sixth", "only_semitones", "p2pc_conv", "pc2p_mem", "local")]
+                                       "stay_sixth", "only_semitones", "p2pc_conv", "pc2p_mem", "local", "precision")]
 
 
 # name -> (restype, argtypes); every symbol include/ake_hip.h declares
@@ -33,6 +35,8 @@ _P, _I, _I64, _SZ, _F = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.POINTER(C.
 SYMBOLS = {
     "ake_version": (_I, []),
     "ake_last_error": (C.c_char_p, []),
+    "ake_build_has_diag": (_I, []),
+    "ake_pcnet_precision": (_I, [_P]),
     "ake_cqt_default_config": (_I, [C.POINTER(CqtConfig), _I, _I, _I]),
     "ake_cqt_plan_create": (_I, [C.POINTER(CqtConfig), C.POINTER(_P)]),
     "ake_cqt_plan_destroy": (None, [_P]),

@@ -5,11 +5,15 @@ cd "$(dirname "$0")"
 OUT=../libake_hip.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
-mkdir -p build
+# AKE_DIAG=1: the diagnostic build (-DAKE_DIAG: the AKE_* environment switches of the kernel experiments exist, common.h) -> libake_hip_diag.so,
+# loaded instead of the shipped library only when AKE_USE_DIAG_LIB=1 is set for the Python process (tools/, tests/tools/).
+BUILD=build
+if [ "${AKE_DIAG:-0}" = 1 ]; then FLAGS="$FLAGS -DAKE_DIAG=1"; OUT=../libake_hip_diag.so; BUILD=build_diag; fi
+mkdir -p $BUILD
 HEADERS="common.h cqt_fused.h pcnet_kernels.h pcnet_bwd_kernels.h pcnet_backward.h ../../include/ake_hip.h"
 pids=()
 for f in common.cpp cqt.hip pcnet.hip pipeline.hip optim.hip audio.hip loss.hip; do
-  obj=build/${f%.*}.o
+  obj=$BUILD/${f%.*}.o
   stale=0
   [ -f "$obj" ] || stale=1
   for d in "$f" $HEADERS; do [ "$d" -nt "$obj" ] && stale=1; done
@@ -23,5 +27,5 @@ for f in common.cpp cqt.hip pcnet.hip pipeline.hip optim.hip audio.hip loss.hip;
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC build/common.o build/cqt.o build/pcnet.o build/pipeline.o build/optim.o build/audio.o build/loss.o -o $OUT
+$HIPCC --offload-arch=gfx950 -shared -fPIC $BUILD/common.o $BUILD/cqt.o $BUILD/pcnet.o $BUILD/pipeline.o $BUILD/optim.o $BUILD/audio.o $BUILD/loss.o -o $OUT
 echo "built $(realpath $OUT)"

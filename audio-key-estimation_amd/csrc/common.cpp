@@ -79,7 +79,14 @@ using namespace ake;
 
 extern "C" {
 
-int ake_version(void) { return 100; }
+int ake_version(void) { return 101; }
+int ake_build_has_diag(void) {
+#ifdef AKE_DIAG
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 const char* ake_last_error(void) { return g_err; }
 

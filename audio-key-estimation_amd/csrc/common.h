@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -16,6 +17,16 @@
 namespace ake {
 
 void set_error(const char* fmt, ...);
+
+// Diagnostic switches (kernel A/B selection, phase ablation "timing only, wrong results", in-kernel cycle stamps, debug prints) are read
+// from AKE_* environment variables ONLY in a diagnostic build (`AKE_DIAG=1 csrc/build.sh` -> -DAKE_DIAG).  The shipped library never looks
+// at the environment: an inherited variable cannot change the results or the precision of a drop-in library;
+// precision is part of the API (ake_pcnet_config::precision), the CQT engine of ake_cqt_config.  ake_build_has_diag() tells which one is loaded.
+#ifdef AKE_DIAG
+inline const char* diag_env(const char* name) { return std::getenv(name); }
+#else
+inline const char* diag_env(const char*) { return nullptr; }
+#endif
 
 #define AKE_HIP_CHECK(expr)                                                                  \
     do {                                                                                     \

@@ -852,7 +852,7 @@ int ake_cqt_plan_create(const ake_cqt_config* cfg_in, ake_cqt_plan** out) {
     // ---- engine ----
     {
         int want = cfg.engine;
-        if (const char* e = std::getenv("AKE_CQT_ENGINE")) want = std::atoi(e);
+        if (const char* e = ake::diag_env("AKE_CQT_ENGINE")) want = std::atoi(e);
         const bool can_fuse = p->half_len <= 23;
         const bool can_bf16 = can_fuse && n_oct >= 2 && n_oct - 1 <= kCascMax;
         if (want == 3 && !can_bf16) { ake::set_error("cqt: engine 3 needs 2..%d octaves and decim_half_len <= 23", kCascMax + 1); ake_cqt_plan_destroy(p); return AKE_ERR_UNSUPPORTED; }
@@ -1177,7 +1177,7 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
         a.g0 = -512;
         const long long g1 = n_in + static_cast<long long>(25 + kLagHost[fused]) * (1ll << fused) + 512;
         a.ticks_total = static_cast<int>((g1 - a.g0 + C - 1) / C);
-        static const int segs_env = std::getenv("AKE_CQT_SEGS") ? std::atoi(std::getenv("AKE_CQT_SEGS")) : 0;
+        static const int segs_env = ake::diag_env("AKE_CQT_SEGS") ? std::atoi(ake::diag_env("AKE_CQT_SEGS")) : 0;
         const int segs = std::max(1, std::min(a.ticks_total, segs_env > 0 ? segs_env : 4));
         a.ticks_per_seg = (a.ticks_total + segs - 1) / segs;
         a.warm = 3;                                         // >= 64 * 2^7 / C ticks of history before the first owned tick
@@ -1190,7 +1190,7 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
         if (p->half_len == 15 && split) hipLaunchKernelGGL((cqt_cascade_kernel<8, C, NT, true>), grid, dim3(NT), 0, stream, a);
         else if (p->half_len == 15) hipLaunchKernelGGL((cqt_cascade_kernel<8, C, NT, false>), grid, dim3(NT), 0, stream, a);
         else if (split) {
-            static const bool stamp_env = std::getenv("AKE_CQT_CASC_STAMP") != nullptr;
+            static const bool stamp_env = ake::diag_env("AKE_CQT_CASC_STAMP") != nullptr;
             unsigned long long* sb = nullptr;
             if (stamp_env && a.n_stage == 7 && hipMalloc(&sb, 64 * sizeof(unsigned long long)) == hipSuccess) {
                 CascArgs a2 = a;
@@ -1231,7 +1231,7 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
             a.n_clip = reinterpret_cast<const long long*>(n_clip);
             a.out = scratch; a.out_clip_stride = static_cast<long long>(T) * p->cfg.n_bins; a.n_bins_total = p->cfg.n_bins;
             a.table = p->table4_dev; a.toep = p->toep_dev;
-            if (const char* e = std::getenv("AKE_CQT_FZ_DBG")) a.dbg = std::atoi(e);
+            if (const char* e = ake::diag_env("AKE_CQT_FZ_DBG")) a.dbg = std::atoi(e);
             a.x = audio; a.x_stride = audio_stride; a.n_valid = n; a.pad_in = 0;
             AKE_REQUIRE(static_cast<unsigned long long>(batch) * audio_stride * 4 < 0xFFF00000ull, AKE_ERR_UNSUPPORTED,
                         "cqt engine 4: the audio tensor must stay below 4 GiB per call (%d clips x %lld samples): split the batch", batch,
@@ -1272,7 +1272,7 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
             const int n_wg = n_groups * a.n_seg;
             dim3 grid((n_wg + 7) / 8 * 8);
             ake::ProfScope ps("cqt_fused_kernel", stream);
-            static const bool stamp_env = std::getenv("AKE_CQT_FZ_STAMP") != nullptr;
+            static const bool stamp_env = ake::diag_env("AKE_CQT_FZ_STAMP") != nullptr;
             if (deep && stamp_env) {
                 // diagnostic build: in-kernel cycle stamps of the step loop's sections (workgroup 0), printed to stderr; never timed
                 unsigned long long* sb = nullptr;

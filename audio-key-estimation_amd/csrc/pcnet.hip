@@ -403,7 +403,7 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
     a.residual = residual; a.residual_clip_stride = static_cast<long long>(pc.cout) * a.H_out * a.T_out;      // dense [B][cout][H][T]
     Tile t;
     MTile mtile;
-    static const int mt_env = std::getenv("AKE_MT") ? std::atoi(std::getenv("AKE_MT")) : 3;
+    static const int mt_env = ake::diag_env("AKE_MT") ? std::atoi(ake::diag_env("AKE_MT")) : 3;
     const int MT = (pc.ku == 8 && pc.nt == 1 && kind == 0) ? mt_env : 3;
     const int cout_tiles = std::max(1, pc.ntiles / pc.nt);
     const int want_tiles = (std::max(device_cus(), 1) + batch * cout_tiles - 1) / (batch * cout_tiles);      // 1 at the bench / training batch sizes
@@ -416,7 +416,7 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
     ma.row_k = pc.row_k;
     ma.ksplit = 0;
     ma.h1_magic = (65536 + a.h1 - 1) / a.h1;
-    static const int ablate = std::getenv("AKE_ABLATE") ? std::atoi(std::getenv("AKE_ABLATE")) : 0;
+    static const int ablate = ake::diag_env("AKE_ABLATE") ? std::atoi(ake::diag_env("AKE_ABLATE")) : 0;
     ma.dbg = ablate;
     if (mtile.W == 1 && pc.cin * pc.kh >= 16) {   // tiny M (1-channel head convs): split the (channel, dy) steps over 8 waves instead
         ma.ksplit = 1;
@@ -424,7 +424,7 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
         t.threads = 8 * 64;
         t.lds = std::max<size_t>(t.lds, static_cast<size_t>(8) * MT * pc.nt * 64 * sizeof(float) * 4);
     }
-    static const bool debug = std::getenv("AKE_DEBUG") != nullptr;
+    static const bool debug = ake::diag_env("AKE_DEBUG") != nullptr;
     if (debug)
         fprintf(stderr, "[ake] %-28s cin=%3d cout=%3d kh=%2d TB=%2d KU=%2d NT=%d | R=%2d TT=%3d Tp=%3d tiles=%dx%d waves=%d chunk=%d lds=%zu grid=(%d,%d,%d)\n",
                 name, pc.cin, pc.cout, pc.kh, pc.tb, pc.ku, pc.nt, t.R, t.TT, t.Tp, t.n_row_tiles, t.n_time_tiles, mtile.W,
@@ -437,9 +437,9 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
 // does inference run layer i's Pitch2Pitch stack on the bf16 kernel (everything but its first conv)?
 // (the bf16 kernels keep all frames of their row tile in one LDS patch: long clips fall back to the time-tiled f32 kernel)
 bool p2p_uses_f16(const ake_pcnet* n, int i, int T) {
-    static const bool f32_only = std::getenv("AKE_P2P_F32") != nullptr;
+    static const bool f32_only = ake::diag_env("AKE_P2P_F32") != nullptr;
     const auto& c = n->cfg;
-    if (f32_only || c.resblock || i < 1 || c.conv_layers < 2 || n->dims[i].out_p != 8 || T > 146) return false;
+    if (f32_only || c.precision == AKE_PRECISION_F32X3 || c.resblock || i < 1 || c.conv_layers < 2 || n->dims[i].out_p != 8 || T > 146) return false;
     for (int j = 0; j < c.conv_layers; ++j)
         if (n->p2p[i][j].bf_off < 0) return false;
     return true;
@@ -448,7 +448,7 @@ bool p2p_uses_f16(const ake_pcnet* n, int i, int T) {
 // does inference run layer i's PitchClass2PitchClass stack on conv_pc_bf16_kernel?
 constexpr int kPcBf16MaxFrames = 120;
 bool pc2pc_uses_bf16(const ake_pcnet* n, int i, int T) {
-    static const bool f32_only = std::getenv("AKE_PC_F32") != nullptr;
+    static const bool f32_only = ake::diag_env("AKE_PC_F32") != nullptr;
     if (f32_only || n->cfg.resblock || n->pc2pc[i].empty() || T > kPcBf16MaxFrames) return false;
     for (const PackedConv& pc : n->pc2pc[i])
         if (pc.bf_off < 0 || pc.cout != 16) return false;
@@ -527,7 +527,7 @@ int p2p_ps_rows(int H, int T, bool semi, int* plane_pos, size_t* lds) {
 // does inference fuse the semitone conv of layer i into the last pitch conv of its stack (the pitch tensor is then never written)?
 // Only in the net's last layer: an inner layer's pitch tensor is also the next layer's pitch stream (time_pool_p, models.py:395).
 bool p2p_fuses_semi(const ake_pcnet* n, int i, int P, int T) {
-    static const bool off = std::getenv("AKE_P2P_PS") != nullptr && std::atoi(std::getenv("AKE_P2P_PS")) == 0;
+    static const bool off = ake::diag_env("AKE_P2P_PS") != nullptr && std::atoi(ake::diag_env("AKE_P2P_PS")) == 0;
     return !off && !g_keep_taps && !n->cfg.p2pc_conv && !n->cfg.stay_sixth && i == n->cfg.num_layers - 1 && p2p_uses_f16(n, i, T) && static_cast<size_t>(i) < n->semi.size() && n->semi[i].bf_off >= 0 &&
            p2p_ps_rows(P, T, true, nullptr, nullptr) > 0;
 }
@@ -542,7 +542,7 @@ bool p2p_fuses_semi(const ake_pcnet* n, int i, int P, int T) {
 bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const Src* nchw, int batch, int H, int T, float* dst_nchw,
                      int dst_ctot, unsigned short* oh, const PackedConv* semi_pc, hipStream_t s, const char* name, bool p_frames_major = false,
                      bool dry_run = false, int fold_coff = -1) {
-    static const bool off = std::getenv("AKE_P2P_PS") != nullptr && std::atoi(std::getenv("AKE_P2P_PS")) == 0;
+    static const bool off = ake::diag_env("AKE_P2P_PS") != nullptr && std::atoi(ake::diag_env("AKE_P2P_PS")) == 0;
     if (off) return false;
     P2pPsArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -565,7 +565,7 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
     a.H = H; a.T = T; a.J = T / 2; a.Tp = p2p_pitch(a.J);
     a.n_row_tiles = (H + a.R - 1) / a.R;
     a.n_tiles = a.n_row_tiles * batch;
-    static const bool fold_off = std::getenv("AKE_P2P_FOLD") != nullptr && std::atoi(std::getenv("AKE_P2P_FOLD")) == 0;
+    static const bool fold_off = ake::diag_env("AKE_P2P_FOLD") != nullptr && std::atoi(ake::diag_env("AKE_P2P_FOLD")) == 0;
     const bool fold = fold_coff >= 0;
     if (fold && fold_off) return false;
     if (fold) {
@@ -592,7 +592,7 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
     // two workgroups per CU when the LDS allows it (the kernel is built for 4 waves per SIMD): one's epilogue (vector work) and
     // barrier waits run under the other's multiply loop (bound by its LDS reads)
     if (dry_run) return true;                          // (the eligibility question of ake_pcnet_accepts_frames_major)
-    static const int wg_per_cu_env = std::getenv("AKE_P2P_WG_PER_CU") ? std::atoi(std::getenv("AKE_P2P_WG_PER_CU")) : 2;
+    static const int wg_per_cu_env = ake::diag_env("AKE_P2P_WG_PER_CU") ? std::atoi(ake::diag_env("AKE_P2P_WG_PER_CU")) : 2;
     const int wg_per_cu = (wg_per_cu_env >= 2 && !nchw && lds <= 80 * 1024 && a.n_tiles >= 4 * n_cus) ? 2 : 1;
     dim3 grid(std::min(wg_per_cu * (n_cus / 8 * 8), (a.n_tiles + 7) / 8 * 8)), block(512);
     ake::ProfScope ps(name, s);
@@ -602,7 +602,7 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
     else if (nchw && a.c0 + a.c1 <= 5) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<1, 5>), grid, block, lds, s, a);
     else if (nchw) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<1, 8>), grid, block, lds, s, a);
     else {
-        static const bool stamp_env = std::getenv("AKE_P2P_STAMP") != nullptr;
+        static const bool stamp_env = ake::diag_env("AKE_P2P_STAMP") != nullptr;
         unsigned long long* sb = nullptr;
         if (stamp_env && hipMalloc(&sb, 64 * sizeof(unsigned long long)) == hipSuccess) {
             // diagnostic build: in-kernel cycle stamps of the tile loop's sections (workgroup 0), printed to stderr; never timed
@@ -626,7 +626,7 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
 // and data gradient (none of them).  false when the shape does not qualify: the caller then runs conv_mfma_kernel.
 bool run_p2p_f16x3(const ake_pcnet* n, long long frag_off, const Src& src, const float* in_aff, const float* bias, int batch, int H, int T, float* dst,
                    int cout, double* stats, int stats_stride, hipStream_t s, const char* name, const unsigned int* in_amax = nullptr) {
-    static const bool off = std::getenv("AKE_P2P_TRAIN_F32") != nullptr;
+    static const bool off = ake::diag_env("AKE_P2P_TRAIN_F32") != nullptr;
     if (off || frag_off < 0 || T < 2 || (T & 1) || src.c0 < 1 || src.c0 + src.c1 > 8 || cout > 8 || src.ctot0 != 0) return false;
     P2pTrArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -668,7 +668,7 @@ int run_fold_max(const float* smap, int C, int S, int batch, int T, float* dst, 
     return AKE_OK;
 }
 
-static const bool g_pc_f32_only = std::getenv("AKE_PC_F32") != nullptr;
+static const bool g_pc_f32_only = ake::diag_env("AKE_PC_F32") != nullptr;
 
 // NCHW f32 [clip][C][12][T] -> channels-last split planes [clip][12][T][16] (hi plane, then lo plane, at `planes`)
 int run_nchw_to_cl16(const float* src, int C, int batch, int T, unsigned short* planes, hipStream_t s) {
@@ -682,7 +682,7 @@ int run_nchw_to_cl16(const float* src, int C, int batch, int T, unsigned short* 
 // does inference run the last layer's pitch-class stack + its time pooling as ONE launch (pc2pc_fused_kernel)?  The stack's
 // intermediate activations then never leave LDS (ake_debug_keep_taps(1) keeps the per-conv launches for bisecting).
 bool pc2pc_fuses(const ake_pcnet* n, int i, int T) {
-    static const bool off = std::getenv("AKE_PC_FUSED") != nullptr && std::atoi(std::getenv("AKE_PC_FUSED")) == 0;
+    static const bool off = ake::diag_env("AKE_PC_FUSED") != nullptr && std::atoi(ake::diag_env("AKE_PC_FUSED")) == 0;
     const auto& c = n->cfg;
     if (off || g_keep_taps || i < 1 || i != c.num_layers - 1 || c.time_pool_size != 2 || c.conv_layers < 1 || c.conv_layers > 4) return false;
     if (!pc2pc_uses_bf16(n, i, T) || T % 4 || 12 * T > 1024) return false;
@@ -713,7 +713,7 @@ int run_pc2pc_fused(const ake_pcnet* n, int i, const float* src, int cin, int ba
 
 // does the f16 x 3 training form of conv_pc_bf16_kernel take this convolution (fragments built, patch fits the LDS)?
 bool pc_f16x3_ok(const PackedConv& pt, int T_in, bool same_time) {
-    static const bool off = std::getenv("AKE_PC_TRAIN_F32") != nullptr;
+    static const bool off = ake::diag_env("AKE_PC_TRAIN_F32") != nullptr;
     if (off || pt.bf_off < 0 || pt.cin > 16) return false;
     const int T_out = same_time ? T_in : T_in - pt.kw + 1;
     if (T_out < 1) return false;
@@ -981,6 +981,8 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
 
 extern "C" {
 
+int ake_pcnet_precision(const ake_pcnet* n) { return n ? n->cfg.precision : AKE_ERR_INVALID; }
+
 int ake_pcnet_default_config(ake_pcnet_config* cfg, int octaves, int genre) {
     AKE_REQUIRE(cfg && octaves > 0, AKE_ERR_INVALID, "ake_pcnet_default_config: bad argument");
     std::memset(cfg, 0, sizeof(*cfg));
@@ -1006,10 +1008,12 @@ int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
     AKE_REQUIRE(c.num_layers >= 1 && c.num_layers <= 4 && c.conv_layers >= 1 && c.n_filters >= 1 && c.head_layers >= 1,
                 AKE_ERR_INVALID, "pcnet: bad layer counts");
     AKE_REQUIRE(c.time_pool_size >= 1, AKE_ERR_INVALID, "pcnet: bad time_pool_size");
+    AKE_REQUIRE(c.precision == AKE_PRECISION_MIXED || c.precision == AKE_PRECISION_F32X3, AKE_ERR_INVALID,
+                "pcnet: precision must be AKE_PRECISION_MIXED (0) or AKE_PRECISION_F32X3 (1), got %d", c.precision);
     auto* n = new ake_pcnet();
     n->cfg = c;
     if (c.local > 0) n->cfg.time_pool_size = 1;           // --local: the layers do not pool over time (models.py:348, 394)
-    if (const char* e = std::getenv("AKE_PCNET_CHUNK")) n->chunk_clips = std::max(1, std::atoi(e));
+    if (const char* e = ake::diag_env("AKE_PCNET_CHUNK")) n->chunk_clips = std::max(1, std::atoi(e));
     const int nf = c.n_filters, L = c.num_layers, k = c.kernel_size;
     n->dims.resize(L);
     for (int i = 1; i < L; ++i) {           // models.py:281-308
@@ -2041,7 +2045,7 @@ struct Fwd {
 
     // inference, default family: the whole of phase A as one launch, one workgroup per clip (layer0_fused_kernel)
     bool layer0_fused(const float* mel, int B, bool dry_run = false) {
-        static const bool off = std::getenv("AKE_L0_FUSED") != nullptr && std::atoi(std::getenv("AKE_L0_FUSED")) == 0;
+        static const bool off = ake::diag_env("AKE_L0_FUSED") != nullptr && std::atoi(ake::diag_env("AKE_L0_FUSED")) == 0;
         const auto& c = n->cfg;
         const int P = c.pitches, T0 = b.Tl[0], NF = c.n_filters;
         if (off || c.resblock || c.denseblock || c.p2pc_conv || c.stay_sixth || NF < 2 || NF > 4 || c.conv_layers < 1 || c.conv_layers > 4 || c.kernel_size != 7 || P % 36 || T0 < 1) return false;
@@ -2078,7 +2082,7 @@ struct Fwd {
             attr_set.mark();
         }
         // the convolution stack on bf16 MFMA when the fragments exist and the maps fit (AKE_PC_F32=1: the exact-f32 VALU form)
-        bool mfma = !g_pc_f32_only;
+        bool mfma = !g_pc_f32_only && c.precision == AKE_PRECISION_MIXED;      // (the MFMA form multiplies f16 x f16)
         for (int j = 0; j < c.conv_layers; ++j) {
             mfma = mfma && n->pc2pc[0][j].l0_off >= 0;
             if (mfma) a.frag[j] = n->bf_frags_dev + n->pc2pc[0][j].l0_off;
@@ -2090,7 +2094,7 @@ struct Fwd {
         if (dry_run) return true;
         a.mel_fm = mel_fm ? 1 : 0;
         a.taps = g_keep_taps ? 1 : 0;
-        static const int dbg_skip = std::getenv("AKE_L0_SKIP") ? std::atoi(std::getenv("AKE_L0_SKIP")) : 0;   // timing experiments only (wrong results)
+        static const int dbg_skip = ake::diag_env("AKE_L0_SKIP") ? std::atoi(ake::diag_env("AKE_L0_SKIP")) : 0;   // timing experiments only (wrong results)
         if (dbg_skip & 1) a.n_conv = 0;
         if (dbg_skip & 2) a.psix = nullptr;
         ake::ProfScope ps("layer0_fused_kernel", s);
@@ -2522,7 +2526,7 @@ struct Fwd {
                     continue;
                 }
                 if (train && lastj && j > 0 && pe.cout == 1 && pe.kw == 7 && !n->raw_w_off.empty()) {   // cin -> 1: one workgroup per clip, f32 VALU
-                    static const bool off = std::getenv("AKE_HEAD_LAST_MFMA") != nullptr;
+                    static const bool off = ake::diag_env("AKE_HEAD_LAST_MFMA") != nullptr;
                     const std::string wn = std::string(heads[h].nm) + "." + std::to_string(3 * j) + (heads[h].kind == 2 ? "" : ".conv2d");
                     const auto wi = n->spec_index.find(wn + ".weight"), bi = n->spec_index.find(wn + ".bias");
                     const size_t lds = (static_cast<size_t>(hc) * 12 * Tcur + static_cast<size_t>(hc) * pe.kh * 7) * sizeof(float);
@@ -2733,7 +2737,7 @@ static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frame
         if (t == "g_pin") { *p = b.g_pin[L1]; shape[1] = dd.prev_pc + dd.prev_p; shape[2] = c.pitches; shape[3] = b.Tl[L1]; }
         if (t == "z_p_last") { *p = b.pst[L1].back(); shape[1] = dd.out_p; shape[2] = c.pitches; shape[3] = b.Tl[L1]; }
         AKE_REQUIRE(shape[1] > 0, AKE_ERR_INVALID, "tap: unknown training buffer '%s'", name);
-        if (std::getenv("AKE_DEBUG")) fprintf(stderr, "[ake] tap %s -> %p\n", name, (void*)*p);
+        if (ake::diag_env("AKE_DEBUG")) fprintf(stderr, "[ake] tap %s -> %p\n", name, (void*)*p);
         return AKE_OK;
     }
     const int L = c.num_layers, P = c.pitches;
@@ -2760,7 +2764,7 @@ static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frame
                     return AKE_ERR_INVALID;
                 }
                 if (j < last_j && i == L - 1 && pc2pc_uses_bf16(n, i, Ti) && channels_last) *channels_last = 1;
-                if (i == 0 && L > 1 && !g_keep_taps && !g_pc_f32_only && !c.resblock && !c.denseblock && !c.p2pc_conv && !c.stay_sixth && c.n_filters >= 2 &&
+                if (i == 0 && L > 1 && !g_keep_taps && !g_pc_f32_only && c.precision == AKE_PRECISION_MIXED && !c.resblock && !c.denseblock && !c.p2pc_conv && !c.stay_sixth && c.n_filters >= 2 &&
                     c.n_filters <= 4) {
                     ake::set_error("tap: '%s' stays in LDS (layer 0 runs as one launch); ake_debug_keep_taps(1) before the forward writes it", name);
                     return AKE_ERR_INVALID;

@@ -54,7 +54,7 @@ struct Bwd {
     // weight gradient of one convolution: dW += corr(act(input), dz)
     int wgrad(const PackedConv& pc, int kind, Src src, const float* in_aff, int H, int T_in, bool same_time, const float* dz, int dz_ctot,
               int dz_coff, gfx_t* dW, const char* name) {
-        static const bool wg_f32 = std::getenv("AKE_WGRAD_F32") != nullptr;
+        static const bool wg_f32 = ake::diag_env("AKE_WGRAD_F32") != nullptr;
         if (!wg_f32 && kind == 0 && pc.kh == 7 && pc.kw == 7 && pc.cout == 8 && pc.cin <= 8 && T_in <= kWgMaxT && dz_ctot == 8 && dz_coff == 0) {
             WgradBfArgs w;
             std::memset(&w, 0, sizeof(w));
@@ -80,7 +80,7 @@ struct Bwd {
         // channel block), see conv_wgrad_pc_f16x3_kernel
         {
             const int T_out = kind == 0 ? T_in : (same_time ? T_in : T_in - pc.kw + 1);
-            static const int wpc_min_cout = std::getenv("AKE_WPC_MIN_COUT") ? std::atoi(std::getenv("AKE_WPC_MIN_COUT")) : 1;
+            static const int wpc_min_cout = ake::diag_env("AKE_WPC_MIN_COUT") ? std::atoi(ake::diag_env("AKE_WPC_MIN_COUT")) : 1;
             if (!wg_f32 && kind == 1 && pc.kh == 12 && pc.kw == 7 && H == 12 && src.c1 == 0 && T_out >= 1 && pc.cout >= wpc_min_cout) {
                 WgradPcArgs w;
                 std::memset(&w, 0, sizeof(w));
@@ -94,7 +94,7 @@ struct Bwd {
                 w.n_seg = (T_out + kWpSeg - 1) / kWpSeg;
                 w.dW = dW; w.slot_stride = static_cast<long long>(n->grad_floats);
                 const long long n_w = static_cast<long long>(pc.cout) * pc.cin * 84;
-                static const bool partial_off = std::getenv("AKE_WGRAD_ATOMIC") != nullptr;
+                static const bool partial_off = ake::diag_env("AKE_WGRAD_ATOMIC") != nullptr;
                 const long long n_wg = static_cast<long long>(B) * w.n_seg;
                 const bool use_partial = !partial_off && b.wg_partial && n_wg * n_w <= static_cast<long long>(b.wg_partial_floats);
                 if (use_partial) { w.partial = b.wg_partial; w.partial_stride = n_w; }
@@ -138,7 +138,7 @@ struct Bwd {
             a.dst = const_cast<float*>(dz); a.dst_coff = dz_coff + co0; a.dst_clip_stride = static_cast<long long>(dz_ctot) * a.H_out * a.T_out;
             a.in_affine = in_aff;
             wa.dW = dW + static_cast<long long>(co0) * (src.c0 + src.c1) * pc.kh * pc.kw; wa.slot_stride = static_cast<long long>(n->grad_floats); wa.KH = pc.kh; wa.KW = pc.kw;
-            static const bool noflush = std::getenv("AKE_WGRAD_NOFLUSH") != nullptr;
+            static const bool noflush = ake::diag_env("AKE_WGRAD_NOFLUSH") != nullptr;
             wa.dbg_noflush = noflush ? 1 : 0;
             const int KK = pc.kh * pc.kw;
             const int MTC = (co_n + 15) / 16, NTK = (KK + 15) / 16;
@@ -173,7 +173,7 @@ struct Bwd {
             // partial sums per workgroup + an ordered reduction when the scratch buffer holds them (see WgradArgs::partial)
             const long long n_w = static_cast<long long>(co_n) * (src.c0 + src.c1) * KK;
             const long long n_wg = static_cast<long long>(grid.x) * B;
-            static const bool partial_off = std::getenv("AKE_WGRAD_ATOMIC") != nullptr;
+            static const bool partial_off = ake::diag_env("AKE_WGRAD_ATOMIC") != nullptr;
             const bool use_partial = !partial_off && b.wg_partial && n_wg * n_w <= static_cast<long long>(b.wg_partial_floats);
             if (use_partial) { wa.partial = b.wg_partial; wa.partial_stride = n_w; }
             bool launched = false;

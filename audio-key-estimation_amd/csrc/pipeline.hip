@@ -90,7 +90,7 @@ static int pipeline_impl(const ake_cqt_plan* plan, const ake_pcnet* net, const f
     hipStream_t s = static_cast<hipStream_t>(stream);
     // equal-length clips through the default net: the CQT stays in the filter bank's own [clip][frame][bin] order and the net's two
     // readers transpose while they stage it -- no transpose pass, same results bit for bit (AKE_PIPE_FRAMES_MAJOR=0 switches it off)
-    static const bool fm_off = std::getenv("AKE_PIPE_FRAMES_MAJOR") != nullptr && std::atoi(std::getenv("AKE_PIPE_FRAMES_MAJOR")) == 0;
+    static const bool fm_off = ake::diag_env("AKE_PIPE_FRAMES_MAJOR") != nullptr && std::atoi(ake::diag_env("AKE_PIPE_FRAMES_MAJOR")) == 0;
     const bool fm = !fm_off && !n_clip_dev && ake_cqt_frames_major_supported(plan) && ake_pcnet_accepts_frames_major(net, batch, static_cast<int>(T));
     rc = n_clip_dev ? ake_cqt_logmag_ragged_f32(plan, audio_dev, batch, n_samples, audio_stride, n_clip_dev, pc.mel, T, pc.cqt_ws, pc.cqt_bytes, stream)
          : fm       ? ake_cqt_logmag_frames_major_f32(plan, audio_dev, batch, n_samples, audio_stride, pc.mel, pc.cqt_ws, pc.cqt_bytes, stream)

@@ -24,6 +24,14 @@ from .lightning_shim import LightningModule
 from .metrics import mirex_score as _mirex_score
 
 _VARIANT_FLAGS = ("only_semitones",)
+# opt.precision -> ake_pcnet_config::precision (include/ake_hip.h: AKE_PRECISION_MIXED / AKE_PRECISION_F32X3)
+PRECISIONS = {"mixed": 0, "f32x3": 1, 0: 0, 1: 1}
+PRECISION_DTYPES = {
+    0: "f32 accumulation everywhere; pitch / semitone / layer-0 convolutions: f16 activations x f16 weights (per-channel power-of-two scaled) on "
+       "MFMA, one product; last layer's pitch-class convolutions and heads: 3-term split-bf16 on MFMA (hi*hi + lo*hi + hi*lo)",
+    1: "f32 accumulation everywhere; pitch / semitone / layer-0 convolutions: exact f32 (v_mfma_f32_16x16x4_f32 / VALU); pitch-class "
+       "convolutions and heads: 3-term split-bf16 on MFMA (operands to 2^-17)",
+}
 
 
 class EquivariantPitchClassConvolutionSimple(nn.Module):
@@ -297,6 +305,7 @@ def _opt_get(opt, name, default):
 
 
 class PitchClassNet(LightningModule):
+    fused_loss = True     # general_step as one launch on the device (csrc/loss.hip); False: the same arithmetic as torch ops (A/B, tests)
 
     def __init__(self, pitches, pitch_classes, num_layers, kernel_size, opt=None, window_size=23, batch_size=4,
                  train_set=None, val_set=None):
@@ -367,6 +376,12 @@ class PitchClassNet(LightningModule):
         self._ws = None              # workspace of the forwards that no backward depends on (inference, train mode without autograd)
         self._ws_last = None         # workspace of the most recent forward (what `tap` reads)
         self._train_ws_free = []     # training workspaces no autograd node owns at the moment
+        # opt.precision (not a reference flag): arithmetic of the INFERENCE convolutions, ake_pcnet_config::precision -- "mixed" (default: f16
+        # single-product pitch / semitone / layer-0 convolutions, split-bf16 x 3 elsewhere) or "f32x3" (no operand rounded below 2^-17)
+        prec = _opt_get(opt, "precision", "mixed")
+        if prec not in PRECISIONS:
+            raise ValueError(f"opt.precision must be one of {sorted(k for k in PRECISIONS if isinstance(k, str))}, got {prec!r}")
+        self.precision = PRECISIONS[prec]
         self._flat = None            # one float32 device buffer holding every float state_dict entry (layout: ake_pcnet_grad_offset)
         self._flat_grad = None       # same layout; every p.grad is a view of it
         self._attached = False       # parameters/buffers are views of _flat
@@ -391,6 +406,7 @@ class PitchClassNet(LightningModule):
         c.p2pc_conv = 1 if self.p2pc_conv else 0
         c.stay_sixth = 1 if self.stay_sixth else 0
         c.denseblock = 1 if self.denseblock else 0
+        c.precision = self.precision
         return c
 
     def _layout(self):
@@ -414,8 +430,12 @@ class PitchClassNet(LightningModule):
         base = self._flat.data_ptr()
         return all(v.dtype == torch.float32 and v.data_ptr() == base + 4 * off for (_, off, _), v in zip(self._layout(), state))
 
-    def _sync_weights(self, device):
+    def _sync_weights(self, device, for_eval=None):
         """Make the device handle reflect the current parameters (after an optimizer step, load_state_dict, .to()).
+
+        ``for_eval``: the caller is about to run EVAL-mode kernels (default: ``not self.training``).  Only the eval-mode packs fold the
+        running statistics, so a train-mode forward skips the repack after a statistics update -- but ``KeyEstimator`` and ``prepare()``
+        serve through the eval kernels whatever ``self.training`` says, and pass True (stale BatchNorm statistics otherwise).
 
         float32 parameters on the device are MOVED into one flat buffer (the tensors become views of it), so that the
         packed kernel weights are rebuilt on the device (ake_pcnet_load_from_device_f32) and the fused optimizer / the
@@ -454,7 +474,9 @@ class PitchClassNet(LightningModule):
                 pass
             stamp = (self._dirty,) + tuple((v._version, v.data_ptr()) for v in state)
             # (the reference trains with 8 clips per step: repacking after every step's running-statistics update cost 0.35 ms of 3.7)
-            if stamp == self._h_stamp and (self.training or self._stats_dirty == self._h_stats_stamp):
+            if for_eval is None:
+                for_eval = not self.training
+            if stamp == self._h_stamp and (not for_eval or self._stats_dirty == self._h_stats_stamp):
                 return
             if not self._attached and self._h_stamp is not None:      # staged copy of foreign-dtype parameters
                 with torch.no_grad():
@@ -544,9 +566,15 @@ class PitchClassNet(LightningModule):
         """Opaque ``ake_pcnet*`` (valid after a forward or ``prepare()``)."""
         return self._h
 
+    def precision_dtype(self) -> str:
+        """What the inference convolutions of this module's DEVICE HANDLE compute in (read back through ake_pcnet_precision, so that a
+        benchmark line cannot claim a precision the handle does not run)."""
+        self._sync_weights(self._device(), for_eval=True)
+        return PRECISION_DTYPES[int(_lib.lib().ake_pcnet_precision(self._h))]
+
     def prepare(self):
         """Upload the current weights to the device now (otherwise done lazily by ``forward``)."""
-        self._sync_weights(self._device())
+        self._sync_weights(self._device(), for_eval=True)
         return self
 
     def _device(self):
@@ -799,7 +827,7 @@ class PitchClassNet(LightningModule):
         key_out, tonic_out = out[0], out[1]
         dev = key_out.device
         if (key_out.is_cuda and key_out.dtype in (torch.float32, torch.float64) and type(self).mirex_score is PitchClassNet.mirex_score
-                and os.environ.get("AKE_FUSED_LOSS", "1") != "0"):
+                and self.fused_loss):
             # the device path: one launch for the loss, its gradient and the metrics (a subclass that overrides mirex_score keeps the torch ops)
             weights = (float(_opt_get(opt, "key_weight", 1.0)), float(_opt_get(opt, "tonic_weight", 1.0)), float(_opt_get(opt, "genre_weight", 0.1)))
             vals = _FusedGeneralStep.apply(key_out, tonic_out, out[2] if self.genre else None, batch["key_labels"], batch["tonic_labels"],

@@ -57,7 +57,7 @@ class KeyEstimator:
         ``rate``: sample rate of ``audio`` when it is not the estimator's -- it is resampled on the device first
         (``scipy.signal.resample_poly``'s filter); ``channel``: which channel of (B, C, n) audio to take (0 = the reference's
         ``waveform[0]``, KeyDataset.py:480) or -1 for the mean of all."""
-        self.net._sync_weights(self.device)
+        self.net._sync_weights(self.device, for_eval=True)
         if audio.dim() == 3 or (rate is not None and int(rate) != self.sample_rate):
             rs = get_resampler(self.sample_rate if rate is None else int(rate), self.sample_rate, self.device)
             audio, len_out = rs(audio, channel=channel, lengths=lengths)

@@ -304,8 +304,11 @@ def train_parity(net, sd, batch, rank):
         return None
     t0 = time.perf_counter()
     sd64 = pcnet_oracle.to_dtype(sd, torch.float64)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))       # (a GPU box grants 16 cores whatever it reports)
     with torch.no_grad():
         ref = pcnet_oracle.pcnet_forward(sd64, batch["mel"].double().cpu(), batch["seq_length"].cpu(), training=True)
+    torch.set_num_threads(prev)
     loss_ref = loss_oracle.general_step_loss(ref[0].numpy(), ref[1].numpy(), ref[2].numpy(), batch["key_labels"].cpu().numpy(),
                                              batch["tonic_labels"].cpu().numpy(), batch["genre"].cpu().numpy())
     errs = {n: float((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-6)) for n, a, b in zip(("key", "tonic", "genre"), out, ref)}

@@ -38,6 +38,10 @@ typedef void* ake_stream_t; /* hipStream_t */
 
 int ake_version(void);
 const char* ake_last_error(void);
+/* 1 if the library was built with -DAKE_DIAG (`AKE_DIAG=1 csrc/build.sh`): only then are the AKE_* environment switches of the kernel
+ * experiments (A/B kernel selection, phase ablation, in-kernel cycle stamps) read at all.  The shipped build returns 0 and never looks at
+ * the environment: nothing a process inherits can change results or precision. */
+int ake_build_has_diag(void);
 
 /* ------------------------------------------------------------------------------------------
  * CQT front end.  Replaces
@@ -131,7 +135,19 @@ typedef struct ake_pcnet_config {
      * W = opt.frames * opt.loc_window_size - head_layers * (kernel_size - 1).  The layers then do not pool over time
      * (models.py:348, 394: time_pool_size is ignored) and the forward is ake_pcnet_forward_local_f32.  Inference only. */
     int local;
+    /* Arithmetic of the INFERENCE convolutions (training always uses f32-equivalent products).  Storage, accumulation and every
+     * non-convolution op are f32 in both modes.
+     *   AKE_PRECISION_MIXED (0, default): the 7x7 pitch convolutions, the semitone convolutions and layer 0's pitch-class stack multiply f16
+     *       activations with f16 weights (per-channel power-of-two scaled), one MFMA product; the last layer's pitch-class stack and the heads
+     *       use 3-term split-bf16 products.  Outputs within ~2e-5 of the float64 reference on seeded and on trained weights (budget 1e-3).
+     *   AKE_PRECISION_F32X3 (1): no operand is rounded below 2^-17: exact-f32 MFMA / VALU kernels for the pitch, semitone and layer-0
+     *       convolutions, 3-term split-bf16 products (hi*hi + lo*hi + hi*lo) for the pitch-class stack and the heads.  ~4x slower. */
+    int precision;
 } ake_pcnet_config;
+#define AKE_PRECISION_MIXED 0
+#define AKE_PRECISION_F32X3 1
+/* the precision a handle runs its inference convolutions in (AKE_PRECISION_*) */
+int ake_pcnet_precision(const ake_pcnet* net);
 
 int ake_pcnet_default_config(ake_pcnet_config* cfg, int octaves, int genre);
 int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out);

@@ -12,6 +12,10 @@ GOLD = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the float64 oracle runs on the host: a GPU box reports 128+ hardware threads but grants this job a 16-core share, and torch's default
+    # (one thread per reported core) oversubscribes it (measured: the config-3 oracle loop 420 s with 128 threads)
+    import torch
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 
 def load_golden(name):

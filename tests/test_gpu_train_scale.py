@@ -93,28 +93,72 @@ def report(tag, rows):
           f"worst unfloored {max(r[3] for r in rows):.2e}")
 
 
+F32_BAND = (5e-2, 1e-2)     # (worst tensor, median tensor): what float32 PyTorch on the CPU itself shows against float64 at these sizes, see below
+
+
 def test_gradients_at_32_clips(gold_default):
-    """Four data seeds at 32 x 76.  Every seed: inside the kink-damage bound with a tight median; at least two seeds tight in EVERY tensor
-    (a systematic error of a kernel -- a tile dropped in the persistent loop, a partial lost in the reduction -- fails all four)."""
+    """Six data seeds at 32 x 76 against float64 autograd.
+
+    At this size a float32 run cannot be tight in every tensor on every seed: with 2.4e7 LeakyReLU / max decisions per step a handful sit
+    within 1e-6 of the kink, take the other branch than the float64 forward and move every gradient upstream of them by ~1e-3.  Stock
+    float32 PyTorch on the CPU, same batches, against the same float64 gradients: worst tensor 4.6e-3 .. 3.0e-2, MEDIAN tensor 1.0e-3 ..
+    3.6e-3 on every one of seeds 0-3 (measured; 256 clips: 5.2e-3 / 2.1e-3) -- the device is usually far inside that (median 7e-6 on seeds
+    without a flip near the top of the net).  So the statement that separates a kernel defect from such flips:
+      * every seed: inside the float32 band (a defect that scales with the data, e.g. a wrong tile, breaks it);
+      * every TENSOR is tight (3e-5 of its max) on at least one seed: a flip spoils the tensors upstream of it on ITS seed only, a
+        systematic error of a kernel -- a tile dropped by the persistent loop, a partial lost in the ordered reduction, low bits of dz
+        lost -- spoils its tensors on every seed;
+      * at least two seeds have a tight median."""
     net, sd32 = fresh_net(gold_default)
-    tight = 0
-    for seed in range(4):
+    best, tight_median = {}, 0
+    for seed in range(6):
         x, seq, labels = big_case(32, 76, seed)
         loss_ref, ref = oracle_grads(sd32, x, seq, labels)
         loss, got = device_grads(net, x, seq, labels)
         assert abs(loss - loss_ref) < 2e-5 * max(1.0, abs(loss_ref)), (seed, loss, loss_ref)
         rows = error_rows(got, ref)
         report(f"32 clips, seed {seed}", rows)
-        assert rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 1e-4, (seed, rows[:4])
-        # no tensor is "effectively unchecked" (ADVICE r2): even relative to its OWN largest entry every gradient tensor is right to 2 %
+        assert rows[0][0] < F32_BAND[0] and rows[len(rows) // 2][0] < F32_BAND[1], (seed, rows[:4])
+        # no tensor is "effectively unchecked" (ADVICE r2): relative to its OWN largest entry every gradient tensor is right to 10 %
         assert max(r[3] for r in rows if r[1] not in ILL_CONDITIONED) < 1e-1, (seed, sorted(rows, key=lambda r: -r[3])[:4])
-        tight += all(e <= ILL_CONDITIONED.get(n, 3e-5) for e, n, _, _ in rows)
-    assert tight >= 2, tight
+        tight_median += rows[len(rows) // 2][0] < 3e-5
+        for e, n, _, _ in rows:
+            best[n] = min(best.get(n, 1.0), e)
+    never_tight = sorted(((e, n) for n, e in best.items() if e > ILL_CONDITIONED.get(n, 3e-5)), reverse=True)
+    print("\nbest error of every tensor over the seeds: worst", max(best.values()))
+    assert not never_tight, never_tight[:6]
+    assert tight_median >= 2, tight_median
+
+
+def replicate(x, seq, labels, copies, seed):
+    """`copies` copies of every clip, in a random order: the batch statistics of every BatchNorm, the per-clip activations and the (mean)
+    losses are those of the small batch, so the loss is the same FUNCTION of the weights and the gradients are equal."""
+    perm = torch.randperm(x.shape[0] * copies, generator=torch.Generator().manual_seed(seed))
+    rep = lambda t: t.repeat((copies,) + (1,) * (t.dim() - 1))[perm]
+    return rep(x), rep(seq), tuple(rep(t) for t in labels)
+
+
+def test_bench_shard_gradients_equal_those_of_the_replicated_32_clips(gold_default):
+    """The benchmarked shard without any float64 noise floor: 256 clips x 76 frames = 8 shuffled copies of the 32-clip batch above must
+    give the 32-clip gradients (same loss function of the weights; LeakyReLU / max decisions are taken on the same values, to the 1e-7 that
+    the sums over 8x as many elements round differently).  What differs is everything the large launch does differently: 7 424 row tiles
+    on 256 persistent workgroups (29 per workgroup: prefetch, buffer swap, pending stores, statistics flush), 512 weight-gradient partials
+    per convolution, BatchNorm sums over 5.6 M values per channel, dz of 1e-7 (the f16 hi / lo data-gradient operands)."""
+    net, _ = fresh_net(gold_default)
+    x, seq, labels = big_case(32, 76, 0)
+    loss32, g32 = device_grads(net, x, seq, labels)
+    x8, seq8, labels8 = replicate(x, seq, labels, 8, 5)
+    loss256, g256 = device_grads(net, x8, seq8, labels8)
+    assert abs(loss256 - loss32) < 2e-6 * max(1.0, abs(loss32)), (loss256, loss32)
+    rows = error_rows(g256, g32)
+    report("256 = 8 x 32 clips against 32 clips (device both)", rows)
+    assert rows[0][0] < 2e-3 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
 
 
 def test_gradients_at_the_bench_shard(gold_default):
-    """256 clips x 76 frames -- the per-rank batch of `bench.py --train` and of BASELINE configs[3]: 7 424 tiles over 256 workgroups (29 per
-    workgroup), 512 partials per weight gradient, 5.6 M values per BatchNorm channel; dz around 1e-7."""
+    """256 clips x 76 frames of DISTINCT data -- the per-rank batch of `bench.py --train` and of BASELINE configs[3] -- against float64
+    autograd of the whole batch (about a minute on the host).  Inside the float32 band (float32 PyTorch on the CPU, this batch: worst
+    5.2e-3, median 2.1e-3 against the same float64 gradients); the tensors nothing can flip above -- the heads' last convolutions -- tight."""
     net, sd32 = fresh_net(gold_default)
     x, seq, labels = big_case(256, 76, 7)
     loss_ref, ref = oracle_grads(sd32, x, seq, labels)
@@ -122,8 +166,11 @@ def test_gradients_at_the_bench_shard(gold_default):
     assert abs(loss - loss_ref) < 2e-5 * max(1.0, abs(loss_ref)), (loss, loss_ref)
     rows = error_rows(got, ref)
     report("256 clips", rows)
-    assert rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 1e-4, rows[:4]
+    assert rows[0][0] < F32_BAND[0] and rows[len(rows) // 2][0] < F32_BAND[1], rows[:4]
     assert max(r[3] for r in rows if r[1] not in ILL_CONDITIONED) < 1e-1, sorted(rows, key=lambda r: -r[3])[:4]
+    by_name = {n: e for e, n, _, _ in rows}
+    for n in ("key_classifier.3.conv2d.weight", "tonic_classifier.3.conv2d.weight", "genre_classifier.3.weight"):
+        assert by_name[n] < 3e-5, (n, by_name[n])
 
 
 def test_gradients_scale_with_the_loss(gold_default):
@@ -134,15 +181,10 @@ def test_gradients_scale_with_the_loss(gold_default):
     x, seq, labels = big_case(32, 76, 1)
     _, g1 = device_grads(net, x, seq, labels)
     _, g2 = device_grads(net, x, seq, labels, scale=2.0 ** -10)
-    worst = 0.0
-    for n in g1:
-        m = float(g1[n].abs().max())
-        if m < 1e-9:
-            continue
-        e = float((g2[n] * 1024.0 - g1[n]).abs().max()) / m
-        worst = max(worst, e)
-        assert e < 2e-4, (n, e, m)
-    print(f"\nloss-scale homogeneity: worst {worst:.2e}")
+    floor = 1e-4 * max(float(g.abs().max()) for g in g1.values())      # (the tonic head's last bias: sum of softmax - onehot, zero to rounding)
+    errs = sorted(((float((g2[n] * 1024.0 - g1[n]).abs().max()) / max(float(g1[n].abs().max()), floor), n) for n in g1), reverse=True)
+    print(f"\nloss-scale homogeneity: worst {errs[0][0]:.2e} ({errs[0][1]}), median {errs[len(errs) // 2][0]:.2e}")
+    assert errs[0][0] < 2e-4, errs[:5]
 
 
 def test_train_forward_and_batch_statistics_at_the_bench_batch(gold_default):
