@@ -297,6 +297,7 @@ struct Tile {
 // the LDS budget.  Score = useful tile slots / issued, times the row-tile fill.
 struct MTile { int W, cin_chunk; };
 int device_cus();
+int tiling_cus(int which);
 
 // want_tiles > 1 (small batches): tilings with fewer (row, time) tiles than that lose score, so that the launch fills the chip.
 bool choose_tile(bool fullrows, int cin, int H, int KH, int T_out, int TB, int KU, int NT, int MT, Tile* t, MTile* mt_out, int want_tiles = 1) {
@@ -406,7 +407,9 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
     static const int mt_env = ake::diag_env("AKE_MT") ? std::atoi(ake::diag_env("AKE_MT")) : 3;
     const int MT = (pc.ku == 8 && pc.nt == 1 && kind == 0) ? mt_env : 3;
     const int cout_tiles = std::max(1, pc.ntiles / pc.nt);
-    const int want_tiles = (std::max(device_cus(), 1) + batch * cout_tiles - 1) / (batch * cout_tiles);      // 1 at the bench / training batch sizes
+    static const char* const tiling_only = ake::diag_env("AKE_TILING_ONLY");      // diagnostic: AKE_TILING_CUS only for launches whose name contains this
+    const int t_cus = (tiling_only && !std::strstr(name, tiling_only)) ? device_cus() : tiling_cus(0);
+    const int want_tiles = (std::max(t_cus, 1) + batch * cout_tiles - 1) / (batch * cout_tiles);      // 1 at the bench / training batch sizes
     AKE_REQUIRE(choose_tile(fullrows, pc.cin, H, pc.kh, a.T_out, pc.tb, pc.ku, pc.nt, MT, &t, &mtile, want_tiles), AKE_ERR_UNSUPPORTED,
                 "conv %s: no tile fits LDS (cin=%d H=%d)", name, pc.cin, H);
     a.R = t.R; a.TT = t.TT; a.Tp = t.Tp; a.n_row_tiles = t.n_row_tiles; a.n_time_tiles = t.n_time_tiles;
@@ -505,6 +508,15 @@ int device_cus() {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cus = -1;
     }
     return n_cus;
+}
+
+// The CU count the TILING heuristics compare the batch with ("does this launch fill the chip?").  Diagnostic builds can override it
+// (AKE_TILING_CUS): a 32-clip batch with AKE_TILING_CUS=32 runs the tilings a 256-clip batch gets on the 256-CU part, small enough for
+// float64 autograd to check them (the grids of the persistent kernels keep using the real count).
+int tiling_cus(int which) {          // which: 0 the convolution's tile choice, 1 the weight-gradient kernels, 2 the semitone weight gradient
+    static const int over = ake::diag_env("AKE_TILING_CUS") ? std::atoi(ake::diag_env("AKE_TILING_CUS")) : 0;
+    static const int mask = ake::diag_env("AKE_TILING_CUS_MASK") ? std::atoi(ake::diag_env("AKE_TILING_CUS_MASK")) : 7;
+    return (over > 0 && ((mask >> which) & 1)) ? over : device_cus();
 }
 
 // row-tile height of the persistent pitch-conv kernel for H x T maps (0: the shape does not qualify); `semi`: the form fused with the

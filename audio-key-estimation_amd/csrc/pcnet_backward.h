@@ -63,7 +63,7 @@ struct Bwd {
             w.src1_clip_stride = static_cast<long long>(src.c1) * w.h1 * T_in;
             w.in_affine = in_aff; w.dz = dz; w.dW = dW; w.slot_stride = static_cast<long long>(n->grad_floats);
             w.cin = pc.cin; w.H = H; w.T = T_in;
-            const int wgs_per_clip = std::max(4, std::min(H, (512 + B - 1) / B));
+            const int wgs_per_clip = std::max(4, std::min(H, (2 * std::max(tiling_cus(1), 1) + B - 1) / B));
             w.rows_per_wg = (H + wgs_per_clip - 1) / wgs_per_clip;
             dim3 grid((H + w.rows_per_wg - 1) / w.rows_per_wg, 1, B);
             const size_t lds = (static_cast<size_t>(6) * 64 * kWgKP + kWgKP) * sizeof(unsigned short);
@@ -155,7 +155,7 @@ struct Bwd {
             // small batches (the reference trains with 8 clips per step): shorter time tiles and one workgroup per group of 8 input
             // channels, until the launch has about one workgroup per CU
             const int cin_all = src.c0 + src.c1;
-            const int n_cus = std::max(device_cus(), 1);
+            const int n_cus = std::max(tiling_cus(1), 1);
             auto tiles_of = [&](int R_, int TT_) { return ((a.H_out + R_ - 1) / R_) * ((a.T_out + TT_ - 1) / TT_); };
             const int c_groups = static_cast<long long>(B) * tiles_of(R, TT) < n_cus ? (cin_all + 7) / 8 : 1;
             while (static_cast<long long>(B) * tiles_of(R, TT) * c_groups < n_cus && TT > 16) TT = std::max(16, (TT / 2 + 3) / 4 * 4);
@@ -165,7 +165,7 @@ struct Bwd {
             a.n_time_tiles = (a.T_out + TT - 1) / TT;
             const int tiles = a.n_row_tiles * a.n_time_tiles;
             // workgroups per clip: 4 at training batch sizes (fewer atomics), more for small batches so that the chip still fills
-            const int wgs_per_clip = std::min(tiles, std::max(4, (512 + B - 1) / B));
+            const int wgs_per_clip = std::min(tiles, std::max(4, (2 * std::max(tiling_cus(1), 1) + B - 1) / B));
             wa.rt_per_block = std::max(1, (tiles + wgs_per_clip - 1) / wgs_per_clip);
             wa.c_per_block = c_groups > 1 ? 8 : cin_all;
             dim3 grid((tiles + wa.rt_per_block - 1) / wa.rt_per_block, c_groups, B), block(512);
@@ -558,7 +558,7 @@ struct Bwd {
             }
             // rows per workgroup: kSemiRows at training batch sizes (few atomics), down to one row per wave when the batch is small
             const int S = P / 3, pair_groups = (C * C + 63) / 64;
-            const int want = (std::max(device_cus(), 1) + B * pair_groups - 1) / (B * pair_groups);     // workgroups per clip that fill the chip
+            const int want = (std::max(tiling_cus(2), 1) + B * pair_groups - 1) / (B * pair_groups);     // workgroups per clip that fill the chip
             const int rows = std::min(kSemiRows, std::max(4, (S + want - 1) / want));
             hipLaunchKernelGGL(semi_bwd_weight_kernel, dim3((S + rows - 1) / rows, B, pair_groups), dim3(256), lds, s, g, x, x_aff,
                                grad_of(m + "pool_semi.weight"), static_cast<long long>(n->grad_floats), C, P, Tn, rows);

@@ -82,6 +82,34 @@ __device__ __forceinline__ double fx_checked(long long sum, double scale) {     
     return (sum > lim || sum < -lim) ? __longlong_as_double(0x7ff8000000000000ll) : static_cast<double>(sum) / scale;
 }
 
+__device__ __forceinline__ void fx_add_int(double* cell, long long v) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(cell), static_cast<unsigned long long>(v));
+}
+// BatchNorm batch statistics, one lane's share, in DOUBLE: sum v and sum v^2 (the square of an f32 is exact in double, the sums are good to
+// 1e-16 of their size).  Two reasons.  (1) A raw convolution output whose channel mean is many standard deviations from zero (non-negative
+// inputs) made the one-pass E[z^2] - mean^2 on f32 partial sums lose 3.6e-5 of the variance at 256 clips.  (2) With f32 partials the LAST BIT
+// of a BatchNorm table depended on which elements a lane happened to see, i.e. on the tiling the batch size selects: of the 4e7 LeakyReLU /
+// max decisions of a step a handful then went the other way between a 192- and a 256-clip batch of the same clips, and because a gradient
+// tensor is a cancelling sum over ~1e6 positions ONE flipped position moves it by 1e-3 (tests/test_gpu_train_scale.py).  Now the partials are
+// exact to rounding of the total, the fixed-point cells add integers, and the tables are the same bits whatever the tiling.
+struct ShiftStat {
+    double s1, s2;
+    __device__ __forceinline__ void init() { s1 = 0.0; s2 = 0.0; }
+    __device__ __forceinline__ void add(float v) {
+        const double d = v;
+        s1 += d;
+        s2 = fma(d, d, s2);
+    }
+    __device__ __forceinline__ void fixed(long long& i1, long long& i2) const {
+        i1 = __double2ll_rn(s1 * kFxStat);
+        i2 = __double2ll_rn(s2 * kFxStat);
+    }
+};
+__device__ __forceinline__ long long shfl_xor_ll(long long v, int o) {
+    const int lo = __shfl_xor(static_cast<int>(v & 0xffffffffll), o), hi = __shfl_xor(static_cast<int>(v >> 32), o);
+    return (static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo);
+}
+
 // float -> bf16 bits, round to nearest even (finite inputs)
 __device__ __forceinline__ unsigned int bf16_bits(float v) {
     const unsigned int u = __float_as_uint(v);
@@ -564,9 +592,9 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
     float* d = a.dst + clip * a.dst_clip_stride + t0;
     const float* rs = a.residual ? a.residual + clip * a.residual_clip_stride + t0 : nullptr;
     const int row_elems = a.T_out;
-    float st1[NT], st2[NT];
+    ShiftStat stt[TRAIN ? NT : 1];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { st1[nt] = 0.f; st2[nt] = 0.f; }
+    for (int nt = 0; nt < (TRAIN ? NT : 1); ++nt) stt[nt].init();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m0 = (grp * MT + mt) * 16 + 4 * q;
@@ -582,7 +610,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
                 if (ok_m && co < a.cout && tl < tt_here) {
                     float v = acc[mt][nt][reg] + a.bias[co];
                     if (rs) v += rs[(co * a.H_out + (y0 + r)) * row_elems + tl];
-                    if (TRAIN && a.stats) { st1[nt] += v; st2[nt] = fmaf(v, v, st2[nt]); }
+                    if (TRAIN && a.stats) stt[TRAIN ? nt : 0].add(v);
                     if (a.lrelu) v = v > 0.f ? v : v * kSlope;
                     float* dp = d + ((a.dst_coff + co) * a.H_out + (y0 + r)) * row_elems + tl;
                     *dp = (TRAIN && a.accumulate) ? *dp + v : v;
@@ -594,16 +622,17 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(MfmaArgs ma) {
     if (TRAIN && a.stats) {   // per-channel batch statistics: lanes of one channel = TB adjacent columns x 4 row groups
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            float s1 = st1[nt], s2 = st2[nt];
-            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-            for (int o = 1; o < TB; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            long long s1, s2;
+            stt[TRAIN ? nt : 0].fixed(s1, s2);
+            s1 += shfl_xor_ll(s1, 16); s2 += shfl_xor_ll(s2, 16);
+            s1 += shfl_xor_ll(s1, 32); s2 += shfl_xor_ll(s2, 32);
+            for (int o = 1; o < TB; o <<= 1) { s1 += shfl_xor_ll(s1, o); s2 += shfl_xor_ll(s2, o); }
             const int n = (ngrp * NT + nt) * 16 + r16;
             const int co = n / TB;
             if (q == 0 && n - co * TB == 0 && co < a.cout) {
                 double* st = a.stats + static_cast<size_t>((blockIdx.x + 7 * blockIdx.z + wave) & (kStatSlots - 1)) * a.stats_stride;
-                fx_add(st + 2 * co, s1, kFxStat);
-                fx_add(st + 2 * co + 1, s2, kFxStat);
+                fx_add_int(st + 2 * co, s1);
+                fx_add_int(st + 2 * co + 1, s2);
             }
         }
     }
@@ -1302,7 +1331,8 @@ __global__ __launch_bounds__(512) void conv_p2p_f16x3_kernel(P2pTrArgs a) {
             else if (m < prev_mblk) { o[0] = __uint_as_float(outv[mt].x); o[1] = __uint_as_float(outv[mt].y); }
         }
     };
-    float s1 = 0.f, s2 = 0.f;             // this lane's share of channel co's statistics, over all tiles of the workgroup
+    ShiftStat sst;                        // this lane's share of channel co's statistics, over all tiles of the workgroup
+    sst.init();
     int cur = 0;
     for (int tile = tile0; tile >= 0; cur ^= 1) {
         const int next = tile + nwg < a.n_tiles ? tile + nwg : -1;
@@ -1343,7 +1373,7 @@ __global__ __launch_bounds__(512) void conv_p2p_f16x3_kernel(P2pTrArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float v = fmaf(fmaf(accl[mt][i], kP2pLoInv, acc[mt][i]), iscale, bias);
-                if ((wave * MT + mt) * 16 + 4 * q + i < mblk) { s1 += v; s2 = fmaf(v, v, s2); }
+                if ((wave * MT + mt) * 16 + 4 * q + i < mblk) sst.add(v);
                 st[co * 36 + (4 * q + i) * 2 + tau] = v;
             }
         }
@@ -1355,13 +1385,15 @@ __global__ __launch_bounds__(512) void conv_p2p_f16x3_kernel(P2pTrArgs a) {
     }
     if (has_prev) store_pending();
     if (a.stats) {                        // lanes of one channel: r16 = co and co + 8 (tau), four q
-        s1 += __shfl_xor(s1, 8); s2 += __shfl_xor(s2, 8);
-        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        long long s1, s2;
+        sst.fixed(s1, s2);
+        s1 += shfl_xor_ll(s1, 8); s2 += shfl_xor_ll(s2, 8);
+        s1 += shfl_xor_ll(s1, 16); s2 += shfl_xor_ll(s2, 16);
+        s1 += shfl_xor_ll(s1, 32); s2 += shfl_xor_ll(s2, 32);
         if (lane < 8 && lane < a.cout) {
             double* st = a.stats + static_cast<size_t>((blockIdx.x + wave) & (kStatSlots - 1)) * a.stats_stride;
-            fx_add(st + 2 * lane, s1, kFxStat);
-            fx_add(st + 2 * lane + 1, s2, kFxStat);
+            fx_add_int(st + 2 * lane, s1);
+            fx_add_int(st + 2 * lane + 1, s2);
         }
     }
 }
@@ -1534,7 +1566,8 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
         const float bias = (co < a.cout && bptr) ? bptr[co] : 0.f;
         float iscale = (F16X3 && co < a.cout) ? reinterpret_cast<const float*>(bfr + a.KH * 4 * NT * 2 * 64)[co] : 1.f;
         if (F16X3 && a.in_amax) iscale /= f16_weight_scale(__uint_as_float(*a.in_amax));        // (powers of two: exact)
-        float st1 = 0.f, st2 = 0.f;
+        ShiftStat sstat;
+        sstat.init();
         unsigned short* const oh = second ? a.oh2 : a.oh;
         unsigned short* const ol = second ? a.ol2 : a.ol;
 #pragma unroll
@@ -1545,7 +1578,7 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
             for (int i = 0; i < 4; ++i) {
                 if (m0 + i < Mtot && co < a.cout) {
                     float v = F16X3 ? fmaf(fmaf(accl[F16X3 ? mt : 0][F16X3 ? nt : 0][i], kP2pLoInv, acc[mt][nt][i]), iscale, bias) : acc[mt][nt][i] + bias;
-                    if (F16X3) { st1 += v; st2 = fmaf(v, v, st2); }
+                    if (F16X3) sstat.add(v);
                     if (a.lrelu) v = v > 0.f ? v : v * kSlope;
                     if (OUT_CL) {
                         const long long idx = ((static_cast<long long>(clip) * H_out + y) * a.T_out + t) * a.cl_stride + co;
@@ -1561,12 +1594,14 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
             }
         }
         if (F16X3 && a.stats) {   // channel co's statistics: the four q-groups of lanes hold different positions
-            st1 += __shfl_xor(st1, 16); st2 += __shfl_xor(st2, 16);
-            st1 += __shfl_xor(st1, 32); st2 += __shfl_xor(st2, 32);
+            long long st1, st2;
+            sstat.fixed(st1, st2);
+            st1 += shfl_xor_ll(st1, 16); st2 += shfl_xor_ll(st2, 16);
+            st1 += shfl_xor_ll(st1, 32); st2 += shfl_xor_ll(st2, 32);
             if (q == 0 && co < a.cout) {
                 double* st = a.stats + static_cast<size_t>((blockIdx.x + 7 * blockIdx.z + wave) & (kStatSlots - 1)) * a.stats_stride;
-                fx_add(st + 2 * co, st1, kFxStat);
-                fx_add(st + 2 * co + 1, st2, kFxStat);
+                fx_add_int(st + 2 * co, st1);
+                fx_add_int(st + 2 * co + 1, st2);
             }
         }
     }
@@ -2615,13 +2650,15 @@ __device__ __forceinline__ float affine_act(float x, const float* aff, int c) {
 }
 
 // wave-level (sum, sumsq) -> one double atomic pair per wave
-__device__ __forceinline__ void stats_commit(double* stats, int stats_stride, int c, float s1, float s2) {
+__device__ __forceinline__ void stats_commit(double* stats, int stats_stride, int c, const ShiftStat& ss) {
+    long long s1, s2;
+    ss.fixed(s1, s2);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    for (int o = 32; o > 0; o >>= 1) { s1 += shfl_xor_ll(s1, o); s2 += shfl_xor_ll(s2, o); }
     if ((threadIdx.x & 63) == 0) {
         double* st = stats + static_cast<size_t>((blockIdx.x + 7 * blockIdx.z + (threadIdx.x >> 6)) & (kStatSlots - 1)) * stats_stride;
-        fx_add(st + 2 * c, s1, kFxStat);
-        fx_add(st + 2 * c + 1, s2, kFxStat);
+        fx_add_int(st + 2 * c, s1);
+        fx_add_int(st + 2 * c + 1, s2);
     }
 }
 
@@ -2686,13 +2723,14 @@ __global__ void semi_conv_stats_kernel(SemiTrainArgs ta) {
         const bool okc = c < a.C;
         const float b = okc ? a.bias[c] : 0.f;
         float* drow = d + (static_cast<long long>(okc ? c : 0) * rows_out + srow) * a.T;
-        float s1 = 0.f, s2 = 0.f;
+        ShiftStat ss;
+        ss.init();
 #pragma unroll
         for (int j = 0; j < TW; ++j) {
             const float v = acc[co][j] + b;
-            if (okc && live && t0 + j < a.T) { drow[t0 + j] = (ta.out_lrelu && v < 0.f) ? v * kSlope : v; s1 += v; s2 = fmaf(v, v, s2); }
+            if (okc && live && t0 + j < a.T) { drow[t0 + j] = (ta.out_lrelu && v < 0.f) ? v * kSlope : v; ss.add(v); }
         }
-        if (okc && ta.stats) stats_commit(ta.stats, ta.stats_stride, c, s1, s2);      // (null: inference use by --p2pc_conv, no statistics)
+        if (okc && ta.stats) stats_commit(ta.stats, ta.stats_stride, c, ss);      // (null: inference use by --p2pc_conv, no statistics)
     }
 }
 
