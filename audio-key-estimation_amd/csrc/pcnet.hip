@@ -930,7 +930,7 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
     if (c.genre) { b->hid_g = cv.take<float>(2 * hid); b->map_g = cv.take<float>(B * 12 * b->Tf); }
     if (train) {
         b->stats = cv.take<double>(static_cast<size_t>(n->bn_channels) * 2 * kStatSlots);
-        b->stats2 = cv.take<double>(static_cast<size_t>(n->bn_channels) * 3 * kBwdStatSlots + n->bns.size());       // [slot][bn_channels][3], [bn layer] max |dz| bits
+        b->stats2 = cv.take<double>(static_cast<size_t>(n->bn_channels) * 3 * kBwdStatSlots + n->bns.size() * (kAmaxSlots / 2));       // [slot][bn_channels][3], then [bn layer][kAmaxSlots] unsigned: partial maxima of |dz| (float bits)
         b->gslots = cv.take<gfx_t>(static_cast<size_t>(kGradSlots) * n->grad_floats);
         b->wg_partial_floats = static_cast<size_t>(B) * 98304;                         // 384 KB per clip: e.g. two workgroups per clip x the 43 K weights of a head conv
         b->wg_partial = cv.take<float>(b->wg_partial_floats);
@@ -2661,7 +2661,7 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     AKE_REQUIRE(workspace && ws_bytes >= b.bytes, AKE_ERR_WORKSPACE, "pcnet backward: workspace %zu < %zu bytes", ws_bytes, b.bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
     AKE_HIP_CHECK(hipMemsetAsync(b.gslots, 0, sizeof(gfx_t) * n->grad_floats * kGradSlots, s));
-    AKE_HIP_CHECK(hipMemsetAsync(b.stats2, 0, sizeof(double) * (static_cast<size_t>(3) * n->bn_channels * kBwdStatSlots + n->bns.size()), s));
+    AKE_HIP_CHECK(hipMemsetAsync(b.stats2, 0, sizeof(double) * (static_cast<size_t>(3) * n->bn_channels * kBwdStatSlots + n->bns.size() * (kAmaxSlots / 2)), s));
     Bwd bw{n, b, s, b.gslots, batch};
     rc = bw.run(mel, seq_length, d_key, d_tonic, d_genre, key_out);
     if (rc) return rc;

@@ -43,7 +43,7 @@ struct Bwd {
             hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((l.C + 63) / 64), dim3(64), 0, s, st2, static_cast<long long>(3) * n->bn_channels, bst, n->blob_dev + l.gamma_off, coef,
                                grad_of(bn_name + ".weight"), grad_of(bn_name + ".bias"), l.C);
         }
-        unsigned int* cell = reinterpret_cast<unsigned int*>(b.stats2 + static_cast<size_t>(3) * n->bn_channels * kBwdStatSlots + bn);
+        unsigned int* cell = reinterpret_cast<unsigned int*>(b.stats2 + static_cast<size_t>(3) * n->bn_channels * kBwdStatSlots) + static_cast<size_t>(bn) * kAmaxSlots;
         {
             ake::ProfScope ps("bn_bwd_apply_kernel", s);
             hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, g, z, coef, ctot, coff, HT, cell);

@@ -238,10 +238,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
             g[base + i] = v;
         }
     }
-    if (!amax) return;
+    if (!amax) return;      // [kAmaxSlots] cells, one per group of clips: thousands of atomics on ONE address serialise in its L2 channel (1.5 ms per step)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f && m < INFINITY) atomicMax(amax, __float_as_uint(m));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (m > 0.f && m < INFINITY) atomicMax(amax + (clip & (kAmaxSlots - 1)), __float_as_uint(m));
+    }
 }
 
 // sum over (clip, positions) of one channel slice -> bias gradient of a convolution without BatchNorm

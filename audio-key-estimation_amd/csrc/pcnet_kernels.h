@@ -703,6 +703,14 @@ __device__ __forceinline__ float f16_weight_scale(float wmax) {
     frexpf(wmax, &e);                                         // wmax = m * 2^e, m in [0.5, 1)
     return ldexpf(1.f, 14 - e < 100 ? 14 - e : 100);          // (a channel of f32 denormals: the scale itself must stay finite)
 }
+// max |dz| of a tensor: bn_bwd_apply_kernel leaves it as kAmaxSlots partial maxima (float bits); every lane of a wave gets the maximum
+constexpr int kAmaxSlots = 64;
+__device__ __forceinline__ float amax_load(const unsigned int* cells) {
+    float m = __uint_as_float(cells[threadIdx.x & (kAmaxSlots - 1)]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return m;
+}
 __device__ __forceinline__ unsigned int f16_bits(float v) { return __builtin_bit_cast(unsigned short, static_cast<_Float16>(v)); }
 constexpr bool kP2pStreamB = true;
 constexpr int kP2pMT = 3;            // M-tiles (16 positions) per wave
@@ -1269,7 +1277,7 @@ __global__ __launch_bounds__(512) void conv_p2p_f16x3_kernel(P2pTrArgs a) {
         const bool on = a.in_aff != nullptr && c < ctot;
         asc[c] = on ? a.in_aff[3 * c] : 1.f; ash[c] = on ? a.in_aff[3 * c + 1] : 0.f; ang[c] = on ? a.in_aff[3 * c + 2] : 1.f;
     }
-    const float in_mul = (a.in_amax && !a.in_aff) ? f16_weight_scale(__uint_as_float(*a.in_amax)) : 1.f;
+    const float in_mul = (a.in_amax && !a.in_aff) ? f16_weight_scale(amax_load(a.in_amax)) : 1.f;
     if (in_mul != 1.f) {
 #pragma unroll
         for (int c = 0; c < NV; ++c) asc[c] = in_mul;
@@ -1442,6 +1450,7 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
     const int clip = blockIdx.z;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float in_mul = (F16X3 && a.in_amax) ? f16_weight_scale(amax_load(a.in_amax)) : 1.f;      // data gradients: the planes hold dz * in_mul
     const int nw = blockDim.x >> 6;
     const int r16 = lane & 15, q = lane >> 4;
     const int Tp = a.Tp;
@@ -1565,7 +1574,7 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
         const float* const bptr = second ? a.bias2 : a.bias;
         const float bias = (co < a.cout && bptr) ? bptr[co] : 0.f;
         float iscale = (F16X3 && co < a.cout) ? reinterpret_cast<const float*>(bfr + a.KH * 4 * NT * 2 * 64)[co] : 1.f;
-        if (F16X3 && a.in_amax) iscale /= f16_weight_scale(__uint_as_float(*a.in_amax));        // (powers of two: exact)
+        if (F16X3 && a.in_amax) iscale /= in_mul;        // (powers of two: exact)
         ShiftStat sstat;
         sstat.init();
         unsigned short* const oh = second ? a.oh2 : a.oh;
@@ -2002,8 +2011,8 @@ __global__ void nchw_to_cl16_f16x2_kernel(const float* __restrict__ src, long lo
                                           unsigned short* __restrict__ xh, unsigned short* __restrict__ xl, long long npos,
                                           const unsigned int* __restrict__ amax) {
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;      // (clip, row, t)
+    const float mul = amax ? f16_weight_scale(amax_load(amax)) : 1.f;        // (before the bounds check: every lane of the wave takes part)
     if (i >= npos) return;
-    const float mul = amax ? f16_weight_scale(__uint_as_float(*amax)) : 1.f;
     const int t = static_cast<int>(i % T);
     const long long r = i / T;
     const int y = static_cast<int>(r % 12);
