@@ -10,7 +10,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
 BUILD=build
 if [ "${AKE_DIAG:-0}" = 1 ]; then FLAGS="$FLAGS -DAKE_DIAG=1"; OUT=../libake_hip_diag.so; BUILD=build_diag; fi
 mkdir -p $BUILD
-HEADERS="common.h cqt_fused.h pcnet_kernels.h pcnet_bwd_kernels.h pcnet_backward.h ../../include/ake_hip.h"
+HEADERS="common.h cqt_stream.h pcnet_kernels.h pcnet_bwd_kernels.h pcnet_backward.h ../../include/ake_hip.h"
 pids=()
 for f in common.cpp cqt.hip pcnet.hip pipeline.hip optim.hip audio.hip loss.hip; do
   obj=$BUILD/${f%.*}.o

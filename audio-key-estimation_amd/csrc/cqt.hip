@@ -83,7 +83,7 @@ struct BankCall {
 
 }  // namespace
 
-#include "cqt_fused.h"
+#include "cqt_stream.h"
 
 struct ake_cqt_plan {
     ake_cqt_config cfg;
@@ -102,9 +102,7 @@ struct ake_cqt_plan {
     uint4* table2_dev = nullptr;
     int ppad = 0;                        // pad of the split planes (covers every tap window)
     size_t bank2_lds = 0;
-    std::vector<fz::Level> flv;          // engine 4: one entry per octave (ring fields are filled per launch)
-    uint4* table4_dev = nullptr;
-    uint4* toep_dev = nullptr;
+    uint4* toep5_dev = nullptr;          // engine 5: the four Toeplitz matrices of the streaming MFMA cascade (sm::build_toeplitz)
     int n_cu = 256;
 };
 
@@ -570,7 +568,7 @@ __global__ __launch_bounds__(1024) void cqt_bank_bf16_kernel(
     const int per_xcd = gridDim.x >> 3;
     const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (t >= n_frames) return;
-    const int o = blockIdx.y + o_first;                             // (engine 4 runs this kernel for the octaves below its fused four)
+    const int o = blockIdx.y + o_first;
     const OctDesc2 g = octs[o];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -710,7 +708,8 @@ int len_store(const ake_cqt_plan* p, int o, int64_t n) {   // floats stored per 
     return (static_cast<int>(l) + 2 * pad_of(p) + 3) / 4 * 4;
 }
 
-// engine 4: level-4 signal handed from the first launch to the second (f32, sample m at index m + kNextPad)
+// level 4 handed from a first launch to the deep levels' cascade launch: its sample m sits at input index m + kNextPad (engine 3's two-launch
+// cascade reads level 4's split plane that way, engine 5 an f32 copy)
 constexpr int kNextPad = 24;
 int next_len(int64_t n) { return (static_cast<int>((n + 15) / 16) + 2 * kNextPad + 3) / 4 * 4; }
 
@@ -857,149 +856,29 @@ int ake_cqt_plan_create(const ake_cqt_config* cfg_in, ake_cqt_plan** out) {
         const bool can_bf16 = can_fuse && n_oct >= 2 && n_oct - 1 <= kCascMax;
         if (want == 3 && !can_bf16) { ake::set_error("cqt: engine 3 needs 2..%d octaves and decim_half_len <= 23", kCascMax + 1); ake_cqt_plan_destroy(p); return AKE_ERR_UNSUPPORTED; }
         if (want == 2 && !can_fuse) { ake::set_error("cqt: engine 2 needs decim_half_len <= 23"); ake_cqt_plan_destroy(p); return AKE_ERR_UNSUPPORTED; }
-        // engine 4 (fused cascade + bank): 47-tap half-band, <= 8 octaves, tap windows that fit the LDS rings
-        int uh_max = 0;
-        for (int o = 0; o < n_oct; ++o) {
-            const int k0 = cfg.n_bins - bpo * (o + 1);
-            uh_max = std::max(uh_max, static_cast<int>(std::ceil(-std::floor(-len[k0] / 2.0) / (1 << o))) + 1);
-        }
-        const int w4 = (2 * uh_max + 8 + 31) / 32 * 32;
-        // ... whose parts need the windows of consecutive frames disjoint enough at each of its (up to four) levels: hop / 2^l >= window - part;
-        // the octaves below the fourth go through engine 3's cascade + bank (from level 4), which needs at least two of them
-        bool parts_ok = true;
-        for (int l = 0; l < std::min(n_oct, fz::kMaxLv); ++l) parts_ok = parts_ok && (cfg.hop_length >> l) >= w4 - 32 * fz::kPart + 16;
-        const bool can_fz = p->half_len == 23 && w4 <= 32 * fz::kMaxBlk && parts_ok &&
-                            (n_oct <= fz::kMaxLv || (n_oct >= fz::kMaxLv + 2 && n_oct <= fz::kMaxLv + kCascMax + 1));
-        if (want == 4 && !can_fz) {
-            ake::set_error("cqt: engine 4 needs decim_half_len 23, 1-4 or 6-%d octaves, tap windows <= %d samples (got %d) and hop >= %d", fz::kMaxLv + kCascMax + 1,
-                           32 * fz::kMaxBlk, w4, (w4 - 32 * fz::kPart + 16) << (std::min(n_oct, fz::kMaxLv) - 1));
+        // engine 5 (streaming MFMA cascade of levels 0..4 + engine 3's cascade for the deeper levels + engine 3's bank)
+        const bool can_sm = p->half_len == 23 && n_oct >= sm::kStages + 2 && n_oct <= sm::kStages + kCascMax + 1;
+        if (want == 5 && !can_sm) {
+            ake::set_error("cqt: engine 5 needs decim_half_len 23 and %d-%d octaves", sm::kStages + 2, sm::kStages + kCascMax + 1);
             ake_cqt_plan_destroy(p);
             return AKE_ERR_UNSUPPORTED;
         }
-        // default: engine 3.  Engine 4 is correct and tested but measured slower at the bench batch (0.30 vs 0.25 ms per 256 clips:
-        // its step loop is latency-bound at one workgroup per CU), so it runs only when asked for.
-        p->engine = (want >= 1 && want <= 4) ? want : (can_bf16 ? 3 : (can_fuse ? 2 : 1));
+        if (want == 4) { ake::set_error("cqt: engine 4 (round 2's fused LDS-ring kernel) was removed in round 3: it never beat engine 3; see engine 5"); ake_cqt_plan_destroy(p); return AKE_ERR_UNSUPPORTED; }
+        p->engine = (want >= 1 && want <= 5) ? want : (can_bf16 ? 3 : (can_fuse ? 2 : 1));
         p->cfg.engine = p->engine;
     }
-    if (p->engine == 4) {
-        auto bf16_rne = [](float v) -> uint16_t {
-            uint32_t u;
-            std::memcpy(&u, &v, 4);
-            u += 0x7FFFu + ((u >> 16) & 1u);
-            return static_cast<uint16_t>(u >> 16);
-        };
-        auto bf16_f32 = [](uint16_t hh) { uint32_t u = static_cast<uint32_t>(hh) << 16; float f; std::memcpy(&f, &u, 4); return f; };
-        // half-band Toeplitz A fragments: A[n][k] = h[k - 24 - 2n], k = 32 ks + 8 (lane >> 4) + e, n = lane & 15 (outputs P + n read inputs 2P - 24 + k)
-        std::vector<uint16_t> tp(3 * 2 * 64 * 8, 0);
-        for (int ks = 0; ks < 3; ++ks)
-            for (int ln = 0; ln < 64; ++ln)
-                for (int e = 0; e < 8; ++e) {
-                    const int jj = 32 * ks + 8 * (ln >> 4) + e - 24 - 2 * (ln & 15);
-                    float v = 0.f;
-                    if (jj == 0) v = p->taps.h0;
-                    else if (std::abs(jj) <= p->half_len && (std::abs(jj) & 1)) v = p->taps.hodd[(std::abs(jj) - 1) / 2];
-                    const uint16_t hi = bf16_rne(v);
-                    tp[((ks * 2 + 0) * 64 + ln) * 8 + e] = hi;
-                    tp[((ks * 2 + 1) * 64 + ln) * 8 + e] = bf16_rne(v - bf16_f32(hi));
-                }
-        // one filter bank per octave and per anchored phase (t * hop - uh * 2^o) mod (8 * 2^o), MFMA A-fragment order
-        // [phase][32-tap block][N-tile][hi | lo][64 lanes] x 8 bf16
-        size_t total16 = 0;                                                     // 16-byte units
-        const int n_fz = std::min(n_oct, fz::kMaxLv);
-        for (int o = 0; o < n_fz; ++o) {
-            const int dec = 1 << o;
-            fz::Level g;
-            std::memset(&g, 0, sizeof(g));
-            g.k0 = cfg.n_bins - bpo * (o + 1);
-            g.n_bins = bpo;
-            g.n_tiles = (bpo + kTileBins - 1) / kTileBins;
-            auto uh_of = [&](int k) { return static_cast<int>(std::ceil(-std::floor(-len[k] / 2.0) / dec)) + 1; };
-            g.uh = uh_of(g.k0);
-            g.n_blk = (2 * g.uh + 8 + 31) / 32;
-            for (int j = 0; j < g.n_tiles; ++j) {
-                const int uh_j = uh_of(g.k0 + kTileBins * j);
-                g.blk_lo[j] = std::max(0, (g.uh - uh_j) / 32);
-                g.blk_hi[j] = std::min(g.n_blk - 1, (g.uh + uh_j + 7) / 32);
-            }
-            const long long m8 = 8ll * dec;
-            g.period = static_cast<int>(m8 / std::gcd(static_cast<long long>(cfg.hop_length), m8));
-            g.phase_stride = static_cast<long long>(g.n_blk) * kMaxTiles * 2 * 64;
-            g.table_off = static_cast<long long>(total16);
-            total16 += static_cast<size_t>(g.period) * g.phase_stride;
-            p->flv.push_back(g);
-        }
-        std::vector<uint16_t> t4(total16 * 8, 0);
-        struct Job { int o, pi; };
-        std::vector<Job> jobs;
-        for (int o = 0; o < n_fz; ++o) for (int pi = 0; pi < p->flv[o].period; ++pi) jobs.push_back({o, pi});
-        auto fill = [&](size_t j0, size_t j1) {
-            for (size_t ji = j0; ji < j1; ++ji) {
-                const int o = jobs[ji].o, pi = jobs[ji].pi;
-                const fz::Level& g = p->flv[o];
-                const int dec = 1 << o;
-                const long long m8 = 8ll * dec;
-                long long phi = (static_cast<long long>(pi) * cfg.hop_length - static_cast<long long>(g.uh) * dec) % m8;
-                if (phi < 0) phi += m8;
-                uint16_t* dst = t4.data() + (static_cast<size_t>(g.table_off) + static_cast<size_t>(pi) * g.phase_stride) * 8;
-                for (int b = 0; b < bpo; ++b) {
-                    const int k = g.k0 + b;
-                    const int j = b / kTileBins;
-                    const double lo = std::floor(-len[k] / 2.0);
-                    const double L = std::floor(len[k] / 2.0) - lo;
-                    const double scale = dec * std::sqrt(len[k]) / (L / 2.0) / cascade_gain(freq[k], o);
-                    for (int tap = 0; tap < 32 * g.n_blk; ++tap) {
-                        const double pos = static_cast<double>(dec) * (tap - g.uh) - static_cast<double>(phi);   // full-rate offset from the frame centre
-                        if (!(pos >= lo && pos <= lo + L)) continue;
-                        const double win = 0.5 - 0.5 * std::cos(2.0 * M_PI * (pos - lo) / L);
-                        const double arg = 2.0 * M_PI * freq[k] * pos / sr;
-                        const int blk = tap / 32, qq = (tap % 32) / 8, e = tap % 8;
-                        const float vals[2] = {static_cast<float>(scale * win * std::cos(arg)), static_cast<float>(-scale * win * std::sin(arg))};
-                        for (int ri = 0; ri < 2; ++ri) {
-                            const int lane_i = qq * 16 + 2 * (b % kTileBins) + ri;
-                            const uint16_t hi = bf16_rne(vals[ri]);
-                            const size_t f = ((static_cast<size_t>(blk) * kMaxTiles + j) * 2) * 64;
-                            dst[(f + lane_i) * 8 + e] = hi;
-                            dst[(f + 64 + lane_i) * 8 + e] = bf16_rne(vals[ri] - bf16_f32(hi));
-                        }
-                    }
-                }
-            }
-        };
-        {
-            const unsigned nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-            std::vector<std::thread> pool;
-            const size_t per = (jobs.size() + nth - 1) / nth;
-            for (unsigned ti = 0; ti < nth; ++ti) {
-                const size_t j0 = std::min(jobs.size(), ti * per), j1 = std::min(jobs.size(), j0 + per);
-                if (j0 < j1) pool.emplace_back(fill, j0, j1);
-            }
-            for (auto& th : pool) th.join();
-        }
-        const char* what = "hipMalloc(table4)";
-        hipError_t e4 = hipMalloc(&p->table4_dev, t4.size() * sizeof(uint16_t));
-        if (e4 == hipSuccess) { what = "hipMalloc(toeplitz)"; e4 = hipMalloc(&p->toep_dev, tp.size() * sizeof(uint16_t)); }
-        if (e4 == hipSuccess) { what = "hipMemcpy(table4)"; e4 = hipMemcpy(p->table4_dev, t4.data(), t4.size() * sizeof(uint16_t), hipMemcpyHostToDevice); }
-        if (e4 == hipSuccess) { what = "hipMemcpy(toeplitz)"; e4 = hipMemcpy(p->toep_dev, tp.data(), tp.size() * sizeof(uint16_t), hipMemcpyHostToDevice); }
-        if (e4 == hipSuccess) {
-            what = "hipFuncSetAttribute(max dynamic LDS)";
-            const void* fns[] = {reinterpret_cast<const void*>(fz::cqt_fused_kernel<1, false>), reinterpret_cast<const void*>(fz::cqt_fused_kernel<2, false>),
-                                 reinterpret_cast<const void*>(fz::cqt_fused_kernel<3, false>), reinterpret_cast<const void*>(fz::cqt_fused_kernel<4, false>),
-                                 reinterpret_cast<const void*>(fz::cqt_fused_kernel<4, true>), reinterpret_cast<const void*>(fz::cqt_fused_kernel<4, true, true>)};
-            for (const void* f : fns)
-                if (e4 == hipSuccess) e4 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        }
-        if (e4 == hipSuccess) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) p->n_cu = prop.multiProcessorCount;
-        }
-        if (e4 != hipSuccess) {
-            ake::set_error("cqt plan (engine 4, %zu MB of phase tables): %s failed: %s", t4.size() * 2 >> 20, what, hipGetErrorString(e4));
+    if (p->engine == 5) {
+        std::vector<uint16_t> t5;
+        sm::build_toeplitz(p->taps.hodd, p->taps.n_odd, t5);
+        hipError_t e5 = hipMalloc(&p->toep5_dev, t5.size() * sizeof(uint16_t));
+        if (e5 == hipSuccess) e5 = hipMemcpy(p->toep5_dev, t5.data(), t5.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+        if (e5 != hipSuccess) {
+            ake::set_error("cqt plan (engine 5): Toeplitz upload failed: %s", hipGetErrorString(e5));
             ake_cqt_plan_destroy(p);
             return AKE_ERR_HIP;
         }
     }
-    if (p->engine == 3 || (p->engine == 4 && n_oct > fz::kMaxLv)) {        // (engine 4: for the octaves below its fused four)
+    if (p->engine == 3 || p->engine == 5) {
         auto bf16_rne = [](float v) -> uint16_t {
             uint32_t u;
             std::memcpy(&u, &v, 4);
@@ -1087,8 +966,7 @@ void ake_cqt_plan_destroy(ake_cqt_plan* p) {
     if (p->octs_dev) (void)hipFree(p->octs_dev);
     if (p->table2_dev) (void)hipFree(p->table2_dev);
     if (p->octs2_dev) (void)hipFree(p->octs2_dev);
-    if (p->table4_dev) (void)hipFree(p->table4_dev);
-    if (p->toep_dev) (void)hipFree(p->toep_dev);
+    if (p->toep5_dev) (void)hipFree(p->toep5_dev);
     delete p;
 }
 
@@ -1104,12 +982,11 @@ int64_t ake_cqt_num_frames(const ake_cqt_plan* p, int64_t n_samples) {
 size_t ake_cqt_workspace_bytes(const ake_cqt_plan* p, int batch, int64_t n_samples) {
     if (!p || batch <= 0 || n_samples <= 0) return 0;
     ake::Carver c(nullptr, 0);
-    if (p->engine == 4) {
-        if (p->n_oct > fz::kMaxLv) {
-            c.take<float>(static_cast<size_t>(batch) * next_len(n_samples));                                              // level 4, f32
-            for (int l = 0; l + fz::kMaxLv < p->n_oct; ++l)                                                               // split-bf16 levels 4.. for the bank
-                c.take<unsigned int>(static_cast<size_t>(batch) * plane_len(p, l, next_len(n_samples)));
-        }
+    if (p->engine == 5) {
+        for (int l = 0; l < sm::kStages; ++l) c.take<unsigned int>(static_cast<size_t>(batch) * plane_len(p, l, n_samples));   // split planes of levels 0..3
+        c.take<float>(static_cast<size_t>(batch) * next_len(n_samples));                                                        // level 4, f32
+        for (int l = 0; l + sm::kStages < p->n_oct; ++l)                                                                        // split planes of levels 4..
+            c.take<unsigned int>(static_cast<size_t>(batch) * plane_len(p, l, next_len(n_samples)));
     } else if (p->engine == 3) {
         for (int l = 0; l < p->n_oct; ++l) c.take<unsigned int>(static_cast<size_t>(batch) * plane_len(p, l, n_samples));   // split-bf16 level signals
     } else {
@@ -1133,7 +1010,7 @@ int ake_cqt_logmag_f32(const ake_cqt_plan* p, const float* audio, int batch, int
     return cqt_logmag_impl(p, audio, batch, n, audio_stride, nullptr, out, out_frames, workspace, ws_bytes, stream_);
 }
 
-int ake_cqt_frames_major_supported(const ake_cqt_plan* p) { return p && p->engine == 3 ? 1 : 0; }
+int ake_cqt_frames_major_supported(const ake_cqt_plan* p) { return p && (p->engine == 3 || p->engine == 5) ? 1 : 0; }
 
 int ake_cqt_logmag_frames_major_f32(const ake_cqt_plan* p, const float* audio, int batch, int64_t n, int64_t audio_stride, float* out,
                                     void* workspace, size_t ws_bytes, ake_stream_t stream_) {
@@ -1145,7 +1022,7 @@ int ake_cqt_logmag_ragged_f32(const ake_cqt_plan* p, const float* audio, int bat
                               const int64_t* n_samples_dev, float* out, int64_t out_frames, void* workspace, size_t ws_bytes,
                               ake_stream_t stream_) {
     AKE_REQUIRE(n_samples_dev, AKE_ERR_INVALID, "ake_cqt_logmag_ragged_f32: null n_samples_dev");
-    AKE_REQUIRE(p && (p->engine == 3 || p->engine == 4), AKE_ERR_UNSUPPORTED, "cqt: ragged batches need engine 3 or 4 (the defaults up to 8 octaves)");
+    AKE_REQUIRE(p && (p->engine == 3 || p->engine == 5), AKE_ERR_UNSUPPORTED, "cqt: ragged batches need engine 3 or 5 (the defaults up to 8 octaves)");
     return cqt_logmag_impl(p, audio, batch, n_max, audio_stride, n_samples_dev, out, out_frames, workspace, ws_bytes, stream_);
 }
 
@@ -1157,7 +1034,7 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
                     float* out, int64_t out_frames, void* workspace, size_t ws_bytes, ake_stream_t stream_, bool frames_major) {
     AKE_REQUIRE(p && audio && out, AKE_ERR_INVALID, "ake_cqt_logmag_f32: null argument");
     // frames_major: leave the result as the filter bank writes it, [clip][frame][bin] (no transpose pass); engine 3, equal-length clips
-    AKE_REQUIRE(!frames_major || (p->engine == 3 && !n_clip), AKE_ERR_UNSUPPORTED, "cqt: the frames-major output needs engine 3 and equal-length clips");
+    AKE_REQUIRE(!frames_major || ((p->engine == 3 || p->engine == 5) && !n_clip), AKE_ERR_UNSUPPORTED, "cqt: the frames-major output needs engine 3 or 5 and equal-length clips");
     AKE_REQUIRE(batch > 0 && n > 0 && audio_stride >= n, AKE_ERR_INVALID, "cqt: bad batch/n_samples/stride");
     AKE_REQUIRE(n < (1ll << 30), AKE_ERR_INVALID, "cqt: clip too long (%lld samples)", static_cast<long long>(n));
     const int64_t T = ake_cqt_num_frames(p, n);
@@ -1210,117 +1087,70 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
         }
         else hipLaunchKernelGGL((cqt_cascade_kernel<12, C, NT, false>), grid, dim3(NT), 0, stream, a);
     };
-    if (p->engine == 4) {
-        const bool deep = p->n_oct > fz::kMaxLv;
+    if (p->engine == 5) {
+        // levels 0..4: cqt_stream_kernel (MFMA half-band stages in registers; split planes of levels 0..3 near the frame centres + level 4 as f32)
+        sm::Args sa;
+        std::memset(&sa, 0, sizeof(sa));
+        BankCall2 call2;
+        std::memset(&call2, 0, sizeof(call2));
+        call2.pad = p->ppad;
+        sa.x = audio; sa.x_stride = audio_stride; sa.n = static_cast<int>(n); sa.n_clip = reinterpret_cast<const long long*>(n_clip); sa.batch = batch;
+        sa.ppad = p->ppad; sa.hop = p->cfg.hop_length; sa.toep = p->toep5_dev; sa.h0 = p->taps.h0;
+        if (const char* e = ake::diag_env("AKE_SM_ABLATE")) sa.dbg = std::atoi(e);
+        for (int l = 0; l < sm::kStages; ++l) {
+            const int pl = plane_len(p, l, n);
+            sa.ph[l] = c.take<unsigned int>(static_cast<size_t>(batch) * pl);
+            sa.p_stride[l] = pl; sa.p_count[l] = pl;
+            call2.xw[l] = sa.ph[l]; call2.stride[l] = pl;
+            const OctDesc2& g = p->octs2[l];
+            const long long need = static_cast<long long>(std::max(g.uh, 32 * g.n_blk - g.uh) + 8) << l;      // taps [c - uh, c - uh + 32 n_blk) around a centre c
+            sa.need[l] = 2 * need >= sa.hop ? -1 : static_cast<int>(need);
+        }
         const int n_next = next_len(n);
-        float* next = deep ? c.take<float>(static_cast<size_t>(batch) * n_next) : nullptr;
-        unsigned int* planes[kMaxOct] = {nullptr};
-        int plane_n[kMaxOct] = {0};
-        if (deep)
-            for (int l = 0; l + fz::kMaxLv < p->n_oct; ++l) {
-                plane_n[l] = plane_len(p, l, n_next);
-                planes[l] = c.take<unsigned int>(static_cast<size_t>(batch) * plane_n[l]);
-            }
-        scratch = c.take<float>(static_cast<size_t>(batch) * T * p->cfg.n_bins);
-        const int n_groups = (batch + fz::kClips - 1) / fz::kClips;
+        float* next = c.take<float>(static_cast<size_t>(batch) * n_next);
+        sa.next = next; sa.next_stride = n_next; sa.next_count = n_next; sa.pad_next = kNextPad;
+        // (everything in periods of 8 chunks: the kernel's stage parities are compile-time)
+        sa.c_begin = -static_cast<int>((((static_cast<long long>(p->ppad) + 64) * 8 + 63) / 64 + 7) / 8 * 8);  // level 3's left pad, as silence
+        sa.c_end = static_cast<int>(((n + 2048) / 64 + 9 + 7) / 8 * 8);                                        // ... and every level's tail + the pipeline's delay
+        static const int segs_env = ake::diag_env("AKE_CQT_SEGS") ? std::atoi(ake::diag_env("AKE_CQT_SEGS")) : 0;
+        const int n_groups = (batch + 15) / 16;
+        int segs = segs_env > 0 ? segs_env : std::max(1, (4 * p->n_cu + n_groups - 1) / n_groups);            // one wave per SIMD
+        sa.warm = 24;
+        const int total = sa.c_end - sa.c_begin;
+        segs = std::max(1, std::min(segs, total / (2 * sa.warm)));                                             // (short clips: warm-up must not dominate)
+        sa.chunks_per_seg = ((total + segs - 1) / segs + 7) / 8 * 8;
         {
-            fz::Args a;
-            std::memset(&a, 0, sizeof(a));
-            const int NL = std::min(fz::kMaxLv, p->n_oct);
-            a.L0 = 0; a.hop = p->cfg.hop_length; a.batch = batch; a.T = static_cast<int>(T);
-            a.n_clip = reinterpret_cast<const long long*>(n_clip);
-            a.out = scratch; a.out_clip_stride = static_cast<long long>(T) * p->cfg.n_bins; a.n_bins_total = p->cfg.n_bins;
-            a.table = p->table4_dev; a.toep = p->toep_dev;
-            if (const char* e = ake::diag_env("AKE_CQT_FZ_DBG")) a.dbg = std::atoi(e);
-            a.x = audio; a.x_stride = audio_stride; a.n_valid = n; a.pad_in = 0;
-            AKE_REQUIRE(static_cast<unsigned long long>(batch) * audio_stride * 4 < 0xFFF00000ull, AKE_ERR_UNSUPPORTED,
-                        "cqt engine 4: the audio tensor must stay below 4 GiB per call (%d clips x %lld samples): split the batch", batch,
-                        static_cast<long long>(audio_stride));
-            a.x_bytes = static_cast<unsigned>(static_cast<unsigned long long>(batch) * audio_stride * 4);
-            a.M_begin = deep ? -(16ll * kNextPad + fz::kStep - 1) / fz::kStep * fz::kStep : 0;
-            long long m_end = n + 1;                                      // exclusive end of what somebody must own (sample numbers)
-            if (deep) {
-                a.next = next; a.next_stride = n_next; a.next_count = n_next; a.pad_next = kNextPad;
-                m_end = std::max<long long>(m_end, 16ll * (n_next - kNextPad));
-            }
-            // rings: level l holds what a step produces twice over + one PART of a tap window (and at least what its cascade stage
-            // reads back), see cqt_fused.h
-            int lds_units = 0;
-            for (int l = 0; l < NL; ++l) {
-                a.lv[l] = p->flv[l];
-                static const int casc_need[4] = {312, 200, 120, 104};
-                a.lv[l].ring_units = (std::max((256 >> l) + 32 * fz::kPart, casc_need[l]) + 7) / 8;
-                a.lv[l].lds_off = lds_units;
-                lds_units += 2 * a.lv[l].ring_units * 16;
-            }
-            const size_t lds_bytes = static_cast<size_t>(lds_units) * 16 + static_cast<size_t>(fz::kStage) * fz::kNT * 16;   // rings + audio staging
-            AKE_REQUIRE(lds_bytes <= 160 * 1024, AKE_ERR_UNSUPPORTED, "cqt engine 4: rings need %zu B of LDS", lds_bytes);
-            // warm-up / tail steps: the deepest level's window reaches (uh + 8) * 2^D samples back and W - uh forward of a frame centre,
-            // its samples depend on 23 * (2^D - 1) inputs either side, and level D runs lag_D samples behind the audio
-            const int D = NL - 1;
-            const fz::Level& ld = a.lv[D];
-            const int lag_d = D == 0 ? -127 : (D == 1 ? 17 : 65);
-            a.h_pre = (((ld.uh + 8) << D) + 23 * ((1 << D) - 1) + 32 + fz::kStep - 1) / fz::kStep;
-            a.h_post = 1 + std::max(0, (((32 * ld.n_blk - ld.uh - 1 + lag_d) << D) + fz::kStep - 1) / fz::kStep);
-            if (deep) { a.h_pre = std::max(a.h_pre, 4); a.h_post = std::max(a.h_post, 9); }
-            const long long total = m_end - a.M_begin;
-            const int min_seg = 1024;
-            int n_seg = std::max(1, (p->n_cu + n_groups - 1) / n_groups);
-            n_seg = static_cast<int>(std::max<long long>(1, std::min<long long>(n_seg, total / min_seg)));
-            a.seg_len = static_cast<int>((total + n_seg - 1) / n_seg + fz::kStep - 1) / fz::kStep * fz::kStep;
-            a.n_seg = static_cast<int>((total + a.seg_len - 1) / a.seg_len);
-            const int n_wg = n_groups * a.n_seg;
-            dim3 grid((n_wg + 7) / 8 * 8);
-            ake::ProfScope ps("cqt_fused_kernel", stream);
-            static const bool stamp_env = ake::diag_env("AKE_CQT_FZ_STAMP") != nullptr;
-            if (deep && stamp_env) {
-                // diagnostic build: in-kernel cycle stamps of the step loop's sections (workgroup 0), printed to stderr; never timed
-                unsigned long long* sb = nullptr;
-                if (hipMalloc(&sb, 64 * sizeof(unsigned long long)) == hipSuccess) {
-                    (void)hipMemsetAsync(sb, 0, 64 * sizeof(unsigned long long), stream);
-                    a.stamps = sb;
-                    hipLaunchKernelGGL((fz::cqt_fused_kernel<4, true, true>), grid, dim3(fz::kNT), lds_bytes, stream, a);
-                    unsigned long long hb[64];
-                    (void)hipMemcpyAsync(hb, sb, sizeof(hb), hipMemcpyDeviceToHost, stream);
-                    (void)hipStreamSynchronize(stream);
-                    (void)hipFree(sb);
-                    for (int wv = 0; wv < 8; ++wv)
-                        fprintf(stderr, "fz stamps wave %d: steps %llu  cycles/step: barrier %.0f convert %.0f cascade %.0f banks %.0f rest %.0f\n", wv, hb[wv * 8 + 5],
-                                hb[wv * 8 + 0] / double(hb[wv * 8 + 5]), hb[wv * 8 + 1] / double(hb[wv * 8 + 5]), hb[wv * 8 + 2] / double(hb[wv * 8 + 5]),
-                                hb[wv * 8 + 3] / double(hb[wv * 8 + 5]), hb[wv * 8 + 4] / double(hb[wv * 8 + 5]));
-                }
-            } else if (deep) hipLaunchKernelGGL((fz::cqt_fused_kernel<4, true>), grid, dim3(fz::kNT), lds_bytes, stream, a);
-            else if (NL == 4) hipLaunchKernelGGL((fz::cqt_fused_kernel<4, false>), grid, dim3(fz::kNT), lds_bytes, stream, a);
-            else if (NL == 3) hipLaunchKernelGGL((fz::cqt_fused_kernel<3, false>), grid, dim3(fz::kNT), lds_bytes, stream, a);
-            else if (NL == 2) hipLaunchKernelGGL((fz::cqt_fused_kernel<2, false>), grid, dim3(fz::kNT), lds_bytes, stream, a);
-            else hipLaunchKernelGGL((fz::cqt_fused_kernel<1, false>), grid, dim3(fz::kNT), lds_bytes, stream, a);
+            dim3 grid((total + sa.chunks_per_seg - 1) / sa.chunks_per_seg, n_groups);
+            ake::ProfScope ps("cqt_stream_kernel", stream);
+            hipLaunchKernelGGL(sm::cqt_stream_kernel, grid, dim3(64), 0, stream, sa);
         }
-        if (deep) {
-            // Octaves 4.. : engine 3's streaming cascade on level 4 (as its "audio": index i <-> level-4 sample i - kNextPad, so its level l
-            // holds true level 4 + l shifted by kNextPad >> l samples -- an integer for l <= 3) and engine 3's bank on the split planes.
-            const int S = p->n_oct - fz::kMaxLv - 1;                      // half-band stages 4 -> 5 -> ...
-            CascArgs ca;
-            fill_cascade_on(ca, S, next, n_next, n_next, nullptr);
-            ca.ppad = p->ppad;
-            BankCall2 call2;
-            std::memset(&call2, 0, sizeof(call2));
-            call2.pad = p->ppad;
-            for (int l = 0; l <= S; ++l) {
-                ca.ph[l] = planes[l]; ca.p_stride[l] = plane_n[l]; ca.p_count[l] = plane_n[l];
-                ca.need[l] = -1;                                           // every sample: the tap windows of these octaves overlap
-                call2.xw[fz::kMaxLv + l] = planes[l] + (kNextPad >> l);
-                call2.stride[fz::kMaxLv + l] = plane_n[l];
-            }
-            launch_cascade(ca);
-            dim3 grid(static_cast<unsigned>((T + 7) / 8 * 8), p->n_oct - fz::kMaxLv, (batch + 255) / 256);
-            ake::ProfScope ps("cqt_bank_bf16_kernel", stream);
-            hipLaunchKernelGGL(cqt_bank_bf16_kernel, grid, dim3(1024), p->bank2_lds, stream, call2, p->octs2_dev, p->table2_dev, batch,
-                               p->cfg.hop_length, p->hop_twos, scratch, static_cast<long long>(T) * p->cfg.n_bins, p->cfg.n_bins, static_cast<int>(T), fz::kMaxLv);
+        // levels 5..: engine 3's cascade on level 4 (as its "audio": index i <-> level-4 sample i - kNextPad, so its level l holds true
+        // level 4 + l shifted by kNextPad >> l samples), which also writes level 4's own split plane
+        const int S = p->n_oct - sm::kStages - 1;
+        CascArgs ca;
+        fill_cascade_on(ca, S, next, n_next, n_next, nullptr);
+        ca.ppad = p->ppad;
+        for (int l = 0; l <= S; ++l) {
+            const int pl = plane_len(p, l, n_next);
+            ca.ph[l] = c.take<unsigned int>(static_cast<size_t>(batch) * pl);
+            ca.p_stride[l] = pl; ca.p_count[l] = pl;
+            ca.need[l] = -1;                                               // every sample: the tap windows of these octaves overlap
+            call2.xw[sm::kStages + l] = ca.ph[l] + (kNextPad >> l);
+            call2.stride[sm::kStages + l] = pl;
         }
+        launch_cascade(ca);
+        scratch = frames_major ? out : c.take<float>(static_cast<size_t>(batch) * T * p->cfg.n_bins);
+        dim3 grid(static_cast<unsigned>((T + 7) / 8 * 8), p->n_oct, (batch + 255) / 256);
+        ake::ProfScope ps("cqt_bank_bf16_kernel", stream);
+        hipLaunchKernelGGL(cqt_bank_bf16_kernel, grid, dim3(1024), p->bank2_lds, stream, call2, p->octs2_dev, p->table2_dev, batch,
+                           p->cfg.hop_length, p->hop_twos, scratch, static_cast<long long>(T) * p->cfg.n_bins, p->cfg.n_bins, static_cast<int>(T), 0);
     } else if (p->engine == 3) {
         BankCall2 call2;
         std::memset(&call2, 0, sizeof(call2));
         CascArgs a;
+        // (Round 3 tried the cascade as two launches -- stages 0..3 streaming, stages 4..6 in a small second launch reading level 4's split
+        // plane, because in-kernel stamps put half of every tick in the deep stages: the first launch went 0.155 -> 0.128 ms per 256 clips, the
+        // second took 0.025 ms whatever its segment count -- a latency chain over 6 ticks -- so the pair gained nothing and was removed.)
         fill_cascade(a, p->n_oct - 1);
         a.ppad = p->ppad;
         call2.pad = p->ppad;

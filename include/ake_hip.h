@@ -61,12 +61,12 @@ typedef struct ake_cqt_config {
     int q_mode;           /* 0: Q = (r^2+1)/(r^2-1) (librosa >= 0.10); 1: Q = 1/(r-1) (<= 0.9) */
     int decim_half_len;   /* half length of the half-band decimator; <=0 selects 23 (47 taps) */
     double decim_beta;    /* Kaiser beta of the decimator; <=0 selects 8.0 */
-    int engine;           /* 0: fastest available; 1: one kernel per decimation stage + f32 filter bank (first version, kept as
-                             the in-library cross-check); 2: fused decimator cascade + f32 bank (bit-identical to 1);
+    int engine;           /* 0: fastest available (3 where it applies); 1: one kernel per decimation stage + f32 filter bank (first version, kept
+                             as the in-library cross-check); 2: fused decimator cascade + f32 bank (bit-identical to 1);
                              3: fused cascade writing split-bf16 level signals + bf16x3 MFMA bank (needs <= 8 octaves);
-                             4 (opt-in): cascade AND bank of the top four octaves in one streaming MFMA kernel, level signals in
-                             LDS only, deeper octaves through engine 3's kernels (needs hop >= ~1700 at 8 octaves; measured
-                             slower than 3 at 256 clips, so 0 never selects it) */
+                             5 (opt-in): the half-band stages of levels 0-4 as Toeplitz products on bf16 MFMA with the clips as the N
+                             dimension, chained through registers (cqt_stream.h), deeper levels and the bank as engine 3 (6-8 octaves,
+                             47-tap decimator; measured level with engine 3 at 256 clips, so 0 never selects it).  4 was removed. */
 } ake_cqt_config;
 
 /* hop = round(sample_rate / frames_per_second) (KeyDataset.py:485), n_bins = 36 * octaves. */
