@@ -79,6 +79,7 @@ struct ake_pcnet {
     std::map<std::string, int> spec_index;
     std::vector<HostTensor> host;
     bool finalized = false;
+    bool eval_frags_stale = false;   // ake_pcnet_load_for_training_f32 skipped the MFMA fragments only the inference kernels read
     int chunk_clips = 256;
 
     // packed parameters
@@ -1517,7 +1518,7 @@ int build_fold_tables(ake_pcnet* n) {
 // with split operands; their weight fragments are derived on the device from the eval packs, after every (re)pack.
 bool pc_bf16_eligible(const PackedConv& pc) { return (pc.kh == 12 || pc.kh == 1) && pc.kw == 7 && pc.cin <= 16 && (pc.cout == 16 || pc.cout == 32); }
 
-int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
+int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s, bool train_only = false) {
     size_t count = 0;
     for (auto& layer : n->p2p)
         for (size_t j = 0; j < layer.size(); ++j) {
@@ -1623,17 +1624,22 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
         n->bf_frags_count = count;
     }
     ake::ProfScope ps("pack_bf16_kernels", s);
+    // train_only (ake_pcnet_load_for_training_f32, after every optimizer step): only the fragments the training-mode forward and the backward
+    // read -- the inference kernels' (20 of the 40 launches; 0.2 ms of a 7 ms step) are rebuilt by the next full load
+    n->eval_frags_stale = train_only;
+    if (!train_only)
     for (const auto& layer : n->p2p)
         for (const PackedConv& pc : layer)
             if (pc.bf_off >= 0)
                 hipLaunchKernelGGL(pack_p2p_f16_kernel, dim3((14 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc.w_off, n->bf_frags_dev + pc.bf_off, pc.cin);
+    if (!train_only)
     for (const PackedConv* pc : pcs)
         if (pc->bf_off >= 0) {
             const int NT = pc->cout / 16;
             hipLaunchKernelGGL(pack_pc_bf16_kernel, dim3((pc->kh * 4 * NT * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
                                n->bf_frags_dev + pc->bf_off, pc->cin, pc->cout, pc->co, NT, pc->kh);
         }
-    if (!n->pc2pc.empty())
+    if (!train_only && !n->pc2pc.empty())
         for (const PackedConv& pc : n->pc2pc[0])
             if (pc.l0_off >= 0)
                 hipLaunchKernelGGL(pack_l0_f16_kernel, dim3(3), dim3(256), 0, s, n->blob_dev + pc.w_off, n->bf_frags_dev + pc.l0_off, pc.cin, pc.cout);
@@ -1663,9 +1669,10 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s) {
             }
     for (const TrainFrag& t : tfr)
         hipLaunchKernelGGL(pack_p2p_f16_raw_kernel, dim3((14 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + t.raw, n->bf_frags_dev + t.pc->bf_off, t.cin, t.cout, t.flip);
-    for (size_t i = 1; i < n->semi.size(); ++i)
+    for (size_t i = 1; !train_only && i < n->semi.size(); ++i)
         if (n->semi[i].bf_off >= 0)
             hipLaunchKernelGGL(pack_semi_f16_kernel, dim3(1), dim3(192), 0, s, n->blob_dev + n->semi[i].w_off, n->bf_frags_dev + n->semi[i].bf_off);
+    if (!train_only)
     for (const PackedConv* pc : h1)
         if (pc->bf_off >= 0)
             hipLaunchKernelGGL(pack_head1_bf16_kernel, dim3((pc->kh * 22 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
@@ -1711,7 +1718,13 @@ int ake_pcnet_finalize(ake_pcnet* n) {
 
 // Device-resident parameters: (re)build every packed weight from a flat f32 parameter buffer on the device (layout =
 // ake_pcnet_grad_offset).  No host round trip after the first call; asynchronous on `stream`.
-int ake_pcnet_load_from_device_f32(ake_pcnet* n, const float* params_dev, ake_stream_t stream) {
+namespace {
+int load_from_device_impl(ake_pcnet* n, const float* params_dev, ake_stream_t stream, bool train_only);
+}
+int ake_pcnet_load_from_device_f32(ake_pcnet* n, const float* params_dev, ake_stream_t stream) { return load_from_device_impl(n, params_dev, stream, false); }
+int ake_pcnet_load_for_training_f32(ake_pcnet* n, const float* params_dev, ake_stream_t stream) { return load_from_device_impl(n, params_dev, stream, true); }
+namespace {
+int load_from_device_impl(ake_pcnet* n, const float* params_dev, ake_stream_t stream, bool train_only) {
     AKE_REQUIRE(n && params_dev, AKE_ERR_INVALID, "load_from_device: null argument");
     if (n->map_host.empty()) {          // first use: learn the layout (values are irrelevant; host tensors only need their sizes)
         for (size_t i = 0; i < n->specs.size(); ++i) {
@@ -1736,13 +1749,14 @@ int ake_pcnet_load_from_device_f32(ake_pcnet* n, const float* params_dev, ake_st
     }
     AKE_HIP_CHECK(hipGetLastError());
     {
-        int rc2 = rebuild_bf16_frags(n, s);
+        int rc2 = rebuild_bf16_frags(n, s, train_only);
         if (!rc2) rc2 = rebuild_dense_affine(n, params_dev, s);
         if (rc2) return rc2;
     }
     n->finalized = true;
     return AKE_OK;
 }
+}  // namespace
 
 // running_mean / running_var inside the flat parameter buffer <- momentum blend with the batch statistics that
 // ake_pcnet_forward_train_f32 returned in bn_stats (torch semantics: unbiased variance; models use momentum 0.1).
@@ -2600,6 +2614,8 @@ int forward_impl(const ake_pcnet* n, bool train, const float* mel, int batch, in
                  bool mel_frames_major = false, bool dry_run = false) {
     AKE_REQUIRE(n && mel && key_out && tonic_out, AKE_ERR_INVALID, "pcnet forward: null argument");
     AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
+    AKE_REQUIRE(train || !n->eval_frags_stale, AKE_ERR_STATE,
+                "pcnet: the last weight load was ake_pcnet_load_for_training_f32 (training fragments only): call ake_pcnet_load_from_device_f32 before inference");
     AKE_REQUIRE(batch > 0 && frames > 0, AKE_ERR_INVALID, "pcnet: bad batch/frames");
     AKE_REQUIRE(!n->cfg.genre || genre_out, AKE_ERR_INVALID, "pcnet: genre head enabled but genre_out is null");
     const int chunk = train ? batch : std::min(batch, n->chunk_clips);     // batch statistics need the whole batch at once

@@ -388,6 +388,7 @@ class PitchClassNet(LightningModule):
         self._dirty = 0              # bumped by the raw-pointer writers of the weights (fused Adam)
         self._stats_dirty = 0        # ... of the running statistics: only the eval-mode packs fold them, so a training forward need not repack
         self._h_stats_stamp = 0
+        self._h_eval_stale = False    # the handle's inference fragments are behind its weights (last load: ake_pcnet_load_for_training_f32)
 
     # ------------------------------------------------------------------ device handle
     def _float_state(self):
@@ -476,16 +477,19 @@ class PitchClassNet(LightningModule):
             # (the reference trains with 8 clips per step: repacking after every step's running-statistics update cost 0.35 ms of 3.7)
             if for_eval is None:
                 for_eval = not self.training
-            if stamp == self._h_stamp and (not for_eval or self._stats_dirty == self._h_stats_stamp):
+            if stamp == self._h_stamp and (not for_eval or (self._stats_dirty == self._h_stats_stamp and not self._h_eval_stale)):
                 return
             if not self._attached and self._h_stamp is not None:      # staged copy of foreign-dtype parameters
                 with torch.no_grad():
                     for (_, off, cnt), v in zip(layout, state):
                         self._flat[off:off + cnt].copy_(v.detach().reshape(-1))
-            _lib.check(L.ake_pcnet_load_from_device_f32(self._h, self._flat.data_ptr(), torch.cuda.current_stream().cuda_stream),
-                       "ake_pcnet_load_from_device_f32")
+            # a training forward needs only the training fragments (half of the repack launches); the next eval-mode use does the full load
+            load = L.ake_pcnet_load_from_device_f32 if for_eval else L.ake_pcnet_load_for_training_f32
+            _lib.check(load(self._h, self._flat.data_ptr(), torch.cuda.current_stream().cuda_stream), "ake_pcnet_load_from_device_f32")
             self._h_stamp = stamp
-            self._h_stats_stamp = self._stats_dirty
+            self._h_eval_stale = not for_eval
+            if for_eval:
+                self._h_stats_stamp = self._stats_dirty
 
     def _grads_in_place(self):
         """True when every p.grad is (or can be made) a view of the flat gradient buffer; prepares it for accumulation."""

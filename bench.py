@@ -375,6 +375,9 @@ def main():
                     help="untimed steps issued for this long BEFORE the W warm-up steps: the first ~0.2 s after idle run 5 %% slower (clock ramp, "
                          "first touch of the workspaces; measured: W = 5 -> 0.697, W = 50 -> 0.672, W = 300 -> 0.664 ms per step), and a serving "
                          "process is never in that state; reported on the line as config.spinup_seconds, cross-checked by 'sustained'")
+    ap.add_argument("--precision", choices=("mixed", "f32x3"), default="mixed",
+                    help="arithmetic of the inference convolutions (ake_pcnet_config.precision): 'mixed' = f16 single-product pitch / semitone / layer-0 "
+                         "convolutions + split-bf16 x 3 elsewhere (default, the headline); 'f32x3' = no operand rounded below 2^-17")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the last step's rows (profiler runs)")
     ap.add_argument("--train", action="store_true",
@@ -395,9 +398,13 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     sd = load_fixture_weights()
-    net = ake_amd.PitchClassNet(P, 12, 2, 7, Namespace(genre=True))
+    net = ake_amd.PitchClassNet(P, 12, 2, 7, Namespace(genre=True, precision=args.precision))
     net.load_state_dict(sd, strict=True)
     net = net.to(dev).eval()
+    net_dtype = net.precision_dtype()                                   # read back from the device handle (ake_pcnet_precision)
+    # the dominant kernel of each mode: the three 7x7 pitch convolutions (65 % of the MACs)
+    DOM = "conv_p2p_f16_kernel" if args.precision == "mixed" else "conv_mfma_kernel/p2p"
+    DOM_PEAK = PEAK_BF16_TFLOPS if args.precision == "mixed" else PEAK_FP32_TFLOPS
     est = ake_amd.KeyEstimator(net, SR, FRAMES, streams=args.streams)
     est1 = est if args.streams == 1 else ake_amd.KeyEstimator(net, SR, FRAMES)      # second, untimed pass: one step after the other
     B, R = args.batch, max(1, args.rotate)
@@ -421,7 +428,7 @@ def main():
     torch.cuda.synchronize()
     # timed region: hipEvents (on the launch stream) bracket only the dominant kernel -- 3 launches per step
     ake_amd._lib.lib().ake_prof_reset()
-    ake_amd._lib.prof_enable("conv_p2p_f16_kernel", True)
+    ake_amd._lib.prof_enable(DOM, True)
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -464,7 +471,7 @@ def main():
     if args.sustained_seconds > 0:
         n_sus = max(args.steps, int(args.sustained_seconds / (dt / args.steps) * 1.1) + 1)
         ake_amd._lib.lib().ake_prof_reset()
-        ake_amd._lib.prof_enable("conv_p2p_f16_kernel", True)
+        ake_amd._lib.prof_enable(DOM, True)
         D.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -475,13 +482,13 @@ def main():
         dt_sus = D.max_over_ranks(time.perf_counter() - t0, dev)
         prof_sus = ake_amd._lib.prof_results()
         ake_amd._lib.prof_enable("", False)
-        s_ms, s_n = prof_sus.get("conv_p2p_f16_kernel", (0.0, 0))
+        s_ms, s_n = prof_sus.get(DOM, (0.0, 0))
         s_tf = 2.0 * P2P_MACS_PER_CLIP * B * n_sus / (s_ms * 1e-3) / 1e12 if s_ms > 0 else None
         sustained = {"seconds": round(dt_sus, 3), "steps": n_sus, "distinct_batches": R, "resident_audio_bytes": R * B * N_SAMPLES * 4,
                      "value": round(B * world * n_sus / dt_sus, 1), "unit": "clips/s", "ms_per_step": round(dt_sus / n_sus * 1e3, 4),
                      "dominant_kernel_avg_launch_ms": round(s_ms / s_n, 4) if s_n else None,
                      "dominant_kernel_tflops": round(s_tf, 2) if s_tf else None,
-                     "dominant_kernel_frac": round(s_tf / PEAK_BF16_TFLOPS, 4) if s_tf else None}
+                     "dominant_kernel_frac": round(s_tf / DOM_PEAK, 4) if s_tf else None}
 
     # result collection (outside the timed region): 35 floats per clip, rank order
     rows = D.gather_rows(torch.cat(out, 1), B * world)
@@ -496,14 +503,14 @@ def main():
     clips = B * world * args.steps
     value = clips / dt
     # dominant kernel: the three 7x7 pitch convolutions (65 % of the network's MACs), conv_p2p_f16_kernel
-    p2p_ms, p2p_n = prof.get("conv_p2p_f16_kernel", (0.0, 0))
+    p2p_ms, p2p_n = prof.get(DOM, (0.0, 0))
     launches_per_step = p2p_n / args.steps if args.steps else 0
     p2p_flops = 2.0 * P2P_MACS_PER_CLIP * B * args.steps              # algorithmic: (5*8 + 8*8 + 8*8) * 49 MACs per position
     achieved = p2p_flops / (p2p_ms * 1e-3) / 1e12 if p2p_ms > 0 else None
     cqt_ms = sum(prof_all.get(k, (0.0, 0))[0] for k in prof_all if k.startswith("cqt_"))
     cqt_gbs = CQT_BYTES_PER_CLIP * B * args.steps / (cqt_ms * 1e-3) / 1e9 if cqt_ms > 0 else None
     kernel_ms = {k: round(v[0] / args.steps, 4) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}
-    p2p1_ms, p2p1_n = prof_all.get("conv_p2p_f16_kernel", (0.0, 0))
+    p2p1_ms, p2p1_n = prof_all.get(DOM, (0.0, 0))
     achieved1 = p2p_flops / (p2p1_ms * 1e-3) / 1e12 if p2p1_ms > 0 else None
     traffic_src, traffic, traffic_stale = pmc_traffic()
     p2p_traffic = cqt_traffic = None
@@ -515,8 +522,8 @@ def main():
         "metric": "clips/s (15 s @ 22.05 kHz), HIP CQT + PitchClassNet forward",
         "value": round(value, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 accumulation everywhere; pitch convolutions: f16 activations x f16 weights (per-channel power-of-two scaled) on MFMA; "
-                                     "pitch-class convolutions, heads and the CQT filter bank: 3-term split-bf16 on MFMA (hi*hi + lo*hi + hi*lo); outputs ~2e-5 of the float64 oracle", "data": "synthetic",
+        "vs_baseline": None, "dtype": net_dtype + "; CQT filter bank: 3-term split-bf16 on MFMA, half-band decimators exact f32", "data": "synthetic",
+        "precision": args.precision,
         "config": {"workload": f"BASELINE configs[1]: batch={B} synthetic 15 s sine-mix clips per GPU, HIP CQT (288 bins, hop 4410) "
                                f"+ default PitchClassNet inference (genre head on), audio resident in HBM",
                    "clips_per_gpu": B, "n_samples": N_SAMPLES, "frames": T_FRAMES, "weights": "tests/golden/pcnet_default.npz (seeded)",
@@ -526,12 +533,14 @@ def main():
                    "steps_in_flight": f"{args.streams}: every step is the whole path over one batch; consecutive steps go round-robin to "
                                       f"{args.streams} streams with a workspace each (KeyEstimator(streams=...))" if args.streams > 1 else "1"},
         "roofline": {"bound": "mfma",
-                     "kernel": "conv_p2p_f16_ps_kernel (persistent 7x7 circular pitch convolution, 8 channels, f16 activations x f16 weights on "
-                               "v_mfma_f32_16x16x32_f16 with f32 accumulation: 1 MFMA product per algorithmic MAC), 3 launches per step; the third "
-                               "also runs the semitone conv and the octave maximum on its output tiles and writes only the folded maps",
-                     "achieved": round(achieved, 2) if achieved else None, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4) if achieved else None,
-                     "mfma_products_per_mac": 1,
+                     "kernel": ("conv_p2p_f16_ps_kernel (persistent 7x7 circular pitch convolution, 8 channels, f16 activations x f16 weights on "
+                                "v_mfma_f32_16x16x32_f16 with f32 accumulation: 1 MFMA product per algorithmic MAC), 3 launches per step; the third "
+                                "also runs the semitone conv and the octave maximum on its output tiles and writes only the folded maps")
+                               if args.precision == "mixed" else
+                               "conv_mfma_kernel (7x7 circular pitch convolution as an implicit GEMM on v_mfma_f32_16x16x4_f32: exact f32, the vector rate), 3 launches per step",
+                     "achieved": round(achieved, 2) if achieved else None, "peak": DOM_PEAK, "unit": "TFLOP/s",
+                     "frac": round(achieved / DOM_PEAK, 4) if achieved else None,
+                     "mfma_products_per_mac": 1 if args.precision == "mixed" else None,
                      "traffic": p2p_traffic,
                      "traffic_source": f"profiles/{traffic_src}: mean HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE" if p2p_traffic else traffic_stale,
                      # mean over the three launches: (1 CQT + 4 x 36-row up_sixth channels, f32 -> 8 channels, f16), (8 -> 8, f16 both), (8 f16 -> 8
@@ -541,7 +550,7 @@ def main():
                      "avg_launch_ms": round(p2p_ms / p2p_n, 4) if p2p_n else None, "launches_per_step": launches_per_step,
                      "note": "measured in the timed region: with streams > 1 another step's kernels share the GPU with these launches" if args.streams > 1 else None,
                      "single_stream": {"achieved": round(achieved1, 2) if achieved1 else None,
-                                       "frac": round(achieved1 / PEAK_BF16_TFLOPS, 4) if achieved1 else None,
+                                       "frac": round(achieved1 / DOM_PEAK, 4) if achieved1 else None,
                                        "avg_launch_ms": round(p2p1_ms / p2p1_n, 4) if p2p1_n else None,
                                        "note": "same launches in the second, untimed pass: one step after the other on one stream"},
                      "algorithmic_flops_per_clip": 2 * P2P_MACS_PER_CLIP},

@@ -169,6 +169,10 @@ int ake_pcnet_finalize(ake_pcnet* net);
  * BatchNorm folding included, bit-identical to set_tensor + finalize -- with two kernels on `stream`; replaces
  * set_tensor/finalize for callers whose weights live on the device.  The buffer is only read during the call. */
 int ake_pcnet_load_from_device_f32(ake_pcnet* net, const float* params_dev, ake_stream_t stream);
+/* The same, but only what the TRAINING-mode entry points read (ake_pcnet_forward_train_f32, ake_pcnet_backward_f32): the MFMA fragments of the
+ * inference kernels are left stale (half of the repack launches of a training step) and inference calls return AKE_ERR_STATE until the
+ * next ake_pcnet_load_from_device_f32.  models.py:1017-1027 updates the weights every optimizer step; eval happens once per epoch. */
+int ake_pcnet_load_for_training_f32(ake_pcnet* net, const float* params_dev, ake_stream_t stream);
 /* nn.BatchNorm2d's train-mode side effect, on the flat parameter buffer: running_mean/var <- (1-m)*running + m*(batch mean,
  * UNBIASED batch variance), from the bn_stats a training forward returned.  Reference default momentum 0.1. */
 int ake_pcnet_update_running_stats_f32(const ake_pcnet* net, const float* bn_stats_dev, float* params_dev, float momentum,

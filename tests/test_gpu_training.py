@@ -365,3 +365,40 @@ def test_training_step_is_deterministic(gold_default):
     g2, w2 = run()
     assert torch.equal(g1, g2) and torch.equal(w1, w2)
     assert float(g1.abs().max()) > 0
+
+
+def test_training_only_weight_load_and_the_eval_fragments(gold_default):
+    """ake_pcnet_load_for_training_f32 (what a training step's weight sync calls: half of the repack launches) leaves the inference kernels'
+    MFMA fragments stale: the C ABI refuses inference on such a handle (AKE_ERR_STATE), and the module's next eval-mode use reloads in full --
+    outputs after three optimizer steps equal those of a fresh module loaded with the trained state_dict."""
+    net, opt = default_net(gold_default)
+    net = net.to(DEV).train()
+    optim = net.configure_optimizers()[0][0]
+    for i in range(3):
+        b = {k: v.to(DEV) for k, v in make_batch(4, 40, 500 + i).items()}
+        optim.zero_grad()
+        net.training_step(b, i)["loss"].backward()
+        optim.step()
+    b = make_batch(4, 40, 600)
+    net.train()
+    net.training_step({k: v.to(DEV) for k, v in b.items()}, 0)      # syncs the handle with the training-only load
+    assert net._h_eval_stale
+    L = _lib.lib()
+    x = b["mel"].to(DEV).contiguous()
+    seq = b["seq_length"].to(DEV)
+    outs = [torch.empty((4, 12), device=DEV), torch.empty((4, 12), device=DEV), torch.empty((4, 11), device=DEV)]
+    ws = torch.empty(int(L.ake_pcnet_workspace_bytes(net.handle, 4, 40)), dtype=torch.uint8, device=DEV)
+    rc = L.ake_pcnet_forward_f32(net.handle, x.data_ptr(), 4, 40, seq.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
+                                 ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    assert rc == -3 and b"ake_pcnet_load_from_device_f32" in L.ake_last_error()
+    net.eval()
+    with torch.no_grad():
+        got = net(x, seq)
+    assert not net._h_eval_stale
+    fresh, _ = default_net(gold_default)
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=True)
+    fresh = fresh.to(DEV).eval()
+    with torch.no_grad():
+        ref = fresh(x, seq)
+    for a, r in zip(got, ref):
+        assert torch.equal(a, r)

@@ -18,9 +18,13 @@ write_csv=$(find $out/pmc_write -name "*_counter_collection.csv" | head -1)
 stats_csv=$(find $out/stats -name "*_kernel_stats.csv" | head -1)
 [ -n "$fetch_csv" ] && [ -n "$write_csv" ] && python3 tools/pmc_traffic.py "$fetch_csv" "$write_csv" $out/pmc_traffic.json > $out/pmc_traffic.txt
 [ -n "$stats_csv" ] && python3 tools/summarize_prof.py "$stats_csv" $out/stats_bench.log $out/kernel_stats.md
+# MFMA utilisation of the network kernels (its own pass: SQ + GRBM counters with --kernel-trace only)
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_mfma -- python3 tools/net_only.py 3 > $out/pmc_mfma.log 2>&1; echo "pmc mfma rc=$?"
+python3 tools/mfma_util.py $out/pmc_mfma $out/pmc_mfma.md > /dev/null 2>&1; echo "mfma_util rc=$?"
 # the bench lines last: the PMC summary of THIS build sits in profiles/ (box-local copy; copy it to the repo's profiles/ afterwards), so
 # the line's roofline.traffic is filled from counters taken with the same kernel sources
 [ -f $out/pmc_traffic.json ] && cp $out/pmc_traffic.json profiles/${tag}_pmc_traffic.json
 timeout -k 10 300 python3 bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"
 timeout -k 10 300 python3 bench.py --train > $out/train_bench.json 2> $out/train_bench.err; echo "train bench rc=$?"
+timeout -k 10 300 python3 bench.py --precision f32x3 --no-cpu-baseline --sustained-seconds 0 --pipelined-streams 0 > $out/bench_f32x3.json 2> $out/bench_f32x3.err; echo "f32x3 bench rc=$?"
 echo "collect_round done"
