@@ -72,8 +72,18 @@ struct Bwd {
                 AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_p2p_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
                 attr_set.mark();
             }
-            ake::ProfScope ps("conv_wgrad_p2p_bf16_kernel", s);
-            hipLaunchKernelGGL(conv_wgrad_p2p_bf16_kernel, grid, dim3(256), lds, s, w);
+            const long long n_w = static_cast<long long>(8) * pc.cin * 49, n_wg = static_cast<long long>(grid.x) * B;
+            static const bool partial_off = ake::diag_env("AKE_WGRAD_ATOMIC") != nullptr;
+            const bool use_partial = !partial_off && b.wg_partial && n_wg * n_w <= static_cast<long long>(b.wg_partial_floats);
+            if (use_partial) { w.partial = b.wg_partial; w.partial_stride = n_w; }
+            {
+                ake::ProfScope ps("conv_wgrad_p2p_bf16_kernel", s);
+                hipLaunchKernelGGL(conv_wgrad_p2p_bf16_kernel, grid, dim3(256), lds, s, w);
+            }
+            if (use_partial) {
+                ake::ProfScope ps("wgrad_partial_reduce_kernel", s);
+                hipLaunchKernelGGL(wgrad_partial_reduce_kernel, dim3(static_cast<unsigned>((n_w + 63) / 64)), dim3(1024), 0, s, b.wg_partial, static_cast<int>(n_wg), n_w, dW);
+            }
             return AKE_OK;
         }
         // 12 x 7 pitch-class convolutions (the pitch-class stacks, the heads' first convs): split-bf16 MFMA, one workgroup per (clip, 16 x 16

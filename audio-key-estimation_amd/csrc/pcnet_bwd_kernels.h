@@ -783,6 +783,11 @@ struct WgradBfArgs {
     gfx_t* dW;                // [8][cin][7][7], slot 0
     long long slot_stride;
     int c0, c1, h1, cin, H, T, rows_per_wg;
+    // nullable: every workgroup stores its partial dW as plain floats at partial[(clip * gridDim.x + blockIdx.x) * partial_stride + weight] and
+    // wgrad_partial_reduce_kernel adds them in workgroup order -- instead of 3 136 fixed-point atomics per workgroup into the SAME cells from
+    // 1 024 workgroups (round 3: that flush, not the multiply, was most of this launch's 0.41 ms per convolution)
+    float* partial;
+    long long partial_stride;
 };
 
 __global__ __launch_bounds__(256) void conv_wgrad_p2p_bf16_kernel(WgradBfArgs a) {
@@ -807,8 +812,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_p2p_bf16_kernel(WgradBfArgs a)
     const float* dzc = a.dz + static_cast<long long>(clip) * 8 * a.H * a.T;
     // staging map: thread -> (channel tid >> 5, frames tl, tl + 32, tl + 64): no divisions, 3 values per operand and row in registers
     const int ch = tid >> 5, tl = tid & 31;
-    float av[3], zv[3];
-    auto fetch = [&](int yl) {                                     // raw values of a-row y0 + yl and dz row l = yl + 3
+    // Three rows of raw operands in flight (round 3): a row's loads are issued three rows before it is committed to the LDS.  With ONE row
+    // ahead (round 2) every row waited out most of a memory latency behind ~900 cycles of multiply: 72 rows per workgroup x ~1.5 us was the
+    // launch's time, three times its MFMA work.
+    float avs[3][3], zvs[3][3];
+    auto fetch = [&](int yl, float (&av)[3], float (&zv)[3]) {     // raw values of a-row y0 + yl and dz row l = yl + 3
         int zr = (y0 + yl + 3) % a.H;
         const int ya = y0 + yl;
         const bool a_ok = ch < a.cin && yl < rows;
@@ -822,7 +830,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_p2p_bf16_kernel(WgradBfArgs a)
             zv[i] = t < a.T ? zp[t] : 0.f;
         }
     };
-    auto commit = [&](int yl) {                                    // registers -> LDS: a-row copy (yl & 1), dz slot (yl + 3) & 7
+    auto commit = [&](int yl, const float (&av)[3], const float (&zv)[3]) {   // registers -> LDS: a-row copy (yl & 1), dz slot (yl + 3) & 7
         unsigned short* aH = aBase + (yl & 1) * 2 * kA;
         unsigned short* aL = aH + kA;
         const int slot = (yl + 3 + 8) & 7;
@@ -874,11 +882,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_p2p_bf16_kernel(WgradBfArgs a)
             }
         }
     }
-    fetch(0);
-    commit(0);
-    fetch(1);
+    fetch(0, avs[0], zvs[0]);
+    commit(0, avs[0], zvs[0]);
+    fetch(1, avs[1], zvs[1]);
+    fetch(2, avs[2], zvs[2]);
+    fetch(3, avs[0], zvs[0]);
     __syncthreads();
-    for (int yl = 0; yl < rows; ++yl) {
+    auto multiply = [&](int yl) {
         const unsigned short* aH = aBase + (yl & 1) * 2 * kA;
         const unsigned short* aL = aH + kA;
         const int slot = (yl - dy + 3 + 8) & 7;
@@ -899,14 +909,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_p2p_bf16_kernel(WgradBfArgs a)
                 acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[ni], 0, 0, 0);
             }
         }
-        // the next row (already in registers) goes to the other a-row copy and to the free ring slot while other waves may still
-        // multiply this one; then the row after that is requested
-        if (yl + 1 < rows) {
-            commit(yl + 1);
-            fetch(yl + 2);
+    };
+    // row yl multiplies while row yl + 1 (register set (yl + 1) % 3, loaded three rows ago) goes to the other a-row copy and the free ring
+    // slot; its registers then take row yl + 4
+#define AKE_WG_ROW(J_)                                                          \
+        if (yl < rows) {                                                         \
+            multiply(yl);                                                        \
+            if (yl + 1 < rows) {                                                 \
+                commit(yl + 1, avs[J_], zvs[J_]);                                \
+                fetch(yl + 4, avs[J_], zvs[J_]);                                 \
+            }                                                                    \
+            __syncthreads();                                                     \
+            ++yl;                                                                \
         }
-        __syncthreads();
+    for (int yl = 0; yl < rows;) {
+        AKE_WG_ROW(1) AKE_WG_ROW(2) AKE_WG_ROW(0)
     }
+#undef AKE_WG_ROW
     // flush: D[row mm = 16 * wave + 4q + i][col n = 16 * ni + r16]
     gfx_t* const dWs = grad_slot(a.dW, a.slot_stride);
 #pragma unroll
@@ -917,7 +936,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_p2p_bf16_kernel(WgradBfArgs a)
         for (int i = 0; i < 4; ++i) {
             const int mm = 16 * wave + 4 * q + i;
             const int dyy = mm >> 3, coo = mm & 7;
-            if (dyy < 7 && dx < 7 && ci < a.cin) grad_add(dWs + ((static_cast<long long>(coo) * a.cin + ci) * 7 + dyy) * 7 + dx, acc[ni][i]);
+            if (dyy < 7 && dx < 7 && ci < a.cin) {
+                const long long idx = ((static_cast<long long>(coo) * a.cin + ci) * 7 + dyy) * 7 + dx;
+                if (a.partial) a.partial[(static_cast<long long>(clip) * gridDim.x + blockIdx.x) * a.partial_stride + idx] = acc[ni][i];
+                else grad_add(dWs + idx, acc[ni][i]);
+            }
         }
     }
 }

@@ -717,6 +717,12 @@ constexpr int kP2pMT = 3;            // M-tiles (16 positions) per wave
 // a pitch conv with <= 5 input channels (the first of a stack: raw pitch stream | up_sixth channels) carries channel 0 as a split operand in
 // its idle slots 5 and 6 (pack_p2p_f16_kernel): the raw log-CQT is the one activation the trained filters difference against itself
 constexpr int kP2pSplit0 = 5;
+// a wave-uniform pointer, told to the compiler (scalar registers): loads through it take the saddr + 32-bit lane offset form
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned int lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned int>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned int>(v >> 32));
+    return reinterpret_cast<const float*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
 
 template <bool OUT_CL, bool IN_NCHW>
 __global__ __launch_bounds__(512) void conv_p2p_f16_kernel(P2pBfArgs a) {
@@ -959,6 +965,12 @@ __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel
         const int clip = tile / a.n_row_tiles;
         const int y0 = (tile - clip * a.n_row_tiles) * a.R;
         const int ctot = a.c0 + a.c1;
+        // Addressing: per channel a wave-uniform base (scalar registers), per patch position ONE 32-bit lane offset shared by all channels of a
+        // source -- the loads then take the `saddr + voffset` form and cost no vector instruction each (round 2 built a 64-bit address per load:
+        // 15 loads x ~4 vector instructions per thread and tile made this launch issue twice the vector instructions of its plane-fed siblings,
+        // profiles/r03_a_pmc_mfma.md: 19.95 M against 9.84 M).
+        const float* const pb = a.p_fm ? a.p + static_cast<long long>(clip) * T * a.H : a.p + static_cast<long long>(clip) * a.c0 * a.H * T;
+        const float* const ub = a.u + static_cast<long long>(clip) * a.c1 * a.h1 * T;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             int row = y0 - 3 + (pn[k] >> 16);
@@ -967,14 +979,13 @@ __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel
             const int t = pn[k] & 0xffff;
             // (frames-major p: one 64-byte line holds 16 bins of a frame = this tile's rows; the lanes of a request walk the frames, so
             // it costs a cache line per lane in the texture addresser, but every line is read 16 times from the L1)
-            const float* pp = a.p_fm ? a.p + (static_cast<long long>(clip) * T + t) * a.H + row
-                                     : a.p + (static_cast<long long>(clip) * a.c0 * a.H + row) * T + t;
-            const float* pu = a.u + (static_cast<long long>(clip) * a.c1 * a.h1 + row % a.h1) * T + t;
+            const int poff = a.p_fm ? t * a.H + row : row * T + t;
+            const int uoff = (row % a.h1) * T + t;
 #pragma unroll
             for (int c = 0; c < NV; ++c) {
-                const int cc = c < ctot ? c : ctot - 1;
-                const float* src = cc < a.c0 ? pp + static_cast<long long>(cc) * a.H * T : pu + static_cast<long long>(cc - a.c0) * a.h1 * T;
-                vin[k][c] = *src;                  // (channels >= ctot re-read the last one; zeroed when the patch is written)
+                const int cc = c < ctot ? c : ctot - 1;               // (channels >= ctot re-read the last one; zeroed when the patch is written)
+                const float* const base = uniform_ptr(cc < a.c0 ? pb + static_cast<long long>(cc) * a.H * T : ub + static_cast<long long>(cc - a.c0) * a.h1 * T);
+                vin[k][c] = base[static_cast<unsigned int>(cc < a.c0 ? poff : uoff)];
             }
         }
     };
