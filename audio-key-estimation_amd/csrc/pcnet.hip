@@ -554,7 +554,7 @@ bool p2p_fuses_semi(const ake_pcnet* n, int i, int P, int T) {
 // [fold_coff, fold_coff + 8) of the concat buffer dst_nchw [clip][dst_ctot][12][T] (OUT = 3); false when the shape does not allow it
 bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned short* xh, const Src* nchw, int batch, int H, int T, float* dst_nchw,
                      int dst_ctot, unsigned short* oh, const PackedConv* semi_pc, hipStream_t s, const char* name, bool p_frames_major = false,
-                     bool dry_run = false, int fold_coff = -1) {
+                     bool dry_run = false, int fold_coff = -1, bool u_f16x4 = false) {     // u_f16x4: nchw->p1 is layer 0's f16 x 4 form of the up_sixth map (Layer0Args::psix_h)
     static const bool off = ake::diag_env("AKE_P2P_PS") != nullptr && std::atoi(ake::diag_env("AKE_P2P_PS")) == 0;
     if (off) return false;
     P2pPsArgs a;
@@ -569,7 +569,13 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
         a.p = nchw->p0; a.c0 = nchw->c0; a.u = nchw->p1 ? nchw->p1 : nchw->p0; a.c1 = nchw->p1 ? nchw->c1 : 0; a.h1 = nchw->h1 > 0 ? nchw->h1 : 1;
         if (p_frames_major && nchw->c0 != 1) return false;
         a.p_fm = p_frames_major ? 1 : 0;
-    } else if (p_frames_major) return false;
+        if (u_f16x4) {
+            if (nchw->c0 != 1 || !nchw->p1 || nchw->c1 > 4) return false;
+            a.uh = reinterpret_cast<const uint2*>(nchw->p1);
+            a.ph = reinterpret_cast<const unsigned int*>(nchw->p0);
+            a.p_fm = 0;
+        }
+    } else if (p_frames_major || u_f16x4) return false;
     a.dst = dst_nchw; a.dst_clip_stride = static_cast<long long>(dst_ctot) * (semi_pc ? H / 3 : H) * T; a.oh = oh;
     if (semi_pc) {
         if (!dst_nchw || semi_pc->bf_off < 0) return false;
@@ -597,7 +603,8 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
         const void* fns[] = {reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<3, 0>),
                              reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<1, 0>), reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<1, 5>),
                              reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<1, 8>), reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<0, 0>),
-                             reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<2, 0>), reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<1, 0, true>)};
+                             reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<2, 0>), reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<1, 0, true>),
+                             reinterpret_cast<const void*>(conv_p2p_f16_ps_kernel<1, 3>)};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
         attr_set.mark();
@@ -606,12 +613,13 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
     // barrier waits run under the other's multiply loop (bound by its LDS reads)
     if (dry_run) return true;                          // (the eligibility question of ake_pcnet_accepts_frames_major)
     static const int wg_per_cu_env = ake::diag_env("AKE_P2P_WG_PER_CU") ? std::atoi(ake::diag_env("AKE_P2P_WG_PER_CU")) : 2;
-    const int wg_per_cu = (wg_per_cu_env >= 2 && !nchw && lds <= 80 * 1024 && a.n_tiles >= 4 * n_cus) ? 2 : 1;
+    const int wg_per_cu = (wg_per_cu_env >= 2 && (!nchw || a.uh) && lds <= 80 * 1024 && a.n_tiles >= 4 * n_cus) ? 2 : 1;
     dim3 grid(std::min(wg_per_cu * (n_cus / 8 * 8), (a.n_tiles + 7) / 8 * 8)), block(512);
     ake::ProfScope ps(name, s);
     if (fold) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<3, 0>), grid, block, lds, s, a);
     else if (semi_pc) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<2, 0>), grid, block, lds, s, a);
     else if (dst_nchw) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<0, 0>), grid, block, lds, s, a);
+    else if (nchw && a.uh) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<1, 3>), grid, block, lds, s, a);
     else if (nchw && a.c0 + a.c1 <= 5) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<1, 5>), grid, block, lds, s, a);
     else if (nchw) hipLaunchKernelGGL((conv_p2p_f16_ps_kernel<1, 8>), grid, block, lds, s, a);
     else {
@@ -851,6 +859,7 @@ int run_semi(const ake_pcnet* n, const PackedConv& pc, const float* src, int bat
 struct Buffers {           // workspace carve
     // per chunk (pitch stream): everything up to the last layer's semitone fold
     float* fold0 = nullptr;
+    unsigned int* melh = nullptr;   // inference: the log-CQT as f16 hi | lo words, [batch][P][T] (layer0_mfma_kernel -> conv_p2p_f16_ps_kernel<1, 3>)
     float* smap = nullptr;     // --p2pc_conv only
     float* p0 = nullptr;       // --stay_sixth only
     std::vector<float*> pcd;   // --stay_sixth only
@@ -896,6 +905,7 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
     const size_t C = chunk, B = batch;
     const size_t dg = c.denseblock ? static_cast<size_t>(c.n_filters) * c.conv_layers : 0;   // channels a dense block appends in place
     b->fold0 = cv.take<float>(B * (L == 1 ? 1 + dg : 1) * 12 * frames);
+    if (!train && L > 1) b->melh = cv.take<unsigned int>(B * P * frames);
     if (c.stay_sixth) {  // --stay_sixth: layer 0's activated semitone map is the pitch stream; dense copies of the pitch-class stream for the repeat
         b->p0 = cv.take<float>(B * (P / 3) * frames);
         b->pcd.assign(L, nullptr);
@@ -1808,6 +1818,8 @@ struct Fwd {
     hipStream_t s;
     bool train;
     bool mel_fm = false;             // mel is frames-major [clip][T][P] (ake_pcnet_forward_frames_major_f32): only the fused default path can read it
+    int chunk = 0;                   // clips per pitch_chunk call (the last one may be shorter)
+    bool psix_f16 = false;           // layer 0's launch left layer 1's up_sixth map as f16 x 4 words in psix[1] (Layer0Args::psix_h), for conv_p2p_f16_ps_kernel<1, 3>
 
     int bn_of(const std::string& name) const { return n->bn_index.at(name); }
 
@@ -2120,9 +2132,21 @@ struct Fwd {
         if (dry_run) return true;
         a.mel_fm = mel_fm ? 1 : 0;
         a.taps = g_keep_taps ? 1 : 0;
+        // the up_sixth map as f16 x 4 when the conv that reads it is the persistent f16 kernel for every chunk of this batch (it rounds to f16
+        // itself otherwise: same values); psix[1]'s buffer holds either form
+        static const bool uh_off = ake::diag_env("AKE_PSIX_F32") != nullptr;
+        psix_f16 = false;
+        if (take_mfma && b.melh && !uh_off && !g_keep_taps && !c.pc2p_mem && d1.prev_p == 1 && chunk > 0 && p2p_uses_f16(n, 1, b.Tl[1])) {
+            Src sd{mel, 1, b.psix[1], d1.prev_pc, 36};
+            unsigned short* oh = reinterpret_cast<unsigned short*>(b.pa[1]);
+            psix_f16 = run_p2p_f16_ps(n, n->p2p[1][0], nullptr, &sd, std::min(B, chunk), P, b.Tl[1], nullptr, d1.out_p, oh, nullptr, s, "", mel_fm, true, -1, true) &&
+                       (B <= chunk || B % chunk == 0 ||
+                        run_p2p_f16_ps(n, n->p2p[1][0], nullptr, &sd, B % chunk, P, b.Tl[1], nullptr, d1.out_p, oh, nullptr, s, "", mel_fm, true, -1, true));
+        }
+        if (psix_f16) { a.psix_h = reinterpret_cast<uint2*>(b.psix[1]); a.psix = nullptr; a.melh = b.melh; }
         static const int dbg_skip = ake::diag_env("AKE_L0_SKIP") ? std::atoi(ake::diag_env("AKE_L0_SKIP")) : 0;   // timing experiments only (wrong results)
         if (dbg_skip & 1) a.n_conv = 0;
-        if (dbg_skip & 2) a.psix = nullptr;
+        if (dbg_skip & 2) { a.psix = nullptr; a.psix_h = nullptr; }
         ake::ProfScope ps("layer0_fused_kernel", s);
         if (take_mfma) hipLaunchKernelGGL(layer0_mfma_kernel, dim3(B), dim3(512), lds_m, s, a);
         else hipLaunchKernelGGL(layer0_fused_kernel, dim3(B), dim3(512), lds, s, a);
@@ -2284,6 +2308,13 @@ struct Fwd {
                     unsigned short* oh = reinterpret_cast<unsigned short*>(out);
                     const bool last_conv = j == c.conv_layers - 1;
                     if (j == 0) {   // the stack's input (pitch stream | repeated up_sixth output) is assembled by the kernel's own loader
+                        if (i == 1 && psix_f16) {   // layer 0 left the up_sixth map as f16 x 4 words (8 bytes per position, clip stride 36 T words)
+                            Src sh{reinterpret_cast<const float*>(b.melh + static_cast<size_t>(c0) * P * Ti), 1,
+                                   reinterpret_cast<const float*>(reinterpret_cast<const uint2*>(b.psix[1]) + static_cast<size_t>(c0) * 36 * Ti), d.prev_pc, 36};
+                            AKE_REQUIRE(run_p2p_f16_ps(n, n->p2p[i][0], nullptr, &sh, B, P, Ti, nullptr, d.out_p, oh, nullptr, s, "conv_p2p_f16_kernel", false, false, -1, true),
+                                        AKE_ERR_STATE, "pcnet: the f16 up_sixth map has no reader for this chunk (%d clips)", B);
+                            continue;
+                        }
                         if (run_p2p_f16_ps(n, n->p2p[i][0], nullptr, &sdesc, B, P, Ti, nullptr, d.out_p, oh, nullptr, s, "conv_p2p_f16_kernel", mel_fm && i == 1)) continue;
                         AKE_REQUIRE(!mel_fm, AKE_ERR_UNSUPPORTED, "pcnet: this shape does not take the frames-major input (ake_pcnet_accepts_frames_major)");
                         if ((rc = run_p2p_f16(n, n->p2p[i][0], nullptr, &sdesc, B, P, Ti, nullptr, d.out_p, oh, s, "conv_p2p_f16_kernel")))
@@ -2627,6 +2658,7 @@ int forward_impl(const ake_pcnet* n, bool train, const float* mel, int batch, in
     if (train) AKE_HIP_CHECK(hipMemsetAsync(b.stats, 0, sizeof(double) * 2 * n->bn_channels * kStatSlots, s));
     Fwd f{n, b, s, train};
     f.mel_fm = mel_frames_major;
+    f.chunk = chunk;
     if (dry_run) {   // ake_pcnet_accepts_frames_major: would the two readers of mel take that layout for this shape?  (no launch)
         const auto& c = n->cfg;
         if (train || c.num_layers != 2 || c.resblock || c.denseblock || c.pc2p_mem || c.p2pc_conv || c.stay_sixth || c.local ||
@@ -2810,7 +2842,13 @@ static int tap_lookup(const ake_pcnet* n, const char* name, int batch, int frame
                 return set((j & 1) ? b.pb[i] : b.pa[i], d.out_p, P, Ti);
             }
         }
-        if (i >= 1 && nm == m + "up_sixth_a") return set(b.psix[i], d.prev_pc, 36, Ti);
+        if (i >= 1 && nm == m + "up_sixth_a") {
+            if (i == 1 && !g_keep_taps && !g_pc_f32_only && c.precision == AKE_PRECISION_MIXED && !c.denseblock && !c.p2pc_conv && !c.stay_sixth && !c.pc2p_mem) {
+                ake::set_error("tap: '%s' may be held as f16 words for the pitch conv that reads it; ake_debug_keep_taps(1) before the forward writes it as f32", name);
+                return AKE_ERR_INVALID;
+            }
+            return set(b.psix[i], d.prev_pc, 36, Ti);
+        }
         if (i >= 1 && nm == m + "cat") return set(b.cat[i], d.prev_pc + d.out_p, 12, Ti);
         if (i == L - 1 && i >= 1 && nm == m + "time_pool_pc") return set(b.pcf, d.out_pc, 12, b.Tf);
     }

@@ -718,10 +718,11 @@ constexpr int kP2pMT = 3;            // M-tiles (16 positions) per wave
 // its idle slots 5 and 6 (pack_p2p_f16_kernel): the raw log-CQT is the one activation the trained filters difference against itself
 constexpr int kP2pSplit0 = 5;
 // a wave-uniform pointer, told to the compiler (scalar registers): loads through it take the saddr + 32-bit lane offset form
-__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+template <typename T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) {
     const unsigned long long v = reinterpret_cast<unsigned long long>(p);
     const unsigned int lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned int>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned int>(v >> 32));
-    return reinterpret_cast<const float*>((static_cast<unsigned long long>(hi) << 32) | lo);
+    return reinterpret_cast<const T*>((static_cast<unsigned long long>(hi) << 32) | lo);
 }
 
 template <bool OUT_CL, bool IN_NCHW>
@@ -865,6 +866,8 @@ struct P2pPsArgs {
     const unsigned short* xh;     // [clip][H][T][8] f16   (IN_NCHW == false)
     const float* p;               // IN_NCHW == true: the stack's input is assembled by the loader, as in conv_p2p_f16_kernel
     const float* u;
+    const uint2* uh;              // NIN == 3: u as four f16 channels per (row, frame), [clip][h1][T] x 8 bytes (layer0_mfma_kernel's psix_h); c0 == 1
+    const unsigned int* ph;       // NIN == 3: p as f16 hi | f16 lo << 16 words, [clip][H][T] (layer0_mfma_kernel's melh)
     int c0, c1, h1;
     int p_fm;                     // p is ONE channel stored frames-major, [clip][T][H] (the CQT filter bank's own output order)
     const uint4* bfrag;           // [14 k-steps][hi|lo * 2^11][64 lanes] x 8 f16
@@ -897,13 +900,18 @@ constexpr int kP2pPsStage = 80;      // uint4 per M-tile of a wave's staging sla
 //   unit = (clip, group of R rows within an octave), tiles 36 rows apart), keeps the running maximum of the semitone outputs in
 //   registers and writes the folded maps [clip][dst channel][12][T] once per unit: neither the semitone maps (60 MB per 256 clips) nor
 //   a fold launch exist.
-// NIN: 0 = channels-last f16 plane in; else the number of f32 channels the loader assembles (5: default net, 8: any)
+// NIN: 0 = channels-last f16 plane in; else the number of f32 channels the loader assembles (5: default net, 8: any); 3 = the default net's
+//   first conv fed by layer 0's launch: the log-CQT as (f16 hi | f16 lo) words (P2pPsArgs::ph) + the repeated up_sixth map as f16 x 4
+//   (P2pPsArgs::uh): two loads, three registers and six bit operations per patch position instead of five loads, five registers and the
+//   conversions, which lets this form run two workgroups per CU like its plane-fed siblings (<1, 5>: 133 VGPRs, one workgroup per CU, 83 us
+//   against their 46; the f32 log-CQT handed over frames-major also cost it a cache line per LANE in the texture addresser)
 // STAMP: diagnostic build with s_memtime stamps around the tile loop's sections (tools/p2p_stamp.py; shares, never timed)
 template <int OUT, int NIN, bool STAMP = false>
-__global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {   // (the assembling loader's 15 input registers do not fit 128)
+__global__ __launch_bounds__(512, ((NIN > 0 && NIN != 3) ? 2 : 4)) void conv_p2p_f16_ps_kernel(P2pPsArgs a) {   // (the assembling loader's 15 input registers do not fit 128)
     constexpr bool OUT_CL = OUT == 1, OUT_SEMI = OUT == 2 || OUT == 3, OUT_FOLD = OUT == 3;
     constexpr bool IN_NCHW = NIN > 0;
-    constexpr int NV = IN_NCHW ? NIN : 1;
+    constexpr bool IN_UH = NIN == 3;
+    constexpr int NV = IN_UH ? 1 : (IN_NCHW ? NIN : 1);
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
     constexpr int MT = kP2pMT;
     const int lane = threadIdx.x & 63;
@@ -951,6 +959,8 @@ __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel
     // IN_NCHW: f32 planes -> registers (requested before the multiply loop) -> f16 channels-last patch (written after it);
     // thread -> the patch positions threadIdx.x, + 512, + 1024
     float vin[3][NV];
+    uint2 vuh[3];
+    unsigned int vw[3];
     int pn[3];
     if (IN_NCHW) {
 #pragma unroll
@@ -971,12 +981,18 @@ __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel
         // profiles/r03_a_pmc_mfma.md: 19.95 M against 9.84 M).
         const float* const pb = a.p_fm ? a.p + static_cast<long long>(clip) * T * a.H : a.p + static_cast<long long>(clip) * a.c0 * a.H * T;
         const float* const ub = a.u + static_cast<long long>(clip) * a.c1 * a.h1 * T;
+        const uint2* const uhb = IN_UH ? uniform_ptr(a.uh + static_cast<long long>(clip) * a.h1 * T) : nullptr;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             int row = y0 - 3 + (pn[k] >> 16);
             row += row < 0 ? a.H : 0;
             row -= row >= a.H ? a.H : 0;
             const int t = pn[k] & 0xffff;
+            if (IN_UH) {
+                vw[k] = uniform_ptr(a.ph + static_cast<long long>(clip) * a.H * T)[static_cast<unsigned int>(row * T + t)];
+                vuh[k] = uhb[static_cast<unsigned int>((row % a.h1) * T + t)];
+                continue;
+            }
             // (frames-major p: one 64-byte line holds 16 bins of a frame = this tile's rows; the lanes of a request walk the frames, so
             // it costs a cache line per lane in the texture addresser, but every line is read 16 times from the L1)
             const int poff = a.p_fm ? t * a.H + row : row * T + t;
@@ -996,6 +1012,16 @@ __global__ __launch_bounds__(512, (NIN > 0 ? 2 : 4)) void conv_p2p_f16_ps_kernel
         for (int k = 0; k < 3; ++k) {
             unsigned int hi[4] = {0, 0, 0, 0};
             typedef float f32x2w __attribute__((ext_vector_type(2)));
+            if (IN_UH) {        // slots: 0 the log-CQT, 1..4 the up_sixth channels, 5 / 6 the log-CQT's low half / high half again (as <1, 5>)
+                const unsigned int hb = vw[k] & 0xffffu;
+                hi[0] = hb | (vuh[k].x << 16);
+                hi[1] = (vuh[k].x >> 16) | (vuh[k].y << 16);
+                hi[2] = (vuh[k].y >> 16) | (vw[k] & 0xffff0000u);
+                hi[3] = hb;
+                const int i = threadIdx.x + 512 * k;
+                if (i < npos) wH[i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                continue;
+            }
 #pragma unroll
             for (int c = 0; c < NV; c += 2) {   // round to nearest even, two channels at a time
                 const f32x2w v = {c < ctot ? vin[k][c] : 0.f, (c + 1 < NV && c + 1 < ctot) ? vin[k][c + 1 < NV ? c + 1 : c] : 0.f};
@@ -2284,6 +2310,10 @@ struct Layer0Args {
     int taps;                    // layer0_mfma_kernel: also write the intermediate conv outputs dst[0 .. n_conv - 2] (debug taps; ake_debug_keep_taps)
     int RPp;                     // layer0_mfma_kernel: row pitch of the channels-last maps, in positions (even, >= T + 8)
     int mel_fm;                  // layer0_mfma_kernel: mel is frames-major, [clip][T][H] (the CQT filter bank's own output order)
+    uint2* psix_h;               // layer0_mfma_kernel: up_sixth's output as four f16 channels per (row, frame), [clip][36][T] x 8 bytes (channels >= NF
+                                 // zero), INSTEAD of psix: what conv_p2p_f16_ps_kernel<1, 3> loads (one 8-byte load per patch position, no conversion)
+    unsigned int* melh;          // (with psix_h) the log-CQT as f16 hi | f16 lo << 16 words in [clip][H][T] order, for the same reader: the transposition of
+                                 // a frames-major mel is paid once, here, where the clip passes through the LDS anyway
 };
 
 __global__ __launch_bounds__(512) void layer0_fused_kernel(Layer0Args a) {
@@ -2510,6 +2540,17 @@ __global__ __launch_bounds__(512) void layer0_mfma_kernel(Layer0Args a) {
         } else
             for (int i = tid; i < n4; i += 512) reinterpret_cast<float4*>(ml)[i] = mel4[i];
         __syncthreads();
+        if (a.melh) {
+            uint4* const mh = reinterpret_cast<uint4*>(a.melh + static_cast<long long>(clip) * a.H * T);
+            auto word = [](float v) {
+                const _Float16 h = static_cast<_Float16>(v);
+                return static_cast<unsigned int>(__builtin_bit_cast(unsigned short, h)) | (f16_bits(v - static_cast<float>(h)) << 16);
+            };
+            for (int i = tid; i < n4; i += 512) {
+                const float4 v = reinterpret_cast<const float4*>(ml)[i];
+                mh[i] = make_uint4(word(v.x), word(v.y), word(v.z), word(v.w));
+            }
+        }
         float w9[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) w9[i] = a.sw[i];
@@ -2608,7 +2649,32 @@ __global__ __launch_bounds__(512) void layer0_mfma_kernel(Layer0Args a) {
         out = const_cast<unsigned short*>(tmp);
     }
     // ---- layer 1's up_sixth + BN + LeakyReLU from the f32 map of the last conv ----
-    if (a.psix) {
+    if (a.psix_h) {          // ... as f16 x 4 per position (the pitch conv that reads it multiplies f16 anyway: the same values, rounded here)
+        typedef const float __attribute__((address_space(4))) cfloat;
+        cfloat* uw = (cfloat*)a.uw;
+        cfloat* ub = (cfloat*)a.ub;
+        uint2* ph = a.psix_h + static_cast<long long>(clip) * 36 * T;
+        for (int i = tid; i < 12 * T; i += 512) {
+            const int p = i / T, t = i - p * T;
+            float x[4];
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) x[ci] = fmap[(ci * 12 + p) * RP + 3 + t];
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                unsigned int h[4];
+#pragma unroll
+                for (int co2 = 0; co2 < 4; ++co2) {
+                    float acc = co2 < NF ? ub[co2 < NF ? co2 : 0] : 0.f;
+#pragma unroll
+                    for (int ci = 0; ci < 4; ++ci)
+                        if (ci < NF && co2 < NF) acc = fmaf(x[ci], uw[(ci * NF + co2) * 3 + jj], acc);
+                    acc = acc > 0.f ? acc : acc * kSlope;
+                    h[co2] = __builtin_bit_cast(unsigned short, static_cast<_Float16>(acc));
+                }
+                ph[(3 * p + jj) * T + t] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            }
+        }
+    } else if (a.psix) {
         typedef const float __attribute__((address_space(4))) cfloat;
         cfloat* uw = (cfloat*)a.uw;
         cfloat* ub = (cfloat*)a.ub;
