@@ -149,8 +149,8 @@ def test_workspace_queries_need_no_gpu():
     rc, h = _create()
     small, big = lib.ake_pcnet_workspace_bytes(h, 1, 76), lib.ake_pcnet_workspace_bytes(h, 256, 76)
     assert 0 < small < big
-    huge = lib.ake_pcnet_workspace_bytes(h, 1024, 76)          # pitch stream chunked at 256 clips; only the small
-    assert big < huge < 2 * big                                 # pitch-class tail buffers grow with the batch
+    huge = lib.ake_pcnet_workspace_bytes(h, 1024, 76)          # pitch stream chunked at 256 clips; only the small pitch-class tail buffers
+    assert big < huge < 2.1 * big                               # and layer 0's f16 copy of the log-CQT (88 KB per clip) grow with the batch
     lib.ake_pcnet_destroy(h)
 
 
