@@ -21,6 +21,10 @@ stats_csv=$(find $out/stats -name "*_kernel_stats.csv" | head -1)
 # MFMA utilisation of the network kernels (its own pass: SQ + GRBM counters with --kernel-trace only)
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_mfma -- python3 tools/net_only.py 3 > $out/pmc_mfma.log 2>&1; echo "pmc mfma rc=$?"
 python3 tools/mfma_util.py $out/pmc_mfma $out/pmc_mfma.md > /dev/null 2>&1; echo "mfma_util rc=$?"
+# CQT stage: instruction / issue counters next to the traffic of the FETCH / WRITE passes above -> the floors table (tools/cqt_floor.py)
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_cqt_a -- python3 tools/cqt_only.py 3 > $out/pmc_cqt_a.log 2>&1; echo "pmc cqt a rc=$?"
+timeout -k 10 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_cqt_b -- python3 tools/cqt_only.py 3 > $out/pmc_cqt_b.log 2>&1; echo "pmc cqt b rc=$?"
+[ -f $out/pmc_traffic.json ] && python3 tools/cqt_floor.py $out/pmc_cqt_a $out/pmc_cqt_b $out/pmc_traffic.json $out/cqt_floor.md > /dev/null 2>$out/cqt_floor.err; echo "cqt_floor rc=$?"
 # the bench lines last: the PMC summary of THIS build sits in profiles/ (box-local copy; copy it to the repo's profiles/ afterwards), so
 # the line's roofline.traffic is filled from counters taken with the same kernel sources
 [ -f $out/pmc_traffic.json ] && cp $out/pmc_traffic.json profiles/${tag}_pmc_traffic.json
