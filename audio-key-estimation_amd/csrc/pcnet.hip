@@ -204,7 +204,7 @@ PackedConv pack_conv(ake_pcnet* n, const std::vector<double>& w, const std::vect
     p.b_off = blob.size();
     blob.resize(blob.size() + static_cast<size_t>(p.groups) * p.co, 0.f);
     for (int co = 0; co < cout; ++co) blob[p.b_off + co] = static_cast<float>(b[co]);
-    if (kw == 7) {   // MFMA fragments
+    if (kw == 7 || kw == 5 || kw == 3) {   // MFMA fragments (Toeplitz in time over kw taps)
         p.tb = cout >= 9 ? 1 : (cout >= 5 ? 2 : (cout >= 2 ? 4 : 16));
         p.ku = (p.tb + kw - 1 + 3) / 4 * 4;
         p.ntiles = (cout * p.tb + 15) / 16;
@@ -353,6 +353,8 @@ int launch_mfma_t(const PackedConv& pc, const MfmaArgs& a, int MT, dim3 grid, di
     if (pc.ku == 12 && pc.nt == 1) { AKE_MFMA(12, 1, 3); }
     if (pc.ku == 24 && pc.nt == 1) { AKE_MFMA(24, 1, 3); }
     if (pc.ku == 4 && pc.nt == 1) { AKE_MFMA(4, 1, 3); }
+    if (pc.ku == 4 && pc.nt == 2) { AKE_MFMA(4, 2, 3); }          // kernel_size 3: the genre head's (1, 3) conv
+    if (pc.ku == 20 && pc.nt == 1) { AKE_MFMA(20, 1, 3); }        // kernel_size 3 / 5: the heads' one-channel last convs (16 frames per column group)
 #undef AKE_MFMA
     ake::set_error("conv: no MFMA kernel for KU=%d NT=%d", pc.ku, pc.nt);
     return AKE_ERR_UNSUPPORTED;
@@ -381,7 +383,7 @@ int run_conv(const ake_pcnet* n, const PackedConv& pc, int kind, Src src, int ba
              const float* residual = nullptr, bool rows_zero = false) {
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
-    AKE_REQUIRE(pc.kw == 7 || pc.row_k, AKE_ERR_UNSUPPORTED, "conv: kernel width %d not built (only 7)", pc.kw);
+    AKE_REQUIRE(pc.kw == 7 || pc.kw == 5 || pc.kw == 3 || pc.row_k, AKE_ERR_UNSUPPORTED, "conv: kernel width %d not built (3, 5, 7)", pc.kw);
     AKE_REQUIRE(src.c0 + src.c1 == pc.cin, AKE_ERR_STATE, "conv %s: cin mismatch", name);
     a.src0 = src.p0; a.c0 = src.c0; a.src1 = src.p1; a.c1 = src.c1; a.h1 = src.h1 > 0 ? src.h1 : 1;
     a.H = H; a.T_in = T_in;
@@ -1027,7 +1029,9 @@ int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
     AKE_REQUIRE(c.local >= 0, AKE_ERR_INVALID, "pcnet: local = pooling window of the --local heads (0: off)");
     AKE_REQUIRE(c.pitch_classes == 12, AKE_ERR_UNSUPPORTED, "pcnet: pitch_classes must be 12");
     AKE_REQUIRE(c.pitches > 0 && c.pitches % 36 == 0, AKE_ERR_INVALID, "pcnet: pitches must be a multiple of 36");
-    AKE_REQUIRE(c.kernel_size == 7, AKE_ERR_UNSUPPORTED, "pcnet: only kernel_size 7 is built");
+    // --kernel_size (train_model.py:194): 7 runs the kernels built for it; 3 and 5 run every convolution on the generic kernels (conv_mfma_kernel,
+    // conv_wgrad_kernel: kernel width is a parameter of theirs), inference and training
+    AKE_REQUIRE(c.kernel_size == 7 || c.kernel_size == 5 || c.kernel_size == 3, AKE_ERR_UNSUPPORTED, "pcnet: kernel_size %d is not built (3, 5, 7)", c.kernel_size);
     AKE_REQUIRE(c.num_layers >= 1 && c.num_layers <= 4 && c.conv_layers >= 1 && c.n_filters >= 1 && c.head_layers >= 1,
                 AKE_ERR_INVALID, "pcnet: bad layer counts");
     AKE_REQUIRE(c.time_pool_size >= 1, AKE_ERR_INVALID, "pcnet: bad time_pool_size");

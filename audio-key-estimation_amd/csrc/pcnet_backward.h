@@ -190,7 +190,7 @@ struct Bwd {
             {
                 ake::ProfScope ps(name, s);
     #define AKE_WG(M_, N_) if (!launched && MTC == M_ && NTK == N_) { hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_>), grid, block, lds, s, wa); launched = true; }
-                AKE_WG(1, 4) AKE_WG(2, 4) AKE_WG(1, 6) AKE_WG(2, 6) AKE_WG(1, 1) AKE_WG(2, 1) AKE_WG(1, 2) AKE_WG(2, 2)
+                AKE_WG(1, 4) AKE_WG(2, 4) AKE_WG(1, 6) AKE_WG(2, 6) AKE_WG(1, 1) AKE_WG(2, 1) AKE_WG(1, 2) AKE_WG(2, 2) AKE_WG(1, 3) AKE_WG(2, 3)
     #undef AKE_WG
             }
             if (!launched) {

@@ -115,7 +115,7 @@ typedef struct ake_pcnet_config {
     int pitches;        /* CQT bins = 36*octaves; models.py:653 */
     int pitch_classes;  /* 12 */
     int num_layers;     /* opt.num_layers, default 2 */
-    int kernel_size;    /* opt.kernel_size, default 7 */
+    int kernel_size;    /* opt.kernel_size, default 7; 3 and 5 are built too (every convolution then runs the generic kernels) */
     int conv_layers;    /* opt.conv_layers, default 3 */
     int n_filters;      /* opt.n_filters, default 4 */
     int head_layers;    /* opt.head_layers, default 2 */

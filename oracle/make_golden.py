@@ -362,6 +362,27 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "pcnet_denseblock_T40.npz"), opt=json.dumps(vars(opt_d)), x=xd.numpy(), seq_length=seq_d.numpy(),
                         key=kd_.numpy(), tonic=td_.numpy(), genre=gnd_.numpy(), **sd_to_npz(sd_d))
 
+    # ---------------------------------------------------------------- K: --kernel_size 3 and 5 (train_model.py:194), B=2, T=40
+    for ksz, seed_k in ((3, 77), (5, 78)):
+        print(f"K: --kernel_size {ksz} (k x k pitch convs, 12 x k pitch-class convs and heads, (2, k) genre conv; heads shrink by k - 1 per layer), B=2, T=40")
+        opt_k = default_opt(kernel_size=ksz)
+        net_k, sd_k = build_reference_net(opt_k, seed=seed_k)
+        net_k.eval()
+        gk = torch.Generator().manual_seed(150 + ksz)
+        xk = (torch.rand((2, 1, 288, 40), generator=gk) * 2.5).float()
+        seq_k = torch.tensor([40, 27])
+        kk_, tk_, gnk_ = net_k(xk.double(), seq_k)
+        okk, otk, ogk = pcnet_oracle.pcnet_forward(sd_k, xk.double(), seq_k, kernel_size=ksz)
+        report["checks"][f"K{ksz}_key"] = check(f"kernel_size {ksz} key", okk, kk_, 1e-12)
+        report["checks"][f"K{ksz}_tonic"] = check(f"kernel_size {ksz} tonic", otk, tk_, 1e-12)
+        report["checks"][f"K{ksz}_genre"] = check(f"kernel_size {ksz} genre", ogk, gnk_, 1e-12)
+        kn_, tn_, gnn_ = net_k(xk.double(), None)
+        okn, otn, ogn = pcnet_oracle.pcnet_forward(sd_k, xk.double(), None, kernel_size=ksz)
+        report["checks"][f"K{ksz}_key_noseq"] = check(f"kernel_size {ksz} key (no seq_length)", okn, kn_, 1e-12)
+        np.savez_compressed(os.path.join(GOLD, f"pcnet_k{ksz}_T40.npz"), opt=json.dumps(vars(opt_k)), x=xk.numpy(), seq_length=seq_k.numpy(),
+                            key=kk_.numpy(), tonic=tk_.numpy(), genre=gnk_.numpy(), key_noseq=kn_.numpy(), tonic_noseq=tn_.numpy(),
+                            genre_noseq=gnn_.numpy(), **sd_to_npz(sd_k))
+
     with open(os.path.join(GOLD, "PROVENANCE.json"), "w") as f:
         json.dump(report, f, indent=1)
     print("wrote", sorted(os.listdir(GOLD)))

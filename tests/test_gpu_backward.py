@@ -35,10 +35,10 @@ def loss_fn(key, tonic, genre, key_labels, tonic_idx, genre_idx, genre_mask):
     return loss
 
 
-def reference_grads(sd32, x, seq, labels, genre=True):
+def reference_grads(sd32, x, seq, labels, genre=True, kernel_size=7):
     sd = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.double() if v.is_floating_point() else v)
           for k, v in sd32.items()}
-    out = pcnet_oracle.pcnet_forward(sd, x.double(), seq, training=True)
+    out = pcnet_oracle.pcnet_forward(sd, x.double(), seq, training=True, kernel_size=kernel_size)
     loss = loss_fn(out[0], out[1], out[2] if genre else None, *labels)
     loss.backward()
     return float(loss.detach()), {k: v.grad for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad}
@@ -253,6 +253,29 @@ def test_variant_net_gradients(flag, num_layers, n_filters, conv_layers, frames,
     # gradient is a cancelling sum at 1e-5 of the others (see grad_errors) -- layer 0's pool_semi_b and, with --p2pc_conv, pool.bn
     tight = [r for r in rows if r[1] not in ("model.0.pool_semi_b.weight", "model.0.pool.bn.weight")]
     assert tight[0][0] < 3e-4 and rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
+
+
+@pytest.mark.parametrize("ksz,frames,seed", [(3, 52, 1), (3, 40, 3), (5, 52, 1), (5, 40, 2)])
+def test_kernel_size_gradients(ksz, frames, seed):
+    """--kernel_size 3 / 5 (train_model.py:194): forward in train mode, loss and every parameter's gradient against float64 autograd through the
+    oracle (which equals the reference on tests/golden/pcnet_k{3,5}_T40.npz).  Every convolution runs the generic kernels here
+    (conv_mfma_kernel with 3 / 5 taps in its Toeplitz fragments, conv_wgrad_kernel with KW = 3 / 5).  Seeds: kink-free picks of
+    tests/tools/ksize_grad_scan.py (17 of its 24 cases are tight to 2e-5 in every tensor, the others show the usual LeakyReLU flips)."""
+    opt = Namespace(conv_layers=3, n_filters=4, head_layers=2, time_pool_size=2, genre=True, max_pool=False, frames=5, kernel_size=ksz)
+    torch.manual_seed(50 + seed)
+    net = ake_amd.PitchClassNet(288, 12, 2, ksz, opt)
+    sd32 = {k: v.clone() for k, v in net.state_dict().items()}
+    assert sd32["model.1.p2p.layer.0.weight"].shape[-2:] == (ksz, ksz)
+    x, seq, labels = make_case(2, frames, seed)
+    loss_ref, ref = reference_grads(sd32, x, seq, labels, kernel_size=ksz)
+    net = net.to(DEV).train()
+    out = net(x.to(DEV), seq.to(DEV))
+    loss = loss_fn(out[0], out[1], out[2], *(t.to(DEV) for t in labels))
+    assert abs(float(loss.detach()) - loss_ref) < 2e-5 * max(1.0, abs(loss_ref))
+    loss.backward()
+    rows = grad_errors(net, ref)
+    tight = [r for r in rows if r[1] not in ILL_CONDITIONED]
+    assert tight[0][0] < 3e-5 and rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
 
 
 @pytest.mark.parametrize("with_seq", [True, False])

@@ -388,6 +388,36 @@ def test_stay_sixth_against_reference_fixture(gold_staysixth):
             assert rel_err(a.cpu(), b) < TOL
 
 
+@pytest.mark.parametrize("ksz", [3, 5])
+def test_kernel_size_3_and_5_against_reference_fixture(ksz):
+    """--kernel_size 3 / 5 (train_model.py:194): the reference's own outputs for its own seeded weights (every convolution on the generic
+    kernels: the kernel width is a parameter of theirs), with and without seq_length; then B = 24, T = 76 and the train-mode forward
+    against the oracle.  Gradients: tests/test_gpu_backward.py::test_kernel_size_gradients."""
+    from conftest import load_golden
+    gold = load_golden(f"pcnet_k{ksz}_T40.npz")
+    net, opt = make_net(gold)
+    assert opt.kernel_size == ksz and net.kernel_size == ksz
+    x = torch.from_numpy(gold["x"]).to(DEV)
+    seq = torch.from_numpy(gold["seq_length"]).to(DEV)
+    for got, name in zip(net(x, seq), ("key", "tonic", "genre")):
+        assert rel_err(got.cpu(), gold[name]) < TOL, name
+    for got, name in zip(net(x, None), ("key_noseq", "tonic_noseq", "genre_noseq")):
+        assert rel_err(got.cpu(), gold[name]) < TOL, name
+    g = torch.Generator().manual_seed(40 + ksz)
+    x2 = torch.rand((24, 1, 288, 76), generator=g) * 2.5
+    seq2 = torch.randint(30, 77, (24,), generator=g)
+    got = net(x2.to(DEV), seq2.to(DEV))
+    idx = [0, 11, 23]
+    sd64 = golden_state_dict(gold, torch.float64)
+    ref = pcnet_oracle.pcnet_forward(sd64, x2[idx].double(), seq2[idx], kernel_size=ksz)
+    for a, b in zip(got, ref):
+        assert rel_err(a[idx].cpu(), b) < TOL
+    ref_t = pcnet_oracle.pcnet_forward(sd64, x2[:6].double(), seq2[:6], kernel_size=ksz, training=True)
+    with torch.no_grad():
+        for a, b in zip(net.train()(x2[:6].to(DEV), seq2[:6].to(DEV)), ref_t):
+            assert rel_err(a.cpu(), b) < TOL
+
+
 def test_denseblock_against_reference_fixture(gold_denseblock):
     """--denseblock (models.py:188-189, 225-226, 456-648), inference: the reference's own outputs for its own seeded weights (n_filters = 2,
     conv_layers = 2), then other shapes against the oracle, then the DEFAULT widths (n_filters = 4, conv_layers = 3: 28- and 76-channel

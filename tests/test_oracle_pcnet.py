@@ -3,6 +3,7 @@ import json
 from argparse import Namespace
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import golden_state_dict
@@ -185,3 +186,17 @@ def test_running_stats_restatement_matches_torch_batchnorm():
     assert torch.allclose(y, y2, atol=1e-12)
     for k, v in bn.state_dict().items():
         assert torch.allclose(sd["p." + k].double(), v.double(), atol=1e-12), k
+
+
+@pytest.mark.parametrize("ksz", [3, 5])
+def test_kernel_size_3_and_5_against_reference_fixture(ksz):
+    """--kernel_size 3 / 5 (train_model.py:194; k x k pitch convs, 12 x k pitch-class convs and heads, (2, k) genre conv): the reference's own
+    outputs for its own seeded weights, with and without seq_length (the heads shrink the frame count by k - 1 per layer, models.py:754-760)."""
+    from conftest import load_golden
+    gold = load_golden(f"pcnet_k{ksz}_T40.npz")
+    sd = golden_state_dict(gold, torch.float64)
+    assert sd["model.1.p2p.layer.0.weight"].shape[-2:] == (ksz, ksz) and sd["key_classifier.0.conv2d.weight"].shape[-2:] == (12, ksz)
+    x = torch.from_numpy(gold["x"]).double()
+    for seq, sfx in ((torch.from_numpy(gold["seq_length"]), ""), (None, "_noseq")):
+        for got, name in zip(pcnet_oracle.pcnet_forward(sd, x, seq, kernel_size=ksz), ("key", "tonic", "genre")):
+            assert np.abs(got.numpy() - gold[name + sfx]).max() <= 1e-12, (name, sfx)
