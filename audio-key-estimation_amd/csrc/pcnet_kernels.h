@@ -70,7 +70,9 @@ constexpr int kStatSlots = 64;
 // The cells keep their old size: a `double` cell holds a long long.
 constexpr double kFxStat = 16777216.0;            // 2^24: sums of activations and their squares (|sum| < 5.5e11, i.e. an rms of 300 over
                                                   // 5.6 M positions; resolution 6e-8 per partial sum = < 1e-9 of a variance; overflow -> NaN, below)
-constexpr double kFxGrad = 1099511627776.0;       // 2^40: gradient-side sums (|sum| < 8.4e6, resolution 9.1e-13)
+constexpr double kFxGrad = 1099511627776.0;       // 2^40: gradient-side sums, resolution 9.1e-13.  Trusted range |sum| < 2^61 / 2^40 = 2.1e6 (fx_checked below: beyond it
+                                                  // the value read back is NaN -- a NaN gradient, which Adam propagates into the weights, is this path's overflow signal;
+                                                  // the reference's float64 sums stay finite there, so a caller with raw gradients of that size scales the loss)
 typedef long long gfx_t;                          // a gradient slot cell
 __device__ __forceinline__ void fx_add(long long* cell, double v, double scale) {
     atomicAdd(reinterpret_cast<unsigned long long*>(cell), static_cast<unsigned long long>(__double2ll_rn(v * scale)));

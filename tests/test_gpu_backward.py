@@ -44,13 +44,17 @@ def reference_grads(sd32, x, seq, labels, genre=True, kernel_size=7):
     return float(loss.detach()), {k: v.grad for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad}
 
 
+FLOORED = ("model.0.pool_semi_b.weight", "model.0.pool.bn.weight")
+
+
 def grad_errors(net, ref):
     """[(max|g - ref| / max|ref|, name, max|ref|)], worst first.  Convolution biases in front of a BatchNorm have an
     exactly-zero gradient (the mean subtraction removes them): there the device must return (near) zero too."""
     rows = []
-    # a tensor whose whole gradient is four orders of magnitude below the step's largest one is a cancelling sum of ~1e6 float32 terms:
-    # its absolute accuracy is set by the others' scale (measured: model.0.pool_semi_b.weight of the one-layer net, max |ref| 1.1e-6
-    # next to 4e-2, moves by 1e-7 when the summation order of a reduction changes), so the error is taken relative to at least that
+    # gamma of a BatchNorm whose (positively homogeneous) output goes straight into a convolution + BatchNorm: the loss does not depend on it,
+    # its gradient is a cancelling sum of ~1e6 float32 terms that should be ZERO (measured: model.0.pool_semi_b.weight of the one-layer net, max
+    # |ref| 1.1e-6 next to 4e-2, moves by 1e-7 when the summation order of a reduction changes) -- only for these is the error taken relative to
+    # the step's largest gradient (x 1e-4); every other tensor is measured against its own size (ADVICE r2), however small it is
     floor = 1e-4 * max(float(ref[name].abs().max()) for name, _ in net.named_parameters())
     for name, p in net.named_parameters():
         g = p.grad.detach().cpu().double()
@@ -58,7 +62,8 @@ def grad_errors(net, ref):
         if name.endswith(".bias") and float(r.abs().max()) < 1e-9:
             assert float(g.abs().max()) < 1e-6, name
             continue
-        rows.append((float((g - r).abs().max()) / max(float(r.abs().max()), floor, 1e-7), name, float(r.abs().max())))
+        scale = max(float(r.abs().max()), floor if name in FLOORED else 0.0, 1e-7)
+        rows.append((float((g - r).abs().max()) / scale, name, float(r.abs().max())))
     rows.sort(reverse=True)
     return rows
 
@@ -192,8 +197,9 @@ def test_three_layer_net_gradients(n_filters, seed):
     assert abs(float(loss.detach()) - loss_ref) < 2e-5 * max(1.0, abs(loss_ref))
     loss.backward()
     rows = grad_errors(net, ref)
-    # model.0.pool_semi_b.weight: max |ref| ~1e-6 next to O(1) gradients, a cancelling sum (see grad_errors)
-    tight = [r for r in rows if r[1] != "model.0.pool_semi_b.weight"]
+    # model.0.pool_semi_b.weight: max |ref| ~1e-6 next to O(1) gradients, a cancelling sum (see grad_errors); with ONE filter the same holds for
+    # the single-channel BatchNorm inside layer 0's stack (its scale is removed by the next BatchNorm: the exact gradient is zero, |ref| 1.1e-6)
+    tight = [r for r in rows if r[1] != "model.0.pool_semi_b.weight" and not (n_filters == 1 and r[1] == "model.0.pc2pc.layer.1.weight")]
     assert tight[0][0] < 3e-4 and rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
 
 
