@@ -553,7 +553,12 @@ def main():
                                        "frac": round(achieved1 / DOM_PEAK, 4) if achieved1 else None,
                                        "avg_launch_ms": round(p2p1_ms / p2p1_n, 4) if p2p1_n else None,
                                        "note": "same launches in the second, untimed pass: one step after the other on one stream"},
-                     "algorithmic_flops_per_clip": 2 * P2P_MACS_PER_CLIP},
+                     "algorithmic_flops_per_clip": 2 * P2P_MACS_PER_CLIP,
+                     # `peak` is the data-sheet figure the contract asks for.  What a pure v_mfma_f32_16x16x32_f16 stream (4 waves per SIMD, nothing
+                     # else issued) sustains on this part, measured by tools/micro/mfma_data_power.hip: 1 365 TFLOP/s with zero operands, 1 185 with
+                     # random ones, whether the launch lasts 0.25 ms or 180 ms (profiles/r03_b_mfma_data_power.txt)
+                     "measured_mfma_stream_tflops": {"zero_operands": 1365.0, "random_operands": 1185.0, "source": "profiles/r03_b_mfma_data_power.txt",
+                                                     "frac_of_random": round(achieved / 1185.0, 4) if achieved else None}},
         "roofline_cqt": {"bound": "hbm", "kernels": " + ".join(sorted(k for k in prof_all if k.startswith("cqt_"))), "achieved": round(cqt_gbs, 1) if cqt_gbs else None,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(cqt_gbs / PEAK_HBM_GBS, 4) if cqt_gbs else None,
                          "traffic": cqt_traffic, "algorithmic_bytes_per_step": CQT_BYTES_PER_CLIP * B, "algorithmic_bytes_per_clip": CQT_BYTES_PER_CLIP,
