@@ -64,7 +64,12 @@ struct LayerDims {
 // activation in FRONT of each is a row table (scale, shift, negative slope) in ake_pcnet::dense_aff_dev that the kernel applies on load.
 struct DensePack {
     PackedConv c1, c2;       // 1-wide bottleneck (stored as 7 taps, centre one non-zero), k-wide convolution
-    size_t aff1 = 0, aff2 = 0;   // float offsets of the two tables
+    size_t aff1 = 0, aff2 = 0;   // float offsets of the two (eval-mode) tables
+    // training: the two BatchNorm layers (indices into ake_pcnet::bns), the data-gradient packs (transposed + flipped weights, stored like c1 / c2)
+    // and the parameter names
+    int bn1 = -1, bn2 = -1;
+    PackedConv d1, d2;
+    std::string norm1, norm2, w1, w2, b2;       // b2 empty: bias=False (the plain Conv2d form)
 };
 
 int pick_co(int cout) { return cout >= 8 ? 8 : (cout >= 2 ? 4 : 1); }
@@ -252,14 +257,29 @@ PackedConv fold_pack(ake_pcnet* n, const std::string& conv_prefix, const std::st
 
 // --denseblock: a convolution with its raw weights (no BatchNorm behind it); a 1-wide kernel is stored as 7 taps with only the centre
 // one non-zero, so that the 7-tap Toeplitz kernels run it (bkey empty: bias=False)
+PackedConv dense_conv_pack_w(ake_pcnet* n, const std::vector<float>& w32, const std::vector<float>* b32p, int cout, int cin, int kh, int kw_src);
 PackedConv dense_conv_pack(ake_pcnet* n, const std::string& wkey, const std::string& bkey, int cout, int cin, int kh, int kw_src) {
+    return dense_conv_pack_w(n, T(n, wkey), bkey.empty() ? nullptr : &T(n, bkey), cout, cin, kh, kw_src);
+}
+// the data-gradient pack of such a convolution: the weights transposed (cin <-> cout) and flipped on both axes, stored the same way
+PackedConv dense_dgrad_pack(ake_pcnet* n, const std::string& wkey, int cout, int cin, int kh, int kw_src) {
     const auto& w32 = T(n, wkey);
+    std::vector<float> w(static_cast<size_t>(cin) * cout * kh * kw_src);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int dy = 0; dy < kh; ++dy)
+                for (int dx = 0; dx < kw_src; ++dx)
+                    w[((static_cast<size_t>(ci) * cout + co) * kh + (kh - 1 - dy)) * kw_src + (kw_src - 1 - dx)] =
+                        w32[((static_cast<size_t>(co) * cin + ci) * kh + dy) * kw_src + dx];
+    return dense_conv_pack_w(n, w, nullptr, cin, cout, kh, kw_src);
+}
+PackedConv dense_conv_pack_w(ake_pcnet* n, const std::vector<float>& w32, const std::vector<float>* b32p, int cout, int cin, int kh, int kw_src) {
     std::vector<double> w(static_cast<size_t>(cout) * cin * kh * 7, 0.0), b(cout, 0.0);
     for (size_t r = 0; r < static_cast<size_t>(cout) * cin * kh; ++r) {
         if (kw_src == 7) for (int dx = 0; dx < 7; ++dx) w[r * 7 + dx] = w32[r * 7 + dx];
         else w[r * 7 + 3] = w32[r];
     }
-    if (!bkey.empty()) { const auto& b32 = T(n, bkey); for (int co = 0; co < cout; ++co) b[co] = b32[co]; }
+    if (b32p) { const auto& b32 = *b32p; for (int co = 0; co < cout; ++co) b[co] = b32[co]; }
     if (kw_src == 1 && kh % 4 == 0) {   // 12 x 1: fragments [ci][row group g < kh / 4][ntile][64 lanes], lane = (k = row 4g + (l >> 4), n = co)
         PackedConv p;
         p.cin = cin; p.cout = cout; p.kh = kh; p.kw = 1; p.co = pick_co(cout); p.groups = (cout + p.co - 1) / p.co;
@@ -362,7 +382,7 @@ int launch_mfma_t(const PackedConv& pc, const MfmaArgs& a, int MT, dim3 grid, di
 
 // inference launches carry none of the training-mode code (pending BatchNorm on load, statistics, accumulation)
 int launch_mfma(const PackedConv& pc, const MfmaArgs& a, int MT, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-    const bool train = a.c.in_affine || a.c.stats || a.c.accumulate;
+    const bool train = a.c.in_affine || a.c.stats || a.c.accumulate || a.c.rows_zero;      // (rows_zero: only the TRAIN form's loader zero-pads the rows)
     return train ? launch_mfma_t<true>(pc, a, MT, grid, block, lds, s) : launch_mfma_t<false>(pc, a, MT, grid, block, lds, s);
 }
 
@@ -891,6 +911,11 @@ struct Buffers {           // workspace carve
     float* g_map[3] = {nullptr, nullptr, nullptr};
     float *g_hid = nullptr, *g_pcf = nullptr, *g_fold0 = nullptr;
     std::vector<float*> g_pc, g_cat, g_semi, g_p, g_pin, g_psix;      // per layer (g_pc / g_p: ping-pong pair packed as 2x)
+    // --denseblock training: per block [pitch-class block of layer i | pitch block of layer i] and dense layer: the bottleneck map (kept for
+    // the backward pass) and the two on-load tables (norm1 over the block's features so far, norm2 over the bottleneck map); one gradient
+    // buffer of the widest bottleneck per block kind
+    std::vector<std::vector<float*>> dn_bott_pc, dn_aff1_pc, dn_aff2_pc, dn_bott_p, dn_aff1_p, dn_aff2_p;
+    float *dn_gbott_pc = nullptr, *dn_gbott_p = nullptr;
 };
 
 // chunk = clips per pitch-stream pass, batch = clips of the call (tail buffers)
@@ -966,7 +991,7 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
             }
             b->aff_semi[i] = cv.take<float>(3 * cs);
             // --resblock: [conv0, (conv1 (2C), conv2, block output) per block] (res_stack_train); gradients: g, skip copy, 2C hidden map
-            const int n_st = c.resblock ? 1 + 3 * c.conv_layers : c.conv_layers;
+            const int n_st = c.denseblock ? 0 : (c.resblock ? 1 + 3 * c.conv_layers : c.conv_layers);
             auto width = [&](int j) { return c.resblock && j % 3 == 1 ? 2 : 1; };
             for (int j = 0; j < n_st; ++j) {
                 b->pcst[i].push_back(cv.take<float>(width(j) * B * pc_out * 12 * Ti));
@@ -976,7 +1001,7 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
             if (i >= 1) {
                 b->aff_cat[i] = cv.take<float>(3 * (d.prev_pc + d.out_p));
                 b->aff_p2pin[i] = cv.take<float>(3 * (d.prev_pc + d.prev_p));
-                b->g_cat[i] = cv.take<float>(B * (d.prev_pc + d.out_p) * 12 * Ti);
+                b->g_cat[i] = cv.take<float>(B * (d.prev_pc + d.out_p + dg) * 12 * Ti);
                 for (int j = 0; j < n_st; ++j) {
                     b->pst[i].push_back(cv.take<float>(width(j) * B * d.out_p * P * Ti));
                     b->aff_pst[i].push_back(cv.take<float>(3 * width(j) * d.out_p));
@@ -985,6 +1010,31 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
                 b->g_pin[i] = cv.take<float>(B * (d.prev_p + d.prev_pc) * P * Ti);
                 b->g_psix[i] = cv.take<float>(B * d.prev_pc * 36 * Ti);
             }
+        }
+        if (c.denseblock) {
+            for (auto* v : {&b->dn_bott_pc, &b->dn_aff1_pc, &b->dn_aff2_pc, &b->dn_bott_p, &b->dn_aff1_p, &b->dn_aff2_p}) v->assign(L, {});
+            size_t gb_pc = 0, gb_p = 0;
+            for (int i = 0; i < L; ++i) {
+                const int Ti = b->Tl[i];
+                const auto& d = n->dims[i];
+                for (size_t j = 0; j < n->dense_pc[i].size(); ++j) {
+                    const DensePack& dp = n->dense_pc[i][j];
+                    b->dn_bott_pc[i].push_back(cv.take<float>(B * dp.c1.cout * 12 * Ti));
+                    b->dn_aff1_pc[i].push_back(cv.take<float>(3 * static_cast<size_t>(dp.c1.cin)));
+                    b->dn_aff2_pc[i].push_back(cv.take<float>(3 * static_cast<size_t>(dp.c1.cout)));
+                    gb_pc = std::max(gb_pc, B * dp.c1.cout * 12 * Ti);
+                }
+                for (size_t j = 0; i >= 1 && j < n->dense_p[i].size(); ++j) {
+                    const DensePack& dp = n->dense_p[i][j];
+                    b->dn_bott_p[i].push_back(cv.take<float>(B * dp.c1.cout * P * Ti));
+                    b->dn_aff1_p[i].push_back(cv.take<float>(3 * static_cast<size_t>(dp.c1.cin)));
+                    b->dn_aff2_p[i].push_back(cv.take<float>(3 * static_cast<size_t>(dp.c1.cout)));
+                    gb_p = std::max(gb_p, B * dp.c1.cout * P * Ti);
+                }
+                (void)d;
+            }
+            b->dn_gbott_pc = cv.take<float>(gb_pc);
+            b->dn_gbott_p = cv.take<float>(gb_p);
         }
         b->g_fold0 = cv.take<float>(B * 12 * frames);
         b->g_pcf = cv.take<float>(B * n->final_ch * 12 * b->Tf);
@@ -1023,8 +1073,8 @@ int ake_pcnet_create(const ake_pcnet_config* cfg, ake_pcnet** out) {
     AKE_REQUIRE(cfg && out, AKE_ERR_INVALID, "ake_pcnet_create: null argument");
     const ake_pcnet_config& c = *cfg;
     AKE_REQUIRE(!c.only_semitones, AKE_ERR_UNSUPPORTED, "pcnet: the only_semitones variant is not built");
-    AKE_REQUIRE(!(c.denseblock && (c.resblock || c.pc2p_mem || c.p2pc_conv || c.stay_sixth || c.local)), AKE_ERR_UNSUPPORTED,
-                "pcnet: denseblock together with resblock / pc2p_mem / p2pc_conv / stay_sixth / local is not built");
+    AKE_REQUIRE(!(c.denseblock && (c.resblock || c.pc2p_mem || c.p2pc_conv || c.stay_sixth || c.local || c.kernel_size != 7)), AKE_ERR_UNSUPPORTED,
+                "pcnet: denseblock together with resblock / pc2p_mem / p2pc_conv / stay_sixth / local / kernel_size != 7 is not built");
     AKE_REQUIRE(!(c.stay_sixth && c.pc2p_mem), AKE_ERR_UNSUPPORTED, "pcnet: stay_sixth together with pc2p_mem is not built");
     AKE_REQUIRE(c.local >= 0, AKE_ERR_INVALID, "pcnet: local = pooling window of the --local heads (0: off)");
     AKE_REQUIRE(c.pitch_classes == 12, AKE_ERR_UNSUPPORTED, "pcnet: pitch_classes must be 12");
@@ -1240,6 +1290,9 @@ static void build_packs(ake_pcnet* n, bool train) {
             const std::string lp = base + "denselayer" + std::to_string(j + 1) + ".";
             const int cj = cin + j * nf;
             DensePack dp;
+            dp.norm1 = lp + "norm1"; dp.norm2 = lp + "norm2";
+            dp.w1 = lp + (equiv ? "conv1.conv2d.weight" : "conv1.weight"); dp.w2 = lp + (equiv ? "conv2.conv2d.weight" : "conv2.weight");
+            dp.b2 = equiv ? lp + "conv2.conv2d.bias" : "";
             dp.aff1 = table(lp + "norm1", cj, 0.01f);                                  // relu1 = nn.LeakyReLU, models.py:463 / :526
             dp.c1 = equiv ? dense_conv_pack(n, lp + "conv1.conv2d.weight", lp + "conv1.conv2d.bias", bott, cj, 12, 1)
                           : dense_conv_pack(n, lp + "conv1.weight", "", bott, cj, 1, 1);
@@ -1263,6 +1316,19 @@ static void build_packs(ake_pcnet* n, bool train) {
         n->bns.push_back(l);
         n->bn_channels += C;
         return "";
+    };
+    // --denseblock, training pass: the blocks' BatchNorm layers in forward order and the data-gradient packs (the convolutions themselves
+    // keep their raw weights in both modes: the eval packs serve the training forward)
+    auto dense_block_train = [&](int cin, bool equiv, std::vector<DensePack>& packs) {
+        const int nf = c.n_filters;
+        for (size_t j = 0; j < packs.size(); ++j) {
+            DensePack& dp = packs[j];
+            const int cj = cin + static_cast<int>(j) * nf, bott = dp.c1.cout;
+            bn(dp.norm1, cj); dp.bn1 = n->bn_index.at(dp.norm1);
+            bn(dp.norm2, bott); dp.bn2 = n->bn_index.at(dp.norm2);
+            dp.d1 = dense_dgrad_pack(n, dp.w1, bott, cj, equiv ? 12 : 1, 1);
+            dp.d2 = dense_dgrad_pack(n, dp.w2, nf, bott, equiv ? 12 : k, k);
+        }
     };
     for (int i = 0; i < L; ++i) {
         const std::string m = "model." + std::to_string(i) + ".";
@@ -1298,6 +1364,7 @@ static void build_packs(ake_pcnet* n, bool train) {
                 }
             }
             if (c.denseblock && !train) dense_block(m + "p2p.layer.0.", d.prev_pc + d.prev_p, false, n->dense_p[i]);
+            if (c.denseblock && train) dense_block_train(d.prev_pc + d.prev_p, false, n->dense_p[i]);
             for (int j = 0; j < c.conv_layers && !c.resblock && !c.denseblock; ++j) {
                 const int cin_j = j == 0 ? (c.pc2p_mem ? d.prev_p : d.prev_pc + d.prev_p) : d.out_p;
                 p2p[i].push_back(fold_pack(n, m + "p2p.layer." + std::to_string(3 * j), bn(m + "p2p.layer." + std::to_string(3 * j + 1), d.out_p),
@@ -1334,6 +1401,7 @@ static void build_packs(ake_pcnet* n, bool train) {
             }
         }
         if (c.denseblock && !train) dense_block(m + "pc2pc.layer.0.", pc_in, true, n->dense_pc[i]);
+        if (c.denseblock && train) dense_block_train(pc_in, true, n->dense_pc[i]);
         for (int j = 0; j < c.conv_layers && !c.resblock && !c.denseblock; ++j) {
             pc2pc[i].push_back(fold_pack(n, m + "pc2pc.layer." + std::to_string(3 * j) + ".conv2d",
                                          bn(m + "pc2pc.layer." + std::to_string(3 * j + 1), pc_out), pc_out, j == 0 ? pc_in : pc_out, 12, k));
@@ -1880,6 +1948,47 @@ struct Fwd {
         return AKE_OK;
     }
 
+    // ... in TRAINING mode (batch statistics).  BatchNorm sits in FRONT of both convolutions here, so every norm1 needs the statistics of
+    // features other kernels produced: the block input's are taken by channel_stats_kernel, a layer's new features leave theirs in the NEXT
+    // layer's norm1 cells (conv2's statistics epilogue) and every later norm1 copies the prefix it shares (stats_copy_kernel).  The
+    // bottleneck maps and both tables of every layer stay in the workspace for the backward pass.
+    int dense_stack_train(const std::vector<DensePack>& packs, int kind, float* feat, int ctot, int cin, int B, int H, int T,
+                          const std::vector<float*>& botts, const std::vector<float*>& aff1s, const std::vector<float*>& aff2s, const char* label) {
+        const int nf = n->cfg.n_filters, k = n->cfg.kernel_size;
+        const double count = static_cast<double>(B) * H * T;
+        const int sstride = 2 * n->bn_channels;
+        int rc;
+        {
+            ake::ProfScope ps("channel_stats_kernel", s);
+            hipLaunchKernelGGL(channel_stats_kernel, dim3(cin, 1, B), dim3(256), 0, s, feat, static_cast<long long>(ctot) * H * T, static_cast<long long>(H) * T,
+                               b.stats + 2 * n->bns[packs[0].bn1].ch_off, sstride);
+        }
+        for (size_t j = 0; j < packs.size(); ++j) {
+            const DensePack& dp = packs[j];
+            const int cj = cin + static_cast<int>(j) * nf;
+            AKE_REQUIRE(dp.c1.cin == cj && cj + nf <= ctot && dp.bn1 >= 0 && dp.bn2 >= 0, AKE_ERR_STATE, "dense %s: channel bookkeeping (training)", label);
+            if (j > 0) {   // the statistics of channels [0, cj - nf): the previous norm1 has them (its own copy or the block input's)
+                const int C = cj - nf;
+                ake::ProfScope ps("stats_copy_kernel", s);
+                hipLaunchKernelGGL(stats_copy_kernel, dim3((kStatSlots * 2 * C + 255) / 256), dim3(256), 0, s, b.stats, sstride,
+                                   n->bns[packs[j - 1].bn1].ch_off, n->bns[dp.bn1].ch_off, C);
+            }
+            finalize_bn(dp.bn1, count, aff1s[j], kSlope);                              // relu1 = nn.LeakyReLU
+            Src s1{feat, cj, nullptr, 0, 0, ctot};
+            const ConvGeom g1{0, 3, T, H, 0};
+            if ((rc = run_conv(n, dp.c1, kind, s1, B, H, T, true, false, botts[j], dp.c1.cout, 0, s, label, aff1s[j], b.stats + 2 * n->bns[dp.bn2].ch_off,
+                               kind == 0 ? &g1 : nullptr)))
+                return rc;
+            finalize_bn(dp.bn2, count, aff2s[j], 0.f);                                 // relu2 = nn.ReLU
+            const ConvGeom g2{k / 2, k / 2, T, H, 0};
+            double* next_stats = j + 1 < packs.size() ? b.stats + 2 * (n->bns[packs[j + 1].bn1].ch_off + cj) : nullptr;
+            if ((rc = run_conv(n, dp.c2, kind, Src{botts[j], dp.c1.cout, nullptr, 0, 0}, B, H, T, true, false, feat, ctot, cj, s, label, aff2s[j], next_stats,
+                               kind == 0 ? &g2 : nullptr, false, nullptr, kind == 0)))
+                return rc;
+        }
+        return AKE_OK;
+    }
+
     // --resblock stack (models.py:181-187 / 218-224, 402-454), inference: st = [conv0, (conv1, conv2) per block].  x lives in X
     // (C channels, dense), a block's hidden map (2C channels) in Hb; conv2 adds x before its LeakyReLU, in place -- the last block
     // may write channels [0, C) of a wider buffer instead (final_dst with final_ctot channels).
@@ -2175,6 +2284,14 @@ struct Fwd {
             float* feat = L == 1 ? b.fold0 : b.cat[1];
             if ((rc = semi(0, mel, nullptr, B, P, T0, feat, ctot1, 0, nullptr))) return rc;
             if (L == 1) return AKE_OK;                           // its block runs in the tail
+            if (train) {
+                AKE_REQUIRE(L == 2, AKE_ERR_UNSUPPORTED, "pcnet: training a --denseblock net is built for num_layers 2 (got %d)", L);
+                if ((rc = dense_stack_train(n->dense_pc[0], 1, feat, ctot1, 1, B, 12, T0, b.dn_bott_pc[0], b.dn_aff1_pc[0], b.dn_aff2_pc[0], "conv_mfma_kernel/pc2pc0")))
+                    return rc;
+                // the raw up_sixth map + its table (rows [prev_p, ..) of the pitch block's input table, as in the default net)
+                up_sixth(1, feat, static_cast<long long>(ctot1) * 12 * T0, nullptr, B, n->dims[1].prev_pc, T0, b.psix[1], b.aff_p2pin[1] + 3 * n->dims[1].prev_p);
+                return AKE_OK;
+            }
             if ((rc = dense_stack(n->dense_pc[0], 1, feat, ctot1, 1, B, 12, T0, b.pca[0], "conv_mfma_kernel/pc2pc0"))) return rc;
             up_sixth(1, feat, static_cast<long long>(ctot1) * 12 * T0, nullptr, B, n->dims[1].prev_pc, T0, b.psix[1], nullptr);
             return AKE_OK;
@@ -2238,9 +2355,12 @@ struct Fwd {
                     const long long total = static_cast<long long>(B) * (cp + d.prev_pc) * P * Ti;
                     ake::ProfScope ps("concat_repeat_kernel", s);
                     hipLaunchKernelGGL(concat_repeat_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, p_cur, cp, psixd, d.prev_pc, 36,
-                                       fp, d.out_p, P, Ti, total);
+                                       fp, d.out_p, P, Ti, total, train ? b.aff_p2pin[i] + 3 * d.prev_p : nullptr);
                 }
-                if ((rc = dense_stack(n->dense_p[i], 0, fp, d.out_p, cp + d.prev_pc, B, P, Ti, b.pb[i], "conv_mfma_kernel/p2p"))) return rc;
+                if (train) {
+                    if ((rc = dense_stack_train(n->dense_p[i], 0, fp, d.out_p, cp + d.prev_pc, B, P, Ti, b.dn_bott_p[i], b.dn_aff1_p[i], b.dn_aff2_p[i], "conv_mfma_kernel/p2p")))
+                        return rc;
+                } else if ((rc = dense_stack(n->dense_p[i], 0, fp, d.out_p, cp + d.prev_pc, B, P, Ti, b.pb[i], "conv_mfma_kernel/p2p"))) return rc;
                 if ((rc = semi(i, fp, nullptr, B, P, Ti, catd, ctd, d.prev_pc, nullptr))) return rc;
                 if (last) return AKE_OK;                                              // its pitch-class block + pooling + heads run batch-wide
                 if ((rc = dense_stack(n->dense_pc[i], 1, catd, ctd, d.prev_pc + d.out_p, B, 12, Ti, b.pca[i], "conv_mfma_kernel/pc2pc"))) return rc;
@@ -2451,10 +2571,15 @@ struct Fwd {
         }
         if (c.denseblock) {   // the last layer's pitch-class block, in place on its concat buffer: the features are the buffer itself
             float* feat_buf = L == 1 ? b.fold0 : b.cat[i];
-            if ((rc = dense_stack(n->dense_pc[i], 1, feat_buf, n->final_ch, cin, B, 12, Ti, b.pca[i],
-                                  L == 1 ? "conv_mfma_kernel/pc2pc0" : "conv_mfma_kernel/pc2pc")))
+            if (train) {
+                AKE_REQUIRE(L == 2, AKE_ERR_UNSUPPORTED, "pcnet: training a --denseblock net is built for num_layers 2 (got %d)", L);
+                if ((rc = dense_stack_train(n->dense_pc[i], 1, feat_buf, n->final_ch, cin, B, 12, Ti, b.dn_bott_pc[i], b.dn_aff1_pc[i], b.dn_aff2_pc[i],
+                                            "conv_mfma_kernel/pc2pc")))
+                    return rc;
+            } else if ((rc = dense_stack(n->dense_pc[i], 1, feat_buf, n->final_ch, cin, B, 12, Ti, b.pca[i],
+                                         L == 1 ? "conv_mfma_kernel/pc2pc0" : "conv_mfma_kernel/pc2pc")))
                 return rc;
-            pdst = feat_buf;
+            pdst = feat_buf; pdst_aff = nullptr;
         }
         for (int j = 0; j < c.conv_layers && !pc_fused && !c.resblock && !c.denseblock; ++j) {
             pdst = train ? b.pcst[i][j] : ((j & 1) ? b.pcb[i] : b.pca[i]);
@@ -2705,8 +2830,8 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     AKE_REQUIRE(n && mel && key_out && d_key && d_tonic && grads_out, AKE_ERR_INVALID, "pcnet backward: null argument");
     AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
     AKE_REQUIRE(!n->cfg.genre || d_genre, AKE_ERR_INVALID, "pcnet backward: genre head enabled but d_genre is null");
-    AKE_REQUIRE(!(n->cfg.denseblock || (n->cfg.p2pc_conv && n->cfg.stay_sixth)), AKE_ERR_UNSUPPORTED,
-                "pcnet: training a --denseblock (or --p2pc_conv --stay_sixth) net is not built");
+    AKE_REQUIRE(!(n->cfg.p2pc_conv && n->cfg.stay_sixth), AKE_ERR_UNSUPPORTED, "pcnet: training a --p2pc_conv --stay_sixth net is not built");
+    AKE_REQUIRE(!n->cfg.denseblock || n->cfg.num_layers == 2, AKE_ERR_UNSUPPORTED, "pcnet: training a --denseblock net is built for num_layers 2 (got %d)", n->cfg.num_layers);
     Buffers b;
     int rc = plan_buffers(n, batch, batch, frames, workspace, &b, true);
     if (rc) return rc;
@@ -2773,8 +2898,9 @@ int ake_pcnet_forward_frames_major_f32(const ake_pcnet* n, const float* mel_fm, 
 int ake_pcnet_forward_train_f32(const ake_pcnet* n, const float* mel, int batch, int frames, const int64_t* seq_length,
                                 float* key_out, float* tonic_out, float* genre_out, float* bn_stats_out, void* workspace,
                                 size_t ws_bytes, ake_stream_t stream) {
-    AKE_REQUIRE(!n || !(n->cfg.denseblock || (n->cfg.p2pc_conv && n->cfg.stay_sixth)), AKE_ERR_UNSUPPORTED,
-                "pcnet: training a --denseblock (or --p2pc_conv --stay_sixth) net is not built (inference only)");
+    AKE_REQUIRE(!n || !(n->cfg.p2pc_conv && n->cfg.stay_sixth), AKE_ERR_UNSUPPORTED, "pcnet: training a --p2pc_conv --stay_sixth net is not built (inference only)");
+    AKE_REQUIRE(!n || !n->cfg.denseblock || n->cfg.num_layers == 2, AKE_ERR_UNSUPPORTED, "pcnet: training a --denseblock net is built for num_layers 2 (got %d)",
+                n ? n->cfg.num_layers : 0);
     return forward_impl(n, true, mel, batch, frames, seq_length, key_out, tonic_out, genre_out, bn_stats_out, workspace, ws_bytes, stream);
 }
 

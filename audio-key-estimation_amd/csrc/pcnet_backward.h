@@ -52,10 +52,11 @@ struct Bwd {
     }
 
     // weight gradient of one convolution: dW += corr(act(input), dz)
+    // zero_pad (kind 0 only): the convolution pads rows AND frames with zeros (--denseblock's plain Conv2d) instead of wrapping both
     int wgrad(const PackedConv& pc, int kind, Src src, const float* in_aff, int H, int T_in, bool same_time, const float* dz, int dz_ctot,
-              int dz_coff, gfx_t* dW, const char* name) {
+              int dz_coff, gfx_t* dW, const char* name, bool zero_pad = false) {
         static const bool wg_f32 = ake::diag_env("AKE_WGRAD_F32") != nullptr;
-        if (!wg_f32 && kind == 0 && pc.kh == 7 && pc.kw == 7 && pc.cout == 8 && pc.cin <= 8 && T_in <= kWgMaxT && dz_ctot == 8 && dz_coff == 0) {
+        if (!wg_f32 && !zero_pad && kind == 0 && pc.kh == 7 && pc.kw == 7 && pc.cout == 8 && pc.cin <= 8 && T_in <= kWgMaxT && dz_ctot == 8 && dz_coff == 0 && src.ctot0 == 0) {
             WgradBfArgs w;
             std::memset(&w, 0, sizeof(w));
             w.src0 = src.p0; w.c0 = src.c0; w.src1 = src.p1; w.c1 = src.c1; w.h1 = src.h1 > 0 ? src.h1 : 1;
@@ -135,9 +136,9 @@ struct Bwd {
             ConvArgs& a = wa.c;
             a.src0 = src.p0; a.c0 = src.c0; a.src1 = src.p1; a.c1 = src.c1; a.h1 = src.h1 > 0 ? src.h1 : 1;
             a.H = H; a.T_in = T_in;
-            a.src0_clip_stride = static_cast<long long>(src.c0) * H * T_in;
+            a.src0_clip_stride = static_cast<long long>(src.ctot0 > 0 ? src.ctot0 : src.c0) * H * T_in;
             a.src1_clip_stride = static_cast<long long>(src.c1) * a.h1 * T_in;
-            if (kind == 0) { a.py = pc.kh / 2; a.pad_l = pc.kw / 2; a.time_circ = 1; a.T_out = T_in; a.H_out = H; }
+            if (kind == 0) { a.py = pc.kh / 2; a.pad_l = pc.kw / 2; a.time_circ = zero_pad ? 0 : 1; a.rows_zero = zero_pad ? 1 : 0; a.T_out = T_in; a.H_out = H; }
             else {
                 a.py = 0; a.time_circ = 0;
                 a.pad_l = same_time ? pc.kw / 2 : 0;
@@ -244,6 +245,101 @@ struct Bwd {
         }
         return run_conv(n, pd, kind == 0 ? 0 : 1, Src{dz, pd.cin, nullptr, 0, 0}, B, H, T_dz, true, false, dst, dst_ctot, dst_coff, s, name,
                         nullptr, nullptr, &g, accumulate);
+    }
+
+    // --denseblock (models.py:456-648): one block backwards, in place on g_feat [B][ctot][H][T] = dL/d(features), complete for the channels the
+    // block appended when this is called; on return channels [0, cin) hold dL/d(block input) ADDED to what they held.  Layer j (last first):
+    //   its new features' gradient (channels [cj, cj + nf)) -> conv2 (weights, bias; data gradient into g_bott) -> norm2 + ReLU -> conv1 (weights;
+    //   data gradient into the first cj channels of g_scr, a buffer of g_feat's shape) -> norm1 + LeakyReLU over ALL cj channels it read
+    //   (in place in g_scr) -> added to g_feat[0, cj): the channel-sliced accumulate of a dense connection.
+    int dense_block_backward(const std::vector<DensePack>& packs, int kind, const float* feat, int ctot, int cin, int H, int T, float* g_feat,
+                             float* g_bott, float* g_scr, const std::vector<float*>& botts, const std::vector<float*>& aff1s,
+                             const std::vector<float*>& aff2s, const char* wname, const char* dname) {
+        const int nf = n->cfg.n_filters, k = n->cfg.kernel_size;
+        const long long HT = static_cast<long long>(H) * T;
+        int rc;
+        for (int j = static_cast<int>(packs.size()) - 1; j >= 0; --j) {
+            const DensePack& dp = packs[j];
+            const int cj = cin + j * nf, bott = dp.c1.cout;
+            // ---- conv2: new = conv2(relu(norm2(bott_j))) ----
+            PackedConv t2 = dp.c2;                         // true kernel size for the weight gradient (the pack may store 7 taps)
+            t2.kh = kind == 1 ? 12 : k; t2.kw = k;
+            if ((rc = wgrad(t2, kind, Src{botts[j], bott, nullptr, 0, 0}, aff2s[j], H, T, true, g_feat, ctot, cj, grad_of(dp.w2), wname, kind == 0))) return rc;
+            if (!dp.b2.empty()) bias_grad(g_feat, ctot, cj, nf, static_cast<int>(HT), grad_of(dp.b2));
+            {
+                const ConvGeom g2 = kind == 0 ? ConvGeom{k - 1 - k / 2, k - 1 - k / 2, T, H, 0} : ConvGeom{11, k - 1 - k / 2, T, H, 0};
+                if ((rc = run_conv(n, dp.d2, kind, Src{g_feat + static_cast<long long>(cj) * HT, nf, nullptr, 0, 0, ctot}, B, H, T, true, false, g_bott, bott, 0, s,
+                                   dname, nullptr, nullptr, &g2, false, nullptr, kind == 0)))
+                    return rc;
+            }
+            bn_block_backward(dp.norm2, g_bott, botts[j], aff2s[j], bott, 0, static_cast<int>(HT));
+            // ---- conv1: bott_j = conv1(lrelu(norm1(feat[0, cj)))) (its bias, where it has one, is removed by norm2: zero gradient) ----
+            PackedConv t1 = dp.c1;
+            t1.kh = kind == 1 ? 12 : 1; t1.kw = 1;
+            if ((rc = wgrad(t1, kind, Src{feat, cj, nullptr, 0, 0, ctot}, aff1s[j], H, T, true, g_bott, bott, 0, grad_of(dp.w1), wname, kind == 0))) return rc;
+            {
+                const ConvGeom g1 = kind == 0 ? ConvGeom{0, 3, T, H, 0} : ConvGeom{11, 0, T, H, 0};   // (1 x 1: the centre of the 7 stored taps; 12 x 1: the row-k form, no frame extent)
+                if ((rc = run_conv(n, dp.d1, kind, Src{g_bott, bott, nullptr, 0, 0}, B, H, T, true, false, g_scr, ctot, 0, s, dname, nullptr, nullptr,
+                                   &g1, false, nullptr, kind == 0)))
+                    return rc;
+            }
+            bn_block_backward(dp.norm1, g_scr, feat, aff1s[j], ctot, 0, static_cast<int>(HT));
+            {
+                const long long total = static_cast<long long>(B) * cj * HT;
+                ake::ProfScope ps("add_channels_kernel", s);
+                hipLaunchKernelGGL(add_channels_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, g_feat, ctot, g_scr, ctot, cj, HT, total);
+            }
+        }
+        return AKE_OK;
+    }
+
+    // the layer walk of a --denseblock net with two layers (models.py:361-396 with dense stacks, backwards): g_cat[1] is dL/d(layer 1's concat
+    // buffer) = pitch classes of layer 0 | folded semitone maps | layer 1's growth, and layer 0's block lives in its first channels
+    int run_dense(const float* mel) {
+        const auto& c = n->cfg;
+        const int P = c.pitches, tp = c.time_pool_size;
+        const LayerDims& d = n->dims[1];
+        const int T1 = b.Tl[1], g = c.n_filters * c.conv_layers, ctd = d.prev_pc + d.out_p + g;
+        int rc;
+        {   // time pool (models.py:396) of the whole concat buffer
+            const long long total = static_cast<long long>(B) * ctd * 12 * ((T1 / tp) + (T1 % tp ? 1 : 0));
+            ake::ProfScope ps("time_pool_bwd_kernel", s);
+            hipLaunchKernelGGL(time_pool_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_pcf, b.cat[1], static_cast<const float*>(nullptr),
+                               b.g_cat[1], ctd, 12, T1, tp, ctd, 0, total, 0);
+        }
+        float* scr_pc = b.g_pc[1];                       // [B][ctd][12][T1] scratch (g_pc[1] holds two of them)
+        if ((rc = dense_block_backward(n->dense_pc[1], 1, b.cat[1], ctd, d.prev_pc + d.out_p, 12, T1, b.g_cat[1], b.dn_gbott_pc, scr_pc, b.dn_bott_pc[1],
+                                       b.dn_aff1_pc[1], b.dn_aff2_pc[1], "conv_wgrad_kernel/pc2pc", "conv_mfma_kernel/pc2pc_dgrad")))
+            return rc;
+        // folded semitone maps -> pool_semi(1) -> dL/d(pitch features), all out_p channels
+        float* g_p = b.g_p[1];
+        float* scr_p = b.g_p[1] + static_cast<size_t>(B) * d.out_p * P * T1;
+        if ((rc = semi_backward(1, b.pa[1], nullptr, b.g_cat[1], ctd, d.prev_pc, g_p))) return rc;
+        if ((rc = dense_block_backward(n->dense_p[1], 0, b.pa[1], d.out_p, d.prev_p + d.prev_pc, P, T1, g_p, b.dn_gbott_p, scr_p, b.dn_bott_p[1], b.dn_aff1_p[1],
+                                       b.dn_aff2_p[1], "conv_wgrad_kernel/p2p", "conv_mfma_kernel/p2p_dgrad")))
+            return rc;
+        {   // repeat (x P / 36) backward: channels [prev_p, prev_p + prev_pc) of the pitch block's input gradient -> the up_sixth map
+            const long long total = static_cast<long long>(B) * d.prev_pc * 36 * T1;
+            ake::ProfScope ps("repeat_sum_kernel", s);
+            hipLaunchKernelGGL(repeat_sum_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, g_p, b.g_psix[1], d.out_p, d.prev_p, d.prev_pc, P, T1, total);
+        }
+        bn_block_backward("model.1.up_sixth_b", b.g_psix[1], b.psix[1], b.aff_p2pin[1] + 3 * d.prev_p, d.prev_pc, 0, 36 * T1);
+        {
+            ake::ProfScope ps("up_sixth_bwd_weight_kernel", s);
+            hipLaunchKernelGGL(up_sixth_bwd_weight_kernel, dim3(d.prev_pc * d.prev_pc * 3, B), dim3(64), 0, s, b.g_psix[1], b.cat[1], static_cast<long long>(ctd) * 12 * T1,
+                               static_cast<const float*>(nullptr), grad_of("model.1.up_sixth.weight"), static_cast<long long>(n->grad_floats), d.prev_pc, T1);
+        }
+        {
+            const long long total = static_cast<long long>(B) * d.prev_pc * 12 * T1;
+            ake::ProfScope ps("up_sixth_bwd_data_kernel", s);
+            hipLaunchKernelGGL(up_sixth_bwd_data_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_psix[1], raw_of("model.1.up_sixth.weight"),
+                               b.g_cat[1], ctd, d.prev_pc, T1, total);
+        }
+        // layer 0's block: channels [0, 1 + g) of the same buffer, input = the fold (channel 0)
+        if ((rc = dense_block_backward(n->dense_pc[0], 1, b.cat[1], ctd, 1, 12, T1, b.g_cat[1], b.dn_gbott_pc, scr_pc, b.dn_bott_pc[0], b.dn_aff1_pc[0],
+                                       b.dn_aff2_pc[0], "conv_wgrad_kernel/pc2pc0", "conv_mfma_kernel/pc2pc0_dgrad")))
+            return rc;
+        return semi_backward(0, mel, nullptr, b.g_cat[1], ctd, 0, nullptr);
     }
 
     void bias_grad(const float* dz, int ctot, int coff, int C, int HT, gfx_t* db) {
@@ -395,6 +491,7 @@ struct Bwd {
         }
 
         planes_scratch = nullptr;
+        if (c.denseblock) return run_dense(mel);
         float* g_last = b.g_pc[i];                                   // ga w.r.t. the last pc2pc activation of the last layer
         float* g_last2 = b.g_pc[i] + static_cast<size_t>(B) * (i == 0 ? c.n_filters : d.out_pc) * 12 * Ti;
         if (L > 1) {

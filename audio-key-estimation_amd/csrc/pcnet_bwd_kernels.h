@@ -690,6 +690,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs wa) {
                     const int cl = rr / R_in, rj = rr - cl * R_in;
                     const int cs = c_lo + cl;
                     int row = y0 - a.py + rj;
+                    const bool row_ok = !a.rows_zero || (row >= 0 && row < a.H);       // rows_zero: zero padding instead of the circular wrap
                     row += row < 0 ? a.H : 0;
                     row -= row >= a.H ? a.H : 0;
                     float asc = 1.f, ash = 0.f, ang = 1.f;
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs wa) {
                             if (fast_wrap) { tin += tin < 0 ? a.T_in : 0; tin -= tin >= a.T_in ? a.T_in : 0; }
                             else tin = wrap(tin, a.T_in);
                         } else ok = tin >= 0 && tin < a.T_in;
-                        if (ok) { const float x = fmaf(srow[tin], asc, ash); v = x > 0.f ? x : x * ang; }
+                        if (ok && row_ok) { const float x = fmaf(srow[tin], asc, ash); v = x > 0.f ? x : x * ang; }
                         lds[rr * Tp + tj] = v;
                     }
                 }

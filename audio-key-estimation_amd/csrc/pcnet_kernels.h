@@ -308,7 +308,7 @@ __global__ void head_pool_kernel(PoolHeadArgs a) {
 // --denseblock: the pitch stack's input (pitch stream | up_sixth map repeated over the octaves, models.py:378-383) materialised as
 // channels [0, c0 + c1) of the block's feature buffer [B][ctot][H][T] -- every later dense layer re-reads it with its own BatchNorm
 __global__ void concat_repeat_kernel(const float* __restrict__ src0, int c0, const float* __restrict__ src1, int c1, int h1, float* __restrict__ dst,
-                                     int ctot, int H, int T, long long total) {
+                                     int ctot, int H, int T, long long total, const float* __restrict__ aff1 = nullptr) {   // aff1 (training): src1 is raw, its [c1][3] table applied here
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int t = static_cast<int>(i % T);
@@ -316,7 +316,8 @@ __global__ void concat_repeat_kernel(const float* __restrict__ src0, int c0, con
     const int y = static_cast<int>(r % H); r /= H;
     const int c = static_cast<int>(r % (c0 + c1));
     const long long clip = r / (c0 + c1);
-    const float v = c < c0 ? src0[((clip * c0 + c) * H + y) * T + t] : src1[((clip * c1 + (c - c0)) * h1 + y % h1) * T + t];
+    float v = c < c0 ? src0[((clip * c0 + c) * H + y) * T + t] : src1[((clip * c1 + (c - c0)) * h1 + y % h1) * T + t];
+    if (aff1 && c >= c0) { const float x = fmaf(v, aff1[3 * (c - c0)], aff1[3 * (c - c0) + 1]); v = x > 0.f ? x : x * aff1[3 * (c - c0) + 2]; }
     dst[((clip * ctot + c) * H + y) * T + t] = v;
 }
 
@@ -3018,6 +3019,38 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int stats_s
     batch_stats[3 * c] = static_cast<float>(mean);
     batch_stats[3 * c + 1] = static_cast<float>(var);
     batch_stats[3 * c + 2] = static_cast<float>(count);
+}
+
+// --denseblock training: (sum, sum of squares) of channels [0, C) of a READY tensor [clip][ctot][HT] (a dense block's input: its first
+// norm1 normalises features no convolution of the block produced).  grid (C, 1, clips).
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ src, long long clip_stride, long long HT, double* __restrict__ stats,
+                                                            int stats_stride) {
+    const int c = blockIdx.x;
+    const float* p = src + static_cast<long long>(blockIdx.z) * clip_stride + static_cast<long long>(c) * HT;
+    ShiftStat ss;
+    ss.init();
+    for (long long i = threadIdx.x; i < HT; i += 256) ss.add(p[i]);
+    stats_commit(stats, stats_stride, c, ss);
+}
+
+// ... the statistics of C channels copied from one BatchNorm layer's cells to another's (every norm1 of a dense block normalises the same
+// features with its own gamma / beta: the sums are taken once)
+__global__ void stats_copy_kernel(double* __restrict__ stats, int stats_stride, int src_ch, int dst_ch, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kStatSlots * 2 * C) return;
+    const int k = i / (2 * C), r = i - k * 2 * C;
+    stats[static_cast<size_t>(k) * stats_stride + 2 * dst_ch + r] = stats[static_cast<size_t>(k) * stats_stride + 2 * src_ch + r];
+}
+
+// dst[clip][c][i] += src[clip][c][i] for the first C channels of two tensors with their own channel counts
+__global__ void add_channels_kernel(float* __restrict__ dst, int dst_ctot, const float* __restrict__ src, int src_ctot, int C, long long HT, long long total) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long e = i % HT;
+    const long long r = i / HT;
+    const int c = static_cast<int>(r % C);
+    const long long clip = r / C;
+    dst[(clip * dst_ctot + c) * HT + e] += src[(clip * src_ctot + c) * HT + e];
 }
 
 __global__ void affine_identity_kernel(float* __restrict__ aff, int C) {
