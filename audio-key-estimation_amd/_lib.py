@@ -72,6 +72,7 @@ SYMBOLS = {
     "ake_pcnet_load_from_device_f32": (_I, [_P, _P, _P]),
     "ake_pcnet_load_for_training_f32": (_I, [_P, _P, _P]),
     "ake_pcnet_update_running_stats_f32": (_I, [_P, _P, _P, C.c_float, _P]),
+    "ake_pcnet_update_recomputed_running_stats_f32": (_I, [_P, _P, _P, C.c_float, _P, _P]),
     "ake_adam_step_f32": (_I, [_P, _P, _P, _P, _P, _SZ] + [C.c_float] * 5 + [_I, C.c_float, _P]),
     "ake_general_step_f32": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I] + [C.c_float] * 3 + [_I, _P, _P, _P, _P, _P]),
     "ake_pcnet_tap_info": (_I, [_P, C.c_char_p, _I, _I, C.POINTER(_I64)]),

@@ -121,6 +121,8 @@ struct ake_pcnet {
     int32_t* fold_ch_dev = nullptr;    // per flat float: -1, or (eval BatchNorm channel << 1) | is_bias
     int32_t* fold_bn_dev = nullptr;    // per eval BatchNorm channel: flat offsets of gamma, beta, running_mean, running_var
     int32_t* run_off_dev = nullptr;    // per training BatchNorm channel (BnLayer::ch_off order): flat offsets of running_mean, running_var
+    int32_t* run_off2_dev = nullptr;   // the same for the layers the reference's BACKWARD runs a second time (checkpointed halves: --denseblock's norm1), -1 elsewhere
+    int recomputed_bn_channels = 0;
     float* folded_dev = nullptr;
     bool tracing = false;
     std::vector<std::vector<DensePack>> dense_pc, dense_p;   // --denseblock: per layer, conv_layers entries
@@ -1226,7 +1228,7 @@ void ake_pcnet_destroy(ake_pcnet* n) {
     if (!n) return;
     if (n->blob_dev) (void)hipFree(n->blob_dev);
     for (void* p : {static_cast<void*>(n->map_dev), static_cast<void*>(n->fold_ch_dev), static_cast<void*>(n->fold_bn_dev),
-                    static_cast<void*>(n->run_off_dev), static_cast<void*>(n->folded_dev), static_cast<void*>(n->bf_frags_dev),
+                    static_cast<void*>(n->run_off_dev), static_cast<void*>(n->run_off2_dev), static_cast<void*>(n->folded_dev), static_cast<void*>(n->bf_frags_dev),
                     static_cast<void*>(n->dense_aff_dev), static_cast<void*>(n->dense_aff_idx_dev)})
         if (p) (void)hipFree(p);
     delete n;
@@ -1472,7 +1474,7 @@ __global__ void gather_blob_kernel(const float* __restrict__ params, const float
 __global__ void running_stats_kernel(const float* __restrict__ bstats, const int32_t* __restrict__ run_off, float* __restrict__ params,
                                      float momentum, int n_ch) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_ch) return;
+    if (c >= n_ch || run_off[2 * c] < 0) return;
     const float mean = bstats[3 * c], var = bstats[3 * c + 1], cnt = bstats[3 * c + 2];
     const float unbiased = var * cnt / fmaxf(cnt - 1.f, 1.f);
     float* rm = params + run_off[2 * c];
@@ -1563,7 +1565,8 @@ int rebuild_dense_affine(ake_pcnet* n, const float* params_dev, hipStream_t s) {
 }
 
 int build_fold_tables(ake_pcnet* n) {
-    std::vector<int32_t> fold_ch(n->grad_floats, -1), fold_bn, run_off(static_cast<size_t>(n->bn_channels) * 2, 0);
+    std::vector<int32_t> fold_ch(n->grad_floats, -1), fold_bn, run_off(static_cast<size_t>(n->bn_channels) * 2, 0), run_off2(static_cast<size_t>(n->bn_channels) * 2, -1);
+    n->recomputed_bn_channels = 0;
     auto off = [&](const std::string& key) { return static_cast<int32_t>(n->grad_off[n->spec_index.at(key)]); };
     int base = 0;
     for (const auto& r : n->fold_records) {
@@ -1586,9 +1589,17 @@ int build_fold_tables(ake_pcnet* n) {
         for (int c = 0; c < l.C; ++c) {
             run_off[2 * (l.ch_off + c)] = off(l.name + ".running_mean") + c;
             run_off[2 * (l.ch_off + c) + 1] = off(l.name + ".running_var") + c;
+            // --denseblock: the reference checkpoints norm1 + conv1 of every dense layer (models.py:484-489, 553): autograd's backward runs that
+            // half again, in train mode -- its BatchNorm blends the batch statistics into the running ones a second time
+            const bool again = n->cfg.denseblock && l.name.size() > 6 && l.name.compare(l.name.size() - 6, 6, ".norm1") == 0;
+            if (again) {
+                run_off2[2 * (l.ch_off + c)] = run_off[2 * (l.ch_off + c)];
+                run_off2[2 * (l.ch_off + c) + 1] = run_off[2 * (l.ch_off + c) + 1];
+                ++n->recomputed_bn_channels;
+            }
         }
     int rc;
-    if ((rc = upload_i32(fold_ch, &n->fold_ch_dev)) || (rc = upload_i32(fold_bn, &n->fold_bn_dev)) || (rc = upload_i32(run_off, &n->run_off_dev)) ||
+    if ((rc = upload_i32(fold_ch, &n->fold_ch_dev)) || (rc = upload_i32(fold_bn, &n->fold_bn_dev)) || (rc = upload_i32(run_off, &n->run_off_dev)) || (rc = upload_i32(run_off2, &n->run_off2_dev)) ||
         (rc = upload_i32(n->map_host, &n->map_dev)))
         return rc;
     if (n->folded_dev) { (void)hipFree(n->folded_dev); n->folded_dev = nullptr; }
@@ -1848,6 +1859,24 @@ int ake_pcnet_update_running_stats_f32(const ake_pcnet* n, const float* bn_stats
     hipStream_t s = static_cast<hipStream_t>(stream);
     ake::ProfScope ps("running_stats_kernel", s);
     hipLaunchKernelGGL(running_stats_kernel, dim3((n->bn_channels + 63) / 64), dim3(64), 0, s, bn_stats_dev, n->run_off_dev, params_dev, momentum,
+                       n->bn_channels);
+    AKE_HIP_CHECK(hipGetLastError());
+    return AKE_OK;
+}
+
+// The BatchNorm layers whose forward the reference's BACKWARD pass runs a second time (checkpointed halves: every dense layer's norm1,
+// models.py:484-489, 553): the same blend once more, with the batch statistics of the forward this backward belongs to.  Returns the number
+// of channels it touches through *channels (nullable); a no-op for nets without such layers.
+int ake_pcnet_update_recomputed_running_stats_f32(const ake_pcnet* n, const float* bn_stats_dev, float* params_dev, float momentum, int* channels,
+                                                  ake_stream_t stream) {
+    AKE_REQUIRE(n, AKE_ERR_INVALID, "update_recomputed_running_stats: null handle");
+    if (channels) *channels = n->recomputed_bn_channels;
+    if (n->recomputed_bn_channels == 0) return AKE_OK;
+    AKE_REQUIRE(bn_stats_dev && params_dev, AKE_ERR_INVALID, "update_recomputed_running_stats: null argument");
+    AKE_REQUIRE(n->finalized && n->run_off2_dev, AKE_ERR_STATE, "update_recomputed_running_stats: the handle has no parameters yet");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ake::ProfScope ps("running_stats_kernel", s);
+    hipLaunchKernelGGL(running_stats_kernel, dim3((n->bn_channels + 63) / 64), dim3(64), 0, s, bn_stats_dev, n->run_off2_dev, params_dev, momentum,
                        n->bn_channels);
     AKE_HIP_CHECK(hipGetLastError());
     return AKE_OK;

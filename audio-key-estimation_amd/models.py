@@ -225,6 +225,7 @@ class _TrainStep(torch.autograd.Function):
         ws = net._train_ws_acquire(B, Tn, x.device)
         key, tonic, genre = net._forward_train_raw(x, seq, ws)
         ctx.net, ctx.x, ctx.seq, ctx.key, ctx.ws = net, x, seq, key, ws
+        ctx.bn_stats = net._last_bn_stats if net.denseblock else None      # (the dense layers' norm1 blend them a second time in backward)
         ctx.param_meta = [(p.dtype, p.shape) for p in params]
         ctx.set_materialize_grads(True)
         if genre is None:
@@ -239,6 +240,9 @@ class _TrainStep(torch.autograd.Function):
                                 "backward (as autograd does without retain_graph)")
         ctx.ws = None
         try:
+            if ctx.bn_stats is not None:
+                net._update_recomputed_running_stats(ctx.bn_stats)
+                ctx.bn_stats = None
             if net._grads_in_place():
                 net._backward_raw(ctx.x, ctx.seq, ctx.key, d_key, d_tonic, d_genre, into=net._flat_grad, ws=ws)
                 return (None, None, None) + (None,) * len(ctx.param_meta)
@@ -685,6 +689,7 @@ class PitchClassNet(LightningModule):
             if self._attached:
                 _lib.check(L.ake_pcnet_update_running_stats_f32(self._h, stats.data_ptr(), self._flat.data_ptr(), 0.1,
                                                                 torch.cuda.current_stream().cuda_stream), "ake_pcnet_update_running_stats_f32")
+        self.__dict__["_last_bn_stats"] = stats
         if self._attached:
             self._stats_dirty += 1                             # eval-mode packs fold the running statistics: repacked at the next eval forward
             with torch.no_grad():
@@ -699,7 +704,7 @@ class PitchClassNet(LightningModule):
             self.__dict__["_nbt_cache"] = (self._h, [mods[name] for name, _, _ in self._bn_layers()])
         return [m.num_batches_tracked for m in self._nbt_cache[1]]
 
-    _DEVICE_STATE = ("_h", "_h_device", "_h_stamp", "_ws", "_ws_last", "_flat", "_flat_grad", "_layout_cache", "_goff_cache", "_bn_cache", "_nbt_cache")
+    _DEVICE_STATE = ("_h", "_h_device", "_h_stamp", "_ws", "_ws_last", "_flat", "_flat_grad", "_layout_cache", "_goff_cache", "_bn_cache", "_nbt_cache", "_last_bn_stats")
 
     def __getstate__(self):
         """copy.deepcopy / pickle: the device handle and the flat buffers belong to this object only."""
@@ -761,6 +766,28 @@ class PitchClassNet(LightningModule):
             bn.running_var.mul_(1 - m).add_(unbiased.to(bn.running_var.dtype) * m)
             bn.num_batches_tracked += 1
         # the device copy of the weights does not depend on the running statistics in train mode; eval re-syncs lazily
+
+    @torch.no_grad()
+    def _update_recomputed_running_stats(self, stats):
+        """--denseblock: the reference checkpoints norm1 + conv1 of every dense layer (models.py:484-489, 553); autograd's backward runs that
+        half again in train mode, so those BatchNorm layers blend the batch statistics a second time and count two batches per step."""
+        if self._attached:
+            with torch.cuda.device(self._h_device):
+                _lib.check(_lib.lib().ake_pcnet_update_recomputed_running_stats_f32(self._h, stats.data_ptr(), self._flat.data_ptr(), 0.1, None,
+                                                                                     torch.cuda.current_stream().cuda_stream),
+                           "ake_pcnet_update_recomputed_running_stats_f32")
+            self._stats_dirty += 1
+        mods = dict(self.named_modules())
+        for name, ch, off in self._bn_layers():
+            if not name.endswith(".norm1"):
+                continue
+            bn = mods[name]
+            if not self._attached:
+                mean, var, cnt = stats[off:off + ch, 0], stats[off:off + ch, 1], stats[off:off + ch, 2]
+                m = bn.momentum if bn.momentum is not None else 0.1
+                bn.running_mean.mul_(1 - m).add_(mean.to(bn.running_mean.dtype) * m)
+                bn.running_var.mul_(1 - m).add_((var * cnt / (cnt - 1).clamp_min(1)).to(bn.running_var.dtype) * m)
+            bn.num_batches_tracked += 1
 
     @staticmethod
     def keep_taps(on=True):

@@ -177,6 +177,13 @@ int ake_pcnet_load_for_training_f32(ake_pcnet* net, const float* params_dev, ake
  * UNBIASED batch variance), from the bn_stats a training forward returned.  Reference default momentum 0.1. */
 int ake_pcnet_update_running_stats_f32(const ake_pcnet* net, const float* bn_stats_dev, float* params_dev, float momentum,
                                        ake_stream_t stream);
+/* --denseblock: the reference checkpoints norm1 + conv1 of every dense layer (torch.utils.checkpoint, models.py:484-489, 553), so autograd's
+ * BACKWARD runs that half a second time in train mode and its BatchNorm blends the batch statistics into the running ones once more
+ * (num_batches_tracked counts 2 per step for those layers).  Call this after ake_pcnet_backward_f32 with the bn_stats of the forward the
+ * backward belonged to: it repeats the blend for exactly those layers.  *channels (nullable) receives how many BatchNorm channels that is;
+ * a no-op (0 channels) for every other configuration. */
+int ake_pcnet_update_recomputed_running_stats_f32(const ake_pcnet* net, const float* bn_stats_dev, float* params_dev, float momentum, int* channels,
+                                                  ake_stream_t stream);
 
 size_t ake_pcnet_workspace_bytes(const ake_pcnet* net, int batch, int frames);
 /*

@@ -59,6 +59,13 @@ def install():
     tm.Accuracy = Accuracy
     sys.modules["torchmetrics"] = tm
 
+    # (torch.utils.checkpoint -- the reference's dense layers use it -- imports torch._dynamo, which calls importlib's find_spec on a list of
+    # module names: a stub without a __spec__ makes that raise)
+    import importlib.machinery
+    for name in ("tensorflow", "pytorch_lightning", "pytorch_lightning.loggers", "pytorch_lightning.callbacks",
+                 "pytorch_lightning.callbacks.early_stopping", "torchmetrics"):
+        sys.modules[name].__spec__ = importlib.machinery.ModuleSpec(name, None)
+
     nn.Module.cuda = lambda self, *a, **k: self
     torch.Tensor.cuda = lambda self, *a, **k: self
     if REFERENCE_ROOT not in sys.path:

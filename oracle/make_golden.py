@@ -383,6 +383,54 @@ def main():
                             key=kk_.numpy(), tonic=tk_.numpy(), genre=gnk_.numpy(), key_noseq=kn_.numpy(), tonic_noseq=tn_.numpy(),
                             genre_noseq=gnn_.numpy(), **sd_to_npz(sd_k))
 
+    # ---------------------------------------------------------------- L: --denseblock, ONE training forward + backward through the real reference
+    print("L: --denseblock in train() mode: loss, every parameter's gradient (the reference's own autograd, float64) and the BatchNorm running "
+          "statistics after the step (the dense layers checkpoint norm1 + conv1, models.py:484-489, 510-514: that half runs twice per step)")
+    with torch.enable_grad():
+        opt_t = default_opt(denseblock=True, n_filters=2, conv_layers=2)
+        net_t, sd_t = build_reference_net(opt_t, seed=88)
+        net_t.train()
+        gt = torch.Generator().manual_seed(188)
+        xt = (torch.rand((2, 1, 288, 40), generator=gt) * 2.5).float()
+        seq_t = torch.tensor([40, 33])
+        key_labels = (torch.rand((2, 12), generator=gt) > 0.5).double()
+        tonic_idx = torch.randint(0, 12, (2,), generator=gt)
+        genre_idx = torch.randint(0, 11, (2,), generator=gt)
+        import torch.nn.functional as F_
+
+        def loss_of(out):      # models.py:878-893 with the default weights (key 1, tonic 1, genre 0.1), every clip labelled
+            return F_.binary_cross_entropy(out[0], key_labels) + F_.cross_entropy(out[1], tonic_idx) + 0.1 * F_.cross_entropy(out[2], genre_idx)
+
+        loss_t = loss_of(net_t(xt.double(), seq_t))
+        loss_t.backward()
+        grads_t = {k: p.grad.detach().clone() for k, p in net_t.named_parameters()}
+        after_t = {k: v.detach().clone() for k, v in net_t.state_dict().items() if "running_" in k}
+        # the restatement's autograd against the reference's
+        sd_o = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd_t.items()}
+        loss_o = loss_of(pcnet_oracle.pcnet_forward(sd_o, xt.double(), seq_t, training=True))
+        loss_o.backward()
+        report["checks"]["L_loss"] = check("denseblock train-mode loss", loss_o.detach(), loss_t.detach(), 1e-12)
+        # (biases in front of a BatchNorm have an exactly-zero gradient: 1e-18 against 1e-18 -- the error is taken relative to at least 1e-9 of
+        # the step's largest gradient)
+        gmax = max(float(g.abs().max()) for g in grads_t.values())
+        worst = max(float((sd_o[k].grad - g).abs().max() / max(float(g.abs().max()), 1e-9 * gmax)) for k, g in grads_t.items())
+        print(f"  oracle autograd vs reference autograd, worst tensor (relative to its max): {worst:.3e}")
+        assert worst < 1e-6, worst
+        report["checks"]["L_grad_worst_rel"] = worst
+        # which BatchNorm layers saw the batch twice?  running = (1 - m)^r * old + (1 - (1 - m)^r) * batch mean, m = 0.1
+        twice = []
+        for k in sorted(after_t):
+            if not k.endswith("running_mean"):
+                continue
+            old, new = sd_t[k], after_t[k]
+            bn_in = None
+            twice.append((k, new, old))
+        np.savez_compressed(os.path.join(GOLD, "pcnet_denseblock_train_T40.npz"), opt=json.dumps(vars(opt_t)), x=xt.numpy(), seq_length=seq_t.numpy(),
+                            key_labels=key_labels.numpy(), tonic_idx=tonic_idx.numpy(), genre_idx=genre_idx.numpy(), loss=loss_t.detach().numpy(),
+                            **{"grad/" + k: v.numpy() for k, v in grads_t.items()}, **{"after/" + k: v.numpy() for k, v in after_t.items()},
+                            **sd_to_npz(sd_t))
+    torch.set_grad_enabled(False)
+
     with open(os.path.join(GOLD, "PROVENANCE.json"), "w") as f:
         json.dump(report, f, indent=1)
     print("wrote", sorted(os.listdir(GOLD)))

@@ -21,7 +21,7 @@ import torch
 import torch.nn.functional as F
 
 import ake_amd
-from conftest import golden_state_dict
+from conftest import golden_state_dict, rel_err
 from oracle import pcnet_oracle
 
 pytestmark = pytest.mark.gpu
@@ -282,6 +282,70 @@ def test_kernel_size_gradients(ksz, frames, seed):
     rows = grad_errors(net, ref)
     tight = [r for r in rows if r[1] not in ILL_CONDITIONED]
     assert tight[0][0] < 3e-5 and rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
+
+
+# --denseblock: gamma of the FIRST norm1 of layer 0's block normalises one channel (the fold) and feeds conv1 + norm2: the loss does not depend
+# on it, its exact gradient is zero (|ref| ~1e-5 next to 0.4: a cancelling sum, as model.0.pool_semi_b.weight)
+DENSE_ILL = ("model.0.pool_semi_b.weight", "model.0.pc2pc.layer.0.denselayer1.norm1.weight")
+
+
+def test_denseblock_training_step_against_reference_fixture():
+    """--denseblock (models.py:456-648) in train() mode against the REFERENCE's own forward + autograd (float64; fixture written by
+    oracle/make_golden.py section L): loss, every parameter's gradient, and the BatchNorm running statistics after the step -- the
+    reference checkpoints norm1 + conv1 of every dense layer (models.py:484-489, 553), so its backward blends those layers' batch statistics
+    a second time and counts two batches per step."""
+    from conftest import load_golden
+    gold = load_golden("pcnet_denseblock_train_T40.npz")
+    opt = Namespace(**json.loads(str(gold["opt"])))
+    net = ake_amd.PitchClassNet(288, 12, 2, 7, opt)
+    net.load_state_dict(golden_state_dict(gold), strict=True)
+    net = net.to(DEV).train()
+    x = torch.from_numpy(gold["x"]).to(DEV)
+    seq = torch.from_numpy(gold["seq_length"]).to(DEV)
+    out = net(x, seq)
+    loss = (F.binary_cross_entropy(out[0], torch.from_numpy(gold["key_labels"]).float().to(DEV)) + F.cross_entropy(out[1], torch.from_numpy(gold["tonic_idx"]).to(DEV))
+            + 0.1 * F.cross_entropy(out[2], torch.from_numpy(gold["genre_idx"]).to(DEV)))
+    assert abs(float(loss.detach()) - float(gold["loss"])) < 2e-5 * max(1.0, abs(float(gold["loss"])))
+    sd_fwd = {k: v.clone() for k, v in net.state_dict().items()}
+    loss.backward()
+    ref = {k[5:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("grad/")}
+    rows = grad_errors(net, ref)
+    tight = [r for r in rows if r[1] not in DENSE_ILL]
+    assert tight[0][0] < 3e-5 and rows[0][0] < 5e-2, rows[:5]
+    sd_after = net.state_dict()
+    for k in gold.files:
+        if not k.startswith("after/"):
+            continue
+        name = k[6:]
+        assert rel_err(sd_after[name].cpu(), gold[k]) < 1e-5, name
+        if name.endswith("running_mean"):
+            bn = name[:-len(".running_mean")]
+            twice = bn.endswith(".norm1")
+            assert int(sd_after[bn + ".num_batches_tracked"]) == (2 if twice else 1), bn
+            # ... and the second blend happened in BACKWARD, not in the forward
+            assert int(sd_fwd[bn + ".num_batches_tracked"]) == 1, bn
+
+
+@pytest.mark.parametrize("n_filters,conv_layers,frames,seed", [(2, 2, 40, 0), (2, 2, 52, 1), (4, 3, 40, 1), (4, 3, 52, 2)])
+def test_denseblock_net_gradients(n_filters, conv_layers, frames, seed):
+    """--denseblock training at the fixture's widths and at the default ones (76-channel bottlenecks, 51 -> 102 channel heads): the dense
+    blocks' train-mode forward (block-input statistics, the statistics every later norm1 shares, per-layer tables) and their backward (the
+    channel-sliced accumulate of the dense connections, zero-padded weight / data gradients of the plain Conv2d form, 12 x 1 bottlenecks)
+    against float64 autograd through the oracle.  Seeds: picks of tests/tools/dense_grad_scan.py."""
+    opt = Namespace(conv_layers=conv_layers, n_filters=n_filters, head_layers=2, time_pool_size=2, genre=True, max_pool=False, frames=5, denseblock=True)
+    torch.manual_seed(60 + seed)
+    net = ake_amd.PitchClassNet(288, 12, 2, 7, opt)
+    sd32 = {k: v.clone() for k, v in net.state_dict().items()}
+    x, seq, labels = make_case(2, frames, seed)
+    loss_ref, ref = reference_grads(sd32, x, seq, labels)
+    net = net.to(DEV).train()
+    out = net(x.to(DEV), seq.to(DEV))
+    loss = loss_fn(out[0], out[1], out[2], *(t.to(DEV) for t in labels))
+    assert abs(float(loss.detach()) - loss_ref) < 2e-5 * max(1.0, abs(loss_ref))
+    loss.backward()
+    rows = grad_errors(net, ref)
+    tight = [r for r in rows if r[1] not in DENSE_ILL]
+    assert tight[0][0] < 3e-5 and rows[0][0] < 1e-1 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
 
 
 @pytest.mark.parametrize("with_seq", [True, False])

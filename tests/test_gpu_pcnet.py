@@ -437,8 +437,12 @@ def test_denseblock_against_reference_fixture(gold_denseblock):
         ref = pcnet_oracle.pcnet_forward(sd, x2.double(), seq2)
         for a, b in zip(net(x2.to(DEV), seq2.to(DEV)), ref):
             assert rel_err(a.cpu(), b) < TOL, (B, T)
-    with pytest.raises(NotImplementedError):
-        net.train()(x, seq)
+    # train mode (batch statistics; gradients and running statistics: tests/test_gpu_backward.py::test_denseblock_*)
+    ref_t = pcnet_oracle.pcnet_forward(sd, x.double().cpu(), seq.cpu(), training=True)
+    with torch.no_grad():
+        for a, b in zip(net.train()(x, seq), ref_t):
+            assert rel_err(a.cpu(), b) < TOL
+    net.eval()
     # default widths
     torch.manual_seed(7)
     big = ake_amd.PitchClassNet(288, 12, 2, 7, Namespace(genre=True, denseblock=True))

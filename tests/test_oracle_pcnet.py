@@ -200,3 +200,22 @@ def test_kernel_size_3_and_5_against_reference_fixture(ksz):
     for seq, sfx in ((torch.from_numpy(gold["seq_length"]), ""), (None, "_noseq")):
         for got, name in zip(pcnet_oracle.pcnet_forward(sd, x, seq, kernel_size=ksz), ("key", "tonic", "genre")):
             assert np.abs(got.numpy() - gold[name + sfx]).max() <= 1e-12, (name, sfx)
+
+
+def test_denseblock_training_step_against_reference_fixture():
+    """--denseblock in train() mode: the loss and every parameter's gradient of the REFERENCE's own forward + autograd (float64, its
+    checkpointed dense layers included) for its own seeded weights -- the restatement's autograd must give the same numbers."""
+    import torch.nn.functional as F
+    from conftest import load_golden
+    gold = load_golden("pcnet_denseblock_train_T40.npz")
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in golden_state_dict(gold, torch.float64).items()}
+    out = pcnet_oracle.pcnet_forward(sd, torch.from_numpy(gold["x"]).double(), torch.from_numpy(gold["seq_length"]), training=True)
+    loss = (F.binary_cross_entropy(out[0], torch.from_numpy(gold["key_labels"])) + F.cross_entropy(out[1], torch.from_numpy(gold["tonic_idx"]))
+            + 0.1 * F.cross_entropy(out[2], torch.from_numpy(gold["genre_idx"])))
+    assert abs(float(loss) - float(gold["loss"])) < 1e-12
+    loss.backward()
+    names = [k[5:] for k in gold.files if k.startswith("grad/")]
+    gmax = max(float(np.abs(gold["grad/" + k]).max()) for k in names)
+    for k in names:
+        ref = gold["grad/" + k]
+        assert np.abs(sd[k].grad.numpy() - ref).max() <= 1e-6 * max(float(np.abs(ref).max()), 1e-9 * gmax), k
