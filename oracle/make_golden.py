@@ -389,6 +389,7 @@ def main():
     with torch.enable_grad():
         opt_t = default_opt(denseblock=True, n_filters=2, conv_layers=2)
         net_t, sd_t = build_reference_net(opt_t, seed=88)
+        sd_t = {k: v.clone() for k, v in sd_t.items()}        # (the integer buffers of state_dict() are the module's own: the step below counts them up)
         net_t.train()
         gt = torch.Generator().manual_seed(188)
         xt = (torch.rand((2, 1, 288, 40), generator=gt) * 2.5).float()

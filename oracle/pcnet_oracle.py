@@ -38,16 +38,21 @@ class record_bn_stats:
         _BN_SINK = None
 
 
-def update_running_stats(sd, rows, momentum=0.1):
-    """Apply torch's train-mode running-statistics update to ``sd`` in place for the rows of ``record_bn_stats``."""
+def update_running_stats(sd, rows, momentum=0.1, backward_ran=True):
+    """Apply torch's train-mode running-statistics update to ``sd`` in place for the rows of ``record_bn_stats``.
+
+    ``backward_ran``: the reference checkpoints norm1 + conv1 of every dense layer (``cp.checkpoint``, models.py:484-489, 553), so a
+    training step's BACKWARD runs those BatchNorms a second time in train mode: they blend the same batch statistics twice and count two
+    batches per step (pinned by tests/golden/pcnet_denseblock_train_T40.npz)."""
     with torch.no_grad():
         for prefix, mean, var, count in rows:
             unbiased = var * count / max(count - 1, 1)
-            sd[prefix + "running_mean"].mul_(1 - momentum).add_(momentum * mean.detach().to(sd[prefix + "running_mean"].dtype))
-            sd[prefix + "running_var"].mul_(1 - momentum).add_(momentum * unbiased.detach().to(sd[prefix + "running_var"].dtype))
-            key = prefix + "num_batches_tracked"
-            if key in sd:
-                sd[key] += 1
+            for _ in range(2 if backward_ran and ".denselayer" in prefix and prefix.endswith(".norm1.") else 1):
+                sd[prefix + "running_mean"].mul_(1 - momentum).add_(momentum * mean.detach().to(sd[prefix + "running_mean"].dtype))
+                sd[prefix + "running_var"].mul_(1 - momentum).add_(momentum * unbiased.detach().to(sd[prefix + "running_var"].dtype))
+                key = prefix + "num_batches_tracked"
+                if key in sd:
+                    sd[key] += 1
 
 
 def _bn(x, sd, prefix, training=False, stats=None):

@@ -345,7 +345,7 @@ def test_denseblock_net_gradients(n_filters, conv_layers, frames, seed):
     loss.backward()
     rows = grad_errors(net, ref)
     tight = [r for r in rows if r[1] not in DENSE_ILL]
-    assert tight[0][0] < 3e-5 and rows[0][0] < 1e-1 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
+    assert tight[0][0] < 1e-4 and rows[0][0] < 1e-1 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
 
 
 @pytest.mark.parametrize("with_seq", [True, False])

@@ -284,6 +284,40 @@ def test_resblock_short_fit_follows_the_oracle_loss_curve(gold_resblock):
     assert float((key.cpu().double() - ref[0]).abs().max()) < 2e-2 and torch.isfinite(tonic).all() and torch.isfinite(genre).all()
 
 
+def test_denseblock_short_fit_follows_the_oracle_loss_curve(gold_denseblock):
+    """The reference fixture's --denseblock net (models.py:456-648; its weights, n_filters = 2, conv_layers = 2) through the same short fit:
+    per-batch loss against the float64 loop; every dense layer's norm1 counts TWO batches per step (the reference's checkpointed half runs
+    again in backward) and its running statistics follow the double blend; eval-mode inference still runs after."""
+    net, opt = default_net(gold_denseblock)
+    assert net.denseblock
+    sd32 = golden_state_dict(gold_denseblock)
+    batches = [make_batch(4, 40, 500 + i) for i in range(8)]
+    acc, steps = 2, 4
+    ref_losses, ref_sd = oracle_fit(sd32, opt, batches, acc, steps)
+    net = net.to(DEV)
+    trainer = ake_amd.Trainer(max_epochs=1, accumulate_grad_batches=acc)
+    trainer.fit(net, train_dataloaders=batches, max_steps=steps)
+    got = trainer.train_losses
+    assert len(got) == len(ref_losses) == acc * steps
+    rel = [abs(a - b) / abs(b) for a, b in zip(got, ref_losses)]
+    print("denseblock loss curve (device / oracle):", [f"{a:.5f}/{b:.5f}" for a, b in zip(got, ref_losses)])
+    assert max(rel[:acc]) < 1e-5 and max(rel) < 1e-2, rel
+    dev_sd = net.state_dict()
+    diffs = torch.cat([(dev_sd[k].cpu().double() - v.detach()).abs().reshape(-1) for k, v in ref_sd.items()
+                       if v.is_floating_point() and "running" not in k])
+    assert float(diffs.max()) <= 2.05 * steps * 3e-4 and float(diffs.mean()) < 0.2 * steps * 3e-4
+    for k, v in ref_sd.items():
+        if "running" in k:
+            assert float((dev_sd[k].cpu().double() - v).abs().max()) <= 2e-2 * max(1.0, float(v.abs().max())), k
+    assert int(dev_sd["model.1.p2p.layer.0.denselayer1.norm1.num_batches_tracked"]) == 2 * acc * steps
+    assert int(dev_sd["model.1.p2p.layer.0.denselayer1.norm2.num_batches_tracked"]) == acc * steps
+    net.eval()
+    with torch.no_grad():
+        key, tonic, genre = net(batches[0]["mel"].to(DEV), batches[0]["seq_length"].to(DEV))
+    ref = pcnet_oracle.pcnet_forward({k: v.detach() for k, v in ref_sd.items()}, batches[0]["mel"].double(), batches[0]["seq_length"])
+    assert float((key.cpu().double() - ref[0]).abs().max()) < 2e-2 and torch.isfinite(tonic).all() and torch.isfinite(genre).all()
+
+
 # ------------------------------------------------------------------------------------------------------ data parallel
 def _free_port():
     s = socket.socket()
