@@ -999,7 +999,7 @@ int plan_buffers(const ake_pcnet* n, int batch, int chunk, int frames, void* ws,
                 b->pcst[i].push_back(cv.take<float>(width(j) * B * pc_out * 12 * Ti));
                 b->aff_pcst[i].push_back(cv.take<float>(3 * width(j) * pc_out));
             }
-            b->g_pc[i] = cv.take<float>((c.resblock ? 4 : 2) * B * pc_out * 12 * Ti);
+            b->g_pc[i] = cv.take<float>((c.resblock ? 4 : 2) * B * (c.denseblock && i == 0 ? 1 + dg : pc_out) * 12 * Ti);   // (--denseblock, one layer: dL/d(fold | growth))
             if (i >= 1) {
                 b->aff_cat[i] = cv.take<float>(3 * (d.prev_pc + d.out_p));
                 b->aff_p2pin[i] = cv.take<float>(3 * (d.prev_pc + d.prev_p));
@@ -2314,7 +2314,6 @@ struct Fwd {
             if ((rc = semi(0, mel, nullptr, B, P, T0, feat, ctot1, 0, nullptr))) return rc;
             if (L == 1) return AKE_OK;                           // its block runs in the tail
             if (train) {
-                AKE_REQUIRE(L == 2, AKE_ERR_UNSUPPORTED, "pcnet: training a --denseblock net is built for num_layers 2 (got %d)", L);
                 if ((rc = dense_stack_train(n->dense_pc[0], 1, feat, ctot1, 1, B, 12, T0, b.dn_bott_pc[0], b.dn_aff1_pc[0], b.dn_aff2_pc[0], "conv_mfma_kernel/pc2pc0")))
                     return rc;
                 // the raw up_sixth map + its table (rows [prev_p, ..) of the pitch block's input table, as in the default net)
@@ -2378,7 +2377,7 @@ struct Fwd {
                 const int ctd = d.prev_pc + d.out_p + g;                             // = d.out_pc
                 float* catd = b.cat[i] + (last || i == 1 ? static_cast<size_t>(c0) * ctd * 12 * Ti : 0);
                 float* psixd = b.psix[i] + (i == 1 ? static_cast<size_t>(c0) * d.prev_pc * 36 * Ti : 0);
-                if (i > 1) up_sixth(i, pc_cur, static_cast<long long>(ctd) * 12 * Ti, nullptr, B, d.prev_pc, Ti, psixd, nullptr);
+                if (i > 1) up_sixth(i, pc_cur, static_cast<long long>(ctd) * 12 * Ti, nullptr, B, d.prev_pc, Ti, psixd, train ? b.aff_p2pin[i] + 3 * d.prev_p : nullptr);
                 float* fp = b.pa[i];                                                  // [B][out_p][P][Ti]
                 {
                     const long long total = static_cast<long long>(B) * (cp + d.prev_pc) * P * Ti;
@@ -2392,7 +2391,11 @@ struct Fwd {
                 } else if ((rc = dense_stack(n->dense_p[i], 0, fp, d.out_p, cp + d.prev_pc, B, P, Ti, b.pb[i], "conv_mfma_kernel/p2p"))) return rc;
                 if ((rc = semi(i, fp, nullptr, B, P, Ti, catd, ctd, d.prev_pc, nullptr))) return rc;
                 if (last) return AKE_OK;                                              // its pitch-class block + pooling + heads run batch-wide
-                if ((rc = dense_stack(n->dense_pc[i], 1, catd, ctd, d.prev_pc + d.out_p, B, 12, Ti, b.pca[i], "conv_mfma_kernel/pc2pc"))) return rc;
+                if (train) {
+                    if ((rc = dense_stack_train(n->dense_pc[i], 1, catd, ctd, d.prev_pc + d.out_p, B, 12, Ti, b.dn_bott_pc[i], b.dn_aff1_pc[i], b.dn_aff2_pc[i],
+                                                "conv_mfma_kernel/pc2pc")))
+                        return rc;
+                } else if ((rc = dense_stack(n->dense_pc[i], 1, catd, ctd, d.prev_pc + d.out_p, B, 12, Ti, b.pca[i], "conv_mfma_kernel/pc2pc"))) return rc;
                 const LayerDims& dn = n->dims[i + 1];
                 const int ctn = dn.prev_pc + dn.out_p + g;
                 const int Tn = Ti / tp;
@@ -2601,9 +2604,8 @@ struct Fwd {
         if (c.denseblock) {   // the last layer's pitch-class block, in place on its concat buffer: the features are the buffer itself
             float* feat_buf = L == 1 ? b.fold0 : b.cat[i];
             if (train) {
-                AKE_REQUIRE(L == 2, AKE_ERR_UNSUPPORTED, "pcnet: training a --denseblock net is built for num_layers 2 (got %d)", L);
                 if ((rc = dense_stack_train(n->dense_pc[i], 1, feat_buf, n->final_ch, cin, B, 12, Ti, b.dn_bott_pc[i], b.dn_aff1_pc[i], b.dn_aff2_pc[i],
-                                            "conv_mfma_kernel/pc2pc")))
+                                            L == 1 ? "conv_mfma_kernel/pc2pc0" : "conv_mfma_kernel/pc2pc")))
                     return rc;
             } else if ((rc = dense_stack(n->dense_pc[i], 1, feat_buf, n->final_ch, cin, B, 12, Ti, b.pca[i],
                                          L == 1 ? "conv_mfma_kernel/pc2pc0" : "conv_mfma_kernel/pc2pc")))
@@ -2860,7 +2862,6 @@ int ake_pcnet_backward_f32(const ake_pcnet* n, const float* mel, int batch, int 
     AKE_REQUIRE(n->finalized, AKE_ERR_STATE, "pcnet: ake_pcnet_finalize has not been called");
     AKE_REQUIRE(!n->cfg.genre || d_genre, AKE_ERR_INVALID, "pcnet backward: genre head enabled but d_genre is null");
     AKE_REQUIRE(!(n->cfg.p2pc_conv && n->cfg.stay_sixth), AKE_ERR_UNSUPPORTED, "pcnet: training a --p2pc_conv --stay_sixth net is not built");
-    AKE_REQUIRE(!n->cfg.denseblock || n->cfg.num_layers == 2, AKE_ERR_UNSUPPORTED, "pcnet: training a --denseblock net is built for num_layers 2 (got %d)", n->cfg.num_layers);
     Buffers b;
     int rc = plan_buffers(n, batch, batch, frames, workspace, &b, true);
     if (rc) return rc;
@@ -2928,8 +2929,6 @@ int ake_pcnet_forward_train_f32(const ake_pcnet* n, const float* mel, int batch,
                                 float* key_out, float* tonic_out, float* genre_out, float* bn_stats_out, void* workspace,
                                 size_t ws_bytes, ake_stream_t stream) {
     AKE_REQUIRE(!n || !(n->cfg.p2pc_conv && n->cfg.stay_sixth), AKE_ERR_UNSUPPORTED, "pcnet: training a --p2pc_conv --stay_sixth net is not built (inference only)");
-    AKE_REQUIRE(!n || !n->cfg.denseblock || n->cfg.num_layers == 2, AKE_ERR_UNSUPPORTED, "pcnet: training a --denseblock net is built for num_layers 2 (got %d)",
-                n ? n->cfg.num_layers : 0);
     return forward_impl(n, true, mel, batch, frames, seq_length, key_out, tonic_out, genre_out, bn_stats_out, workspace, ws_bytes, stream);
 }
 

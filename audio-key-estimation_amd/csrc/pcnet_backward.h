@@ -293,53 +293,67 @@ struct Bwd {
         return AKE_OK;
     }
 
-    // the layer walk of a --denseblock net with two layers (models.py:361-396 with dense stacks, backwards): g_cat[1] is dL/d(layer 1's concat
-    // buffer) = pitch classes of layer 0 | folded semitone maps | layer 1's growth, and layer 0's block lives in its first channels
+    // the layer walk of a --denseblock net (models.py:361-396 with dense stacks, backwards), num_layers >= 2.  g_cat[li] is dL/d(layer li's concat
+    // buffer) = pitch classes of the layer below | folded semitone maps | the layer's growth; layer 0's block lives in the first channels of
+    // cat[1].  An inner layer's two streams each have a second consumer, the time-pooled copies the layer above starts from (models.py:394-395).
     int run_dense(const float* mel) {
         const auto& c = n->cfg;
-        const int P = c.pitches, tp = c.time_pool_size;
-        const LayerDims& d = n->dims[1];
-        const int T1 = b.Tl[1], g = c.n_filters * c.conv_layers, ctd = d.prev_pc + d.out_p + g;
+        const int L = c.num_layers, P = c.pitches, tp = c.time_pool_size, g = c.n_filters * c.conv_layers;
         int rc;
-        {   // time pool (models.py:396) of the whole concat buffer
-            const long long total = static_cast<long long>(B) * ctd * 12 * ((T1 / tp) + (T1 % tp ? 1 : 0));
-            ake::ProfScope ps("time_pool_bwd_kernel", s);
-            hipLaunchKernelGGL(time_pool_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_pcf, b.cat[1], static_cast<const float*>(nullptr),
-                               b.g_cat[1], ctd, 12, T1, tp, ctd, 0, total, 0);
+        for (int li = L - 1; li >= 1; --li) {
+            const LayerDims& d = n->dims[li];
+            const int Tl = b.Tl[li], ctd = d.prev_pc + d.out_p + g;
+            const std::string m = "model." + std::to_string(li) + ".";
+            {   // the time-pooled copy of the whole concat buffer: the heads' input (last layer) or the first channels of the next layer's buffer
+                const long long total = static_cast<long long>(B) * ctd * 12 * ((Tl / tp) + (Tl % tp ? 1 : 0));
+                const bool last = li == L - 1;
+                const int up_ctot = last ? ctd : n->dims[li + 1].prev_pc + n->dims[li + 1].out_p + g;
+                ake::ProfScope ps("time_pool_bwd_kernel", s);
+                hipLaunchKernelGGL(time_pool_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, last ? b.g_pcf : b.g_cat[li + 1], b.cat[li],
+                                   static_cast<const float*>(nullptr), b.g_cat[li], ctd, 12, Tl, tp, up_ctot, 0, total, 0);
+            }
+            float* scr_pc = b.g_pc[li];                      // [B][ctd][12][Tl] scratch (g_pc[li] holds two of them)
+            if ((rc = dense_block_backward(n->dense_pc[li], 1, b.cat[li], ctd, d.prev_pc + d.out_p, 12, Tl, b.g_cat[li], b.dn_gbott_pc, scr_pc, b.dn_bott_pc[li],
+                                           b.dn_aff1_pc[li], b.dn_aff2_pc[li], "conv_wgrad_kernel/pc2pc", "conv_mfma_kernel/pc2pc_dgrad")))
+                return rc;
+            // folded semitone maps -> pool_semi(li) -> dL/d(pitch features), all out_p channels
+            float* g_p = b.g_p[li];
+            float* scr_p = b.g_p[li] + static_cast<size_t>(B) * d.out_p * P * Tl;
+            if ((rc = semi_backward(li, b.pa[li], nullptr, b.g_cat[li], ctd, d.prev_pc, g_p))) return rc;
+            if (li < L - 1) {   // second consumer of an inner layer's pitch features: their time-pooled copy is the next pitch block's input (channels [0, out_p))
+                const long long total = static_cast<long long>(B) * d.out_p * P * ((Tl / tp) + (Tl % tp ? 1 : 0));
+                ake::ProfScope ps("time_pool_bwd_kernel", s);
+                hipLaunchKernelGGL(time_pool_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_p[li + 1], b.pa[li], static_cast<const float*>(nullptr),
+                                   g_p, d.out_p, P, Tl, tp, n->dims[li + 1].out_p, 0, total, 1);
+            }
+            if ((rc = dense_block_backward(n->dense_p[li], 0, b.pa[li], d.out_p, d.prev_p + d.prev_pc, P, Tl, g_p, b.dn_gbott_p, scr_p, b.dn_bott_p[li], b.dn_aff1_p[li],
+                                           b.dn_aff2_p[li], "conv_wgrad_kernel/p2p", "conv_mfma_kernel/p2p_dgrad")))
+                return rc;
+            {   // repeat (x P / 36) backward: channels [prev_p, prev_p + prev_pc) of the pitch block's input gradient -> the up_sixth map
+                const long long total = static_cast<long long>(B) * d.prev_pc * 36 * Tl;
+                ake::ProfScope ps("repeat_sum_kernel", s);
+                hipLaunchKernelGGL(repeat_sum_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, g_p, b.g_psix[li], d.out_p, d.prev_p, d.prev_pc, P, Tl, total);
+            }
+            bn_block_backward(m + "up_sixth_b", b.g_psix[li], b.psix[li], b.aff_p2pin[li] + 3 * d.prev_p, d.prev_pc, 0, 36 * Tl);
+            {
+                ake::ProfScope ps("up_sixth_bwd_weight_kernel", s);
+                hipLaunchKernelGGL(up_sixth_bwd_weight_kernel, dim3(d.prev_pc * d.prev_pc * 3, B), dim3(64), 0, s, b.g_psix[li], b.cat[li], static_cast<long long>(ctd) * 12 * Tl,
+                                   static_cast<const float*>(nullptr), grad_of(m + "up_sixth.weight"), static_cast<long long>(n->grad_floats), d.prev_pc, Tl);
+            }
+            {
+                const long long total = static_cast<long long>(B) * d.prev_pc * 12 * Tl;
+                ake::ProfScope ps("up_sixth_bwd_data_kernel", s);
+                hipLaunchKernelGGL(up_sixth_bwd_data_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_psix[li], raw_of(m + "up_sixth.weight"),
+                                   b.g_cat[li], ctd, d.prev_pc, Tl, total);
+            }
         }
-        float* scr_pc = b.g_pc[1];                       // [B][ctd][12][T1] scratch (g_pc[1] holds two of them)
-        if ((rc = dense_block_backward(n->dense_pc[1], 1, b.cat[1], ctd, d.prev_pc + d.out_p, 12, T1, b.g_cat[1], b.dn_gbott_pc, scr_pc, b.dn_bott_pc[1],
-                                       b.dn_aff1_pc[1], b.dn_aff2_pc[1], "conv_wgrad_kernel/pc2pc", "conv_mfma_kernel/pc2pc_dgrad")))
-            return rc;
-        // folded semitone maps -> pool_semi(1) -> dL/d(pitch features), all out_p channels
-        float* g_p = b.g_p[1];
-        float* scr_p = b.g_p[1] + static_cast<size_t>(B) * d.out_p * P * T1;
-        if ((rc = semi_backward(1, b.pa[1], nullptr, b.g_cat[1], ctd, d.prev_pc, g_p))) return rc;
-        if ((rc = dense_block_backward(n->dense_p[1], 0, b.pa[1], d.out_p, d.prev_p + d.prev_pc, P, T1, g_p, b.dn_gbott_p, scr_p, b.dn_bott_p[1], b.dn_aff1_p[1],
-                                       b.dn_aff2_p[1], "conv_wgrad_kernel/p2p", "conv_mfma_kernel/p2p_dgrad")))
-            return rc;
-        {   // repeat (x P / 36) backward: channels [prev_p, prev_p + prev_pc) of the pitch block's input gradient -> the up_sixth map
-            const long long total = static_cast<long long>(B) * d.prev_pc * 36 * T1;
-            ake::ProfScope ps("repeat_sum_kernel", s);
-            hipLaunchKernelGGL(repeat_sum_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, g_p, b.g_psix[1], d.out_p, d.prev_p, d.prev_pc, P, T1, total);
-        }
-        bn_block_backward("model.1.up_sixth_b", b.g_psix[1], b.psix[1], b.aff_p2pin[1] + 3 * d.prev_p, d.prev_pc, 0, 36 * T1);
-        {
-            ake::ProfScope ps("up_sixth_bwd_weight_kernel", s);
-            hipLaunchKernelGGL(up_sixth_bwd_weight_kernel, dim3(d.prev_pc * d.prev_pc * 3, B), dim3(64), 0, s, b.g_psix[1], b.cat[1], static_cast<long long>(ctd) * 12 * T1,
-                               static_cast<const float*>(nullptr), grad_of("model.1.up_sixth.weight"), static_cast<long long>(n->grad_floats), d.prev_pc, T1);
-        }
-        {
-            const long long total = static_cast<long long>(B) * d.prev_pc * 12 * T1;
-            ake::ProfScope ps("up_sixth_bwd_data_kernel", s);
-            hipLaunchKernelGGL(up_sixth_bwd_data_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, b.g_psix[1], raw_of("model.1.up_sixth.weight"),
-                               b.g_cat[1], ctd, d.prev_pc, T1, total);
-        }
-        // layer 0's block: channels [0, 1 + g) of the same buffer, input = the fold (channel 0)
-        if ((rc = dense_block_backward(n->dense_pc[0], 1, b.cat[1], ctd, 1, 12, T1, b.g_cat[1], b.dn_gbott_pc, scr_pc, b.dn_bott_pc[0], b.dn_aff1_pc[0],
+        // layer 0's block: channels [0, 1 + g) of layer 1's buffer, input = the fold (channel 0)
+        const LayerDims& d1 = n->dims[1];
+        const int T1 = b.Tl[1], ctd1 = d1.prev_pc + d1.out_p + g;
+        if ((rc = dense_block_backward(n->dense_pc[0], 1, b.cat[1], ctd1, 1, 12, T1, b.g_cat[1], b.dn_gbott_pc, b.g_pc[1], b.dn_bott_pc[0], b.dn_aff1_pc[0],
                                        b.dn_aff2_pc[0], "conv_wgrad_kernel/pc2pc0", "conv_mfma_kernel/pc2pc0_dgrad")))
             return rc;
-        return semi_backward(0, mel, nullptr, b.g_cat[1], ctd, 0, nullptr);
+        return semi_backward(0, mel, nullptr, b.g_cat[1], ctd1, 0, nullptr);
     }
 
     void bias_grad(const float* dz, int ctot, int coff, int C, int HT, gfx_t* db) {
@@ -448,8 +462,8 @@ struct Bwd {
             hipLaunchKernelGGL(head_pool_bwd_kernel, dim3((B * 12 + 63) / 64, 3), dim3(64), 0, s, pa);
         }
         // features feeding the heads: pcf (final) for L > 1, the raw last pc2pc output (+affine) for L == 1
-        const float* feat = L > 1 ? b.pcf : b.pcst[0].back();
-        const float* feat_aff = L > 1 ? nullptr : b.aff_pcst[0].back();
+        const float* feat = L > 1 ? b.pcf : (c.denseblock ? b.fold0 : b.pcst[0].back());      // (--denseblock, one layer: the block's feature buffer itself)
+        const float* feat_aff = (L > 1 || c.denseblock) ? nullptr : b.aff_pcst[0].back();
         float* g_feat = L > 1 ? b.g_pcf : b.g_pc[0];          // gradient w.r.t. the head input activation
         AKE_HIP_CHECK(hipMemsetAsync(g_feat, 0, sizeof(float) * B * fin * 12 * Tf, s));
 
@@ -491,6 +505,13 @@ struct Bwd {
         }
 
         planes_scratch = nullptr;
+        if (c.denseblock && L == 1) {   // g_pc[0] = dL/d(fold | the block's growth), [B][fin][12][T]; its second half is the block's scratch
+            float* gf = b.g_pc[0];
+            if ((rc = dense_block_backward(n->dense_pc[0], 1, b.fold0, fin, 1, 12, Ti, gf, b.dn_gbott_pc, gf + static_cast<size_t>(B) * fin * 12 * Ti, b.dn_bott_pc[0],
+                                           b.dn_aff1_pc[0], b.dn_aff2_pc[0], "conv_wgrad_kernel/pc2pc0", "conv_mfma_kernel/pc2pc0_dgrad")))
+                return rc;
+            return semi_backward(0, mel, nullptr, gf, fin, 0, nullptr);
+        }
         if (c.denseblock) return run_dense(mel);
         float* g_last = b.g_pc[i];                                   // ga w.r.t. the last pc2pc activation of the last layer
         float* g_last2 = b.g_pc[i] + static_cast<size_t>(B) * (i == 0 ? c.n_filters : d.out_pc) * 12 * Ti;

@@ -619,8 +619,6 @@ class PitchClassNet(LightningModule):
             stream = torch.cuda.current_stream().cuda_stream
             if self.training and self.p2pc_conv and self.stay_sixth:
                 raise NotImplementedError("training a --p2pc_conv --stay_sixth net is not built on the HIP path (inference only)")
-            if self.training and self.denseblock and self.num_layers != 2:
-                raise NotImplementedError("training a --denseblock net is built for num_layers 2 on the HIP path")
             if self.training:
                 # BatchNorm with batch statistics; with autograd enabled the call becomes one autograd node whose backward
                 # runs the HIP backward kernels (gradients for every parameter), as loss.backward() does in the reference

@@ -326,15 +326,17 @@ def test_denseblock_training_step_against_reference_fixture():
             assert int(sd_fwd[bn + ".num_batches_tracked"]) == 1, bn
 
 
-@pytest.mark.parametrize("n_filters,conv_layers,frames,seed", [(2, 2, 40, 0), (2, 2, 52, 1), (4, 3, 40, 1), (4, 3, 52, 2)])
-def test_denseblock_net_gradients(n_filters, conv_layers, frames, seed):
+@pytest.mark.parametrize("num_layers,n_filters,conv_layers,frames,seed", [(2, 2, 2, 40, 0), (2, 2, 2, 52, 1), (2, 4, 3, 40, 1), (2, 4, 3, 52, 2),
+                                                                          (1, 2, 2, 40, 0), (1, 4, 3, 52, 1), (3, 1, 1, 96, 0), (3, 2, 2, 96, 2)])
+def test_denseblock_net_gradients(num_layers, n_filters, conv_layers, frames, seed):
     """--denseblock training at the fixture's widths and at the default ones (76-channel bottlenecks, 51 -> 102 channel heads): the dense
     blocks' train-mode forward (block-input statistics, the statistics every later norm1 shares, per-layer tables) and their backward (the
     channel-sliced accumulate of the dense connections, zero-padded weight / data gradients of the plain Conv2d form, 12 x 1 bottlenecks)
-    against float64 autograd through the oracle.  Seeds: picks of tests/tools/dense_grad_scan.py."""
+    against float64 autograd through the oracle; two layers (the default), one (the block then feeds the heads directly) and three (an inner
+    layer: both of its streams have a second consumer, their time-pooled copies).  Seeds: picks of tests/tools/dense_grad_scan.py."""
     opt = Namespace(conv_layers=conv_layers, n_filters=n_filters, head_layers=2, time_pool_size=2, genre=True, max_pool=False, frames=5, denseblock=True)
     torch.manual_seed(60 + seed)
-    net = ake_amd.PitchClassNet(288, 12, 2, 7, opt)
+    net = ake_amd.PitchClassNet(288, 12, num_layers, 7, opt)
     sd32 = {k: v.clone() for k, v in net.state_dict().items()}
     x, seq, labels = make_case(2, frames, seed)
     loss_ref, ref = reference_grads(sd32, x, seq, labels)
