@@ -1736,32 +1736,41 @@ int rebuild_bf16_frags(ake_pcnet* n, hipStream_t s, bool train_only = false) {
         for (const PackedConv& pc : n->pc2pc[0])
             if (pc.l0_off >= 0)
                 hipLaunchKernelGGL(pack_l0_f16_kernel, dim3(3), dim3(256), 0, s, n->blob_dev + pc.w_off, n->bf_frags_dev + pc.l0_off, pc.cin, pc.cout);
-    for (const PackedConv* pc : tpc)
-        if (pc->bf_off >= 0) {
-            const int NT = pc->cout / 16;
-            hipLaunchKernelGGL(pc_weight_scale_kernel, dim3(pc->cout), dim3(256), 0, s, n->blob_dev + pc->w_off,
-                               reinterpret_cast<float*>(n->bf_frags_dev + pc->bf_off + pc->kh * 4 * NT * 2 * 64), pc->cin, pc->cout, pc->co, pc->kh);
-            hipLaunchKernelGGL(pack_pc_f16x3_kernel, dim3((pc->kh * 4 * NT * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
-                               n->bf_frags_dev + pc->bf_off, pc->cin, pc->cout, pc->co, NT, pc->kh, 0, 0);
-        }
-    for (const PackedConv* pc : tpd)
-        if (pc->bf_off >= 0) {
-            const int NT = (pc->cout + 15) / 16;
-            hipLaunchKernelGGL(pc_weight_scale_kernel, dim3(pc->cout), dim3(256), 0, s, n->blob_dev + pc->w_off,
-                               reinterpret_cast<float*>(n->bf_frags_dev + pc->bf_off + pc->kh * 4 * NT * 2 * 64), pc->cin, pc->cout, pc->co, pc->kh);
-            hipLaunchKernelGGL(pack_pc_f16x3_kernel, dim3((pc->kh * 4 * NT * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
-                               n->bf_frags_dev + pc->bf_off, pc->cin, pc->cout, pc->co, NT, pc->kh, pc->kh - 1, 0);
-        }
-    for (const PackedConv* pc : thd)
-        if (pc->bf_off >= 0)
-            for (int half = 0; half < 2; ++half) {
-                hipLaunchKernelGGL(pc_weight_scale_kernel, dim3(pc->cout), dim3(256), 0, s, n->blob_dev + pc->w_off,
-                                   reinterpret_cast<float*>(n->bf_frags_dev + (half ? pc->bf_off2 : pc->bf_off) + pc->kh * 4 * 2 * 64), pc->cin, pc->cout, pc->co, pc->kh);
-                hipLaunchKernelGGL(pack_pc_f16x3_kernel, dim3((pc->kh * 4 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + pc->w_off,
-                                   n->bf_frags_dev + (half ? pc->bf_off2 : pc->bf_off), pc->cin, pc->cout, pc->co, 1, pc->kh, pc->kh - 1, 16 * half);
+    {   // the training-mode packs (pitch-class stacks, their data gradients, the heads' data gradients; the pitch convs' raw forms): ONE launch per
+        // kernel for all of them, the jobs in the kernel argument (28 dependent launches of a few microseconds of work each were 0.39 ms per step)
+        std::vector<PcPackJob> jobs;
+        auto add = [&](const PackedConv* pc, long long off, int NT, int dy_rot, int ci_off) {
+            jobs.push_back(PcPackJob{n->blob_dev + pc->w_off, n->bf_frags_dev + off, pc->cin, pc->cout, pc->co, NT, pc->kh, dy_rot, ci_off});
+        };
+        for (const PackedConv* pc : tpc)
+            if (pc->bf_off >= 0) add(pc, pc->bf_off, pc->cout / 16, 0, 0);
+        for (const PackedConv* pc : tpd)
+            if (pc->bf_off >= 0) add(pc, pc->bf_off, (pc->cout + 15) / 16, pc->kh - 1, 0);
+        for (const PackedConv* pc : thd)
+            if (pc->bf_off >= 0)
+                for (int half = 0; half < 2; ++half) add(pc, half ? pc->bf_off2 : pc->bf_off, 1, pc->kh - 1, 16 * half);
+        for (size_t j0 = 0; j0 < jobs.size(); j0 += kMaxPackJobs) {
+            PcPackJobs js;
+            js.n = static_cast<int>(std::min<size_t>(kMaxPackJobs, jobs.size() - j0));
+            int max_cout = 1, max_blocks = 1;
+            for (int k = 0; k < js.n; ++k) {
+                js.j[k] = jobs[j0 + k];
+                max_cout = std::max(max_cout, js.j[k].cout);
+                max_blocks = std::max(max_blocks, (js.j[k].KH * 4 * js.j[k].NT * 64 + 255) / 256);
             }
-    for (const TrainFrag& t : tfr)
-        hipLaunchKernelGGL(pack_p2p_f16_raw_kernel, dim3((14 * 64 + 255) / 256), dim3(256), 0, s, n->blob_dev + t.raw, n->bf_frags_dev + t.pc->bf_off, t.cin, t.cout, t.flip);
+            hipLaunchKernelGGL(pc_weight_scale_jobs_kernel, dim3(max_cout, js.n), dim3(256), 0, s, js);
+            hipLaunchKernelGGL(pack_pc_f16x3_jobs_kernel, dim3(max_blocks, js.n), dim3(256), 0, s, js);
+        }
+        for (size_t j0 = 0; j0 < tfr.size(); j0 += kMaxPackJobs) {
+            P2pRawJobs js;
+            js.n = static_cast<int>(std::min<size_t>(kMaxPackJobs, tfr.size() - j0));
+            for (int k = 0; k < js.n; ++k) {
+                const TrainFrag& t = tfr[j0 + k];
+                js.j[k] = P2pRawJob{n->blob_dev + t.raw, n->bf_frags_dev + t.pc->bf_off, t.cin, t.cout, t.flip};
+            }
+            hipLaunchKernelGGL(pack_p2p_f16_raw_jobs_kernel, dim3((14 * 64 + 255) / 256, js.n), dim3(256), 0, s, js);
+        }
+    }
     for (size_t i = 1; !train_only && i < n->semi.size(); ++i)
         if (n->semi[i].bf_off >= 0)
             hipLaunchKernelGGL(pack_semi_f16_kernel, dim3(1), dim3(192), 0, s, n->blob_dev + n->semi[i].w_off, n->bf_frags_dev + n->semi[i].bf_off);

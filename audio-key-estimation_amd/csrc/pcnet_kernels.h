@@ -2098,9 +2098,17 @@ __global__ void nchw_to_cl16_f16x2_kernel(const float* __restrict__ src, long lo
 // py = 0 kernel compute it.
 // Inverse power-of-two scale of every output channel of a pack [group][ci][dy][dx][CO] (f16_weight_scale of its largest |w|), written
 // behind the fragments pack_pc_f16x3_kernel fills afterwards.  One workgroup per output channel.
-__global__ __launch_bounds__(256) void pc_weight_scale_kernel(const float* __restrict__ w, float* __restrict__ inv_scale, int cin, int cout, int CO, int KH) {
+// Several packs per launch (round 3: a training step re-packs ~14 convolutions after every optimizer step, two tiny launches each -- 28 dependent
+// launches, 0.39 ms of a 7 ms step, were launch latency): blockIdx.y picks the job, the jobs travel in the kernel argument.
+struct PcPackJob { const float* w; uint4* out; int cin, cout, CO, NT, KH, dy_rot, ci_off; };      // (the inverse scales live behind the fragments: out + KH * 4 * NT * 2 * 64)
+constexpr int kMaxPackJobs = 24;
+struct PcPackJobs { int n; PcPackJob j[kMaxPackJobs]; };
+struct P2pRawJob { const float* w; uint4* out; int cin_fwd, cout_fwd, transpose_flip; };
+struct P2pRawJobs { int n; P2pRawJob j[kMaxPackJobs]; };
+
+__device__ __forceinline__ void pc_weight_scale_body(const float* __restrict__ w, float* __restrict__ inv_scale, int cin, int cout, int CO, int KH, int bx) {
     __shared__ float red[4];
-    const int co = blockIdx.x;
+    const int co = bx;
     const int g = co / CO, c = co - g * CO;
     float m = 0.f;
     for (int r = threadIdx.x; r < cin * KH * 7; r += blockDim.x) m = fmaxf(m, fabsf(w[(static_cast<long long>(g) * cin * KH * 7 + r) * CO + c]));
@@ -2110,13 +2118,21 @@ __global__ __launch_bounds__(256) void pc_weight_scale_kernel(const float* __res
     __syncthreads();
     if (threadIdx.x == 0) inv_scale[co] = 1.f / f16_weight_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
+__global__ __launch_bounds__(256) void pc_weight_scale_kernel(const float* __restrict__ w, float* __restrict__ inv_scale, int cin, int cout, int CO, int KH) {
+    pc_weight_scale_body(w, inv_scale, cin, cout, CO, KH, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void pc_weight_scale_jobs_kernel(PcPackJobs js) {
+    const PcPackJob& J = js.j[blockIdx.y];
+    if (static_cast<int>(blockIdx.x) >= J.cout) return;                 // (uniform per block)
+    pc_weight_scale_body(J.w, reinterpret_cast<float*>(J.out + J.KH * 4 * J.NT * 2 * 64), J.cin, J.cout, J.CO, J.KH, blockIdx.x);
+}
 
 // ci_off: the fragments take input channels [ci_off, ci_off + 16) of the pack (a 32-channel data gradient runs as two halves).
-__global__ void pack_pc_f16x3_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin, int cout, int CO, int NT, int KH, int dy_rot,
-                                     int ci_off) {
+__device__ __forceinline__ void pack_pc_f16x3_body(const float* __restrict__ w, uint4* __restrict__ out, int cin, int cout, int CO, int NT, int KH, int dy_rot,
+                                                   int ci_off, int bx) {
     // (the inverse channel scales behind the fragments were written by pc_weight_scale_kernel: every block of this kernel scanning all
     // weights for the channel maxima cost 28 us per pack, 0.5 ms per training step)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = bx * blockDim.x + threadIdx.x;
     if (i >= KH * 4 * NT * 64) return;
     const int lane = i & 63, nt = (i >> 6) % NT, ks = i / (64 * NT);
     const int dy = ks >> 2, p = ks & 3;
@@ -2134,6 +2150,14 @@ __global__ void pack_pc_f16x3_kernel(const float* __restrict__ w, uint4* __restr
     }
     out[((ks * NT + nt) * 2 + 0) * 64 + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
     out[((ks * NT + nt) * 2 + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+__global__ void pack_pc_f16x3_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin, int cout, int CO, int NT, int KH, int dy_rot,
+                                     int ci_off) {
+    pack_pc_f16x3_body(w, out, cin, cout, CO, NT, KH, dy_rot, ci_off, blockIdx.x);
+}
+__global__ void pack_pc_f16x3_jobs_kernel(PcPackJobs js) {
+    const PcPackJob& J = js.j[blockIdx.y];
+    pack_pc_f16x3_body(J.w, J.out, J.cin, J.cout, J.CO, J.NT, J.KH, J.dy_rot, J.ci_off, blockIdx.x);
 }
 
 // debug taps: channels-last split-bf16 planes (xl != null) or one f16 plane (xl == null) [clip][H][T][C] -> NCHW f32 [clip][C][H][T]
@@ -2235,7 +2259,7 @@ __global__ void pack_semi_f16_kernel(const float* __restrict__ w, uint4* __restr
 // Weight fragments of conv_p2p_f16x3_kernel from the TORCH layout w[co][ci][7][7] (the raw copy of the parameter).
 // transpose_flip = 0: the forward (B[k = (tap, ci)][n = (tau, co)] = w[co][ci][dy][dx]); 1: the data gradient, a correlation of dz with
 // w'[n_out = ci][n_in = co][dy][dx] = w[co][ci][6 - dy][6 - dx].  n_in / n_out: channel counts of the convolution being packed (<= 8).
-__global__ void pack_p2p_f16_raw_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin_fwd, int cout_fwd, int transpose_flip) {
+__device__ __forceinline__ void pack_p2p_f16_raw_body(const float* __restrict__ w, uint4* __restrict__ out, int cin_fwd, int cout_fwd, int transpose_flip, int bx) {
     __shared__ int smax[8];
     const int n_in = transpose_flip ? cout_fwd : cin_fwd, n_out = transpose_flip ? cin_fwd : cout_fwd;
     auto wv = [&](int o, int i, int dy, int dx) {
@@ -2249,7 +2273,7 @@ __global__ void pack_p2p_f16_raw_kernel(const float* __restrict__ w, uint4* __re
         atomicMax(&smax[o], __float_as_int(fabsf(wv(o, i, t / 7, t % 7))));
     }
     __syncthreads();
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // (ks, lane)
+    const int idx = bx * blockDim.x + threadIdx.x;      // (ks, lane)
     if (idx >= 14 * 64) return;
     const int ks = idx / 64, lane = idx - ks * 64;
     const int dy = ks >> 1, h = ks & 1;
@@ -2270,6 +2294,13 @@ __global__ void pack_p2p_f16_raw_kernel(const float* __restrict__ w, uint4* __re
     }
     out[(2 * ks + 0) * 64 + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
     out[(2 * ks + 1) * 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+__global__ void pack_p2p_f16_raw_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cin_fwd, int cout_fwd, int transpose_flip) {
+    pack_p2p_f16_raw_body(w, out, cin_fwd, cout_fwd, transpose_flip, blockIdx.x);
+}
+__global__ void pack_p2p_f16_raw_jobs_kernel(P2pRawJobs js) {
+    const P2pRawJob& J = js.j[blockIdx.y];
+    pack_p2p_f16_raw_body(J.w, J.out, J.cin_fwd, J.cout_fwd, J.transpose_flip, blockIdx.x);
 }
 
 // Pitch2PitchClassPool (models.py:95-106) of ready semitone maps [clip][C][S][T], S a multiple of 12: max over the octaves
