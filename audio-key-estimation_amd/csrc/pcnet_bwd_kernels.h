@@ -494,17 +494,39 @@ __global__ __launch_bounds__(256) void semi_bwd_weight_kernel(const float* __res
     const int s_end = min(S, static_cast<int>(blockIdx.x + 1) * rows_per_wg);
     for (int srow = blockIdx.x * rows_per_wg + wave; srow < s_end; srow += 4) {
         // (index splits by multiply-high with precomputed reciprocals: two integer divisions per staged value were a third of the kernel)
-        for (int i = lane; i < C * T; i += 64) {
-            const int c = static_cast<int>(__umulhi(static_cast<unsigned int>(i), magicT)), t = i - c * T;
-            ldz[i] = dz[((static_cast<long long>(clip) * C + c) * S + srow) * T + t];
+        // Eight loads in flight per lane (round 3): with one load per loop iteration every value waited out a full memory round trip before its
+        // LDS store -- 40 dependent round trips per row and wave were this launch's 0.41 ms per step (its arithmetic is a tenth of that).  The
+        // loads are branch-free (clamped index), only the stores are guarded.
+        constexpr int kU = 8;
+        for (int i0 = lane; i0 < C * T; i0 += 64 * kU) {
+            float v[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int i = min(i0 + 64 * u, C * T - 1);
+                const int c = static_cast<int>(__umulhi(static_cast<unsigned int>(i), magicT)), t = i - c * T;
+                v[u] = dz[((static_cast<long long>(clip) * C + c) * S + srow) * T + t];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                if (i0 + 64 * u < C * T) ldz[i0 + 64 * u] = v[u];
         }
-        for (int i = lane; i < 3 * C * Tp; i += 64) {
-            const int cr = static_cast<int>(__umulhi(static_cast<unsigned int>(i), magicTp));      // (c, r) = i / Tp
-            const int c = static_cast<int>(__umulhi(static_cast<unsigned int>(cr), 0x55555556u)), r = cr - 3 * c, tj = i - cr * Tp;
-            int t = tj - 1;
-            t += t < 0 ? T : 0;
-            t -= t >= T ? T : 0;
-            lx[i] = affine_act(x[((static_cast<long long>(clip) * C + c) * H + 3 * srow + r) * T + t], x_aff, c);
+        for (int i0 = lane; i0 < 3 * C * Tp; i0 += 64 * kU) {
+            float v[kU];
+            int cs[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int i = min(i0 + 64 * u, 3 * C * Tp - 1);
+                const int cr = static_cast<int>(__umulhi(static_cast<unsigned int>(i), magicTp));      // (c, r) = i / Tp
+                const int c = static_cast<int>(__umulhi(static_cast<unsigned int>(cr), 0x55555556u)), r = cr - 3 * c, tj = i - cr * Tp;
+                int t = tj - 1;
+                t += t < 0 ? T : 0;
+                t -= t >= T ? T : 0;
+                cs[u] = c;
+                v[u] = x[((static_cast<long long>(clip) * C + c) * H + 3 * srow + r) * T + t];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                if (i0 + 64 * u < 3 * C * Tp) lx[i0 + 64 * u] = affine_act(v[u], x_aff, cs[u]);
         }
         // a wave's LDS slice is private: no workgroup barrier, the waitcnt the compiler inserts for the reads is enough
         if (pair < pairs) {
@@ -515,7 +537,8 @@ __global__ __launch_bounds__(256) void semi_bwd_weight_kernel(const float* __res
             float x0[3], x1[3];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) { x0[dy] = xr[dy * Tp]; x1[dy] = xr[dy * Tp + 1]; }
-            for (int t = 0; t < T; ++t) {
+#pragma unroll 4
+            for (int t = 0; t < T; ++t) {                          // (unrolled: the 16 LDS reads of four frames are requested together)
                 const float d = dr[t];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
@@ -1049,11 +1072,22 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_f16x3_kernel(WgradPcArgs a)
     // f16 hi + lo * 2^11 holds 22 bits below the largest value whatever the scale)
     const float* const zc = a.dz + clip * a.dz_clip_stride + static_cast<long long>(a.dz_coff + co0) * 12 * a.T_out;
     const int nzl = (a.cout - co0 < 16 ? a.cout - co0 : 16) * 12;
+    // Staging, eight lines in flight per wave (round 3): with one (channel, row) line per loop iteration every global load waited out a full
+    // memory round trip before its LDS stores -- 24 lines x 3 passes = 72 dependent round trips per workgroup, about half of this launch.
+    // A line of dz has T_seg <= 64 frames (one value per lane), a line of the input plane AP <= 128 elements (two); the loads are branch-free
+    // (clamped addresses), the stores guarded.
+    constexpr int kU = 8;
     {
         float m = 0.f;
-        for (int line = wave; line < nzl; line += 8) {
-            const float* zr = zc + static_cast<long long>(line) * a.T_out + t0;      // line = (channel, row): rows of T_out frames follow each other
-            for (int t = lane; t < T_seg; t += 64) m = fmaxf(m, fabsf(zr[t]));
+        for (int l0 = wave; l0 < nzl; l0 += 8 * kU) {
+            float v[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int line = min(l0 + 8 * u, nzl - 1);
+                v[u] = zc[static_cast<long long>(line) * a.T_out + t0 + (lane < T_seg ? lane : T_seg - 1)];      // line = (channel, row): rows of T_out frames follow each other
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) m = fmaxf(m, fabsf(v[u]));                                               // (clamped duplicates do not change a maximum)
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -1070,28 +1104,54 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_f16x3_kernel(WgradPcArgs a)
     {   // stage the input: one (channel, row) line of T_in frames per 64 threads' pass
         const float* xc = a.x + clip * a.x_clip_stride;
         const int ncl = (a.cin - ci0 < 16 ? a.cin - ci0 : 16) * 12;
-        for (int line = wave; line < ncl; line += 8) {
-            const int c = line / 12, row = line - 12 * c;
-            const float* xr = xc + (static_cast<long long>(ci0 + c) * 12 + row) * a.T_in;
-            for (int e0 = lane; e0 < a.AP; e0 += 64) {             // plane element e0 <-> input frame t0 + e0 - 8
-                const int t = t0 + e0 - 8;
-                if (t < 0 || t >= a.T_in) continue;
-                const float v = affine_act(xr[t], a.in_affine, ci0 + c);
-                const _Float16 hv = static_cast<_Float16>(v);
-                const int e = (row * 16 + c) * a.AP + e0;
-                aH[e] = __builtin_bit_cast(unsigned short, hv);
-                aL[e] = static_cast<unsigned short>(f16_bits((v - static_cast<float>(hv)) * kP2pLoScale));
+        for (int l0 = wave; l0 < ncl; l0 += 8 * kU) {
+            float v[kU][2];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int line = min(l0 + 8 * u, ncl - 1);
+                const int c = line / 12, row = line - 12 * c;
+                const float* xr = xc + (static_cast<long long>(ci0 + c) * 12 + row) * a.T_in;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {                          // plane element e0 <-> input frame t0 + e0 - 8
+                    int t = t0 + lane + 64 * h - 8;
+                    t = t < 0 ? 0 : (t >= a.T_in ? a.T_in - 1 : t);
+                    v[u][h] = xr[t];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int line = l0 + 8 * u;
+                if (line >= ncl) break;
+                const int c = line / 12, row = line - 12 * c;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e0 = lane + 64 * h, t = t0 + e0 - 8;
+                    if (e0 >= a.AP || t < 0 || t >= a.T_in) continue;
+                    const float x = affine_act(v[u][h], a.in_affine, ci0 + c);
+                    const _Float16 hv = static_cast<_Float16>(x);
+                    const int e = (row * 16 + c) * a.AP + e0;
+                    aH[e] = __builtin_bit_cast(unsigned short, hv);
+                    aL[e] = static_cast<unsigned short>(f16_bits((x - static_cast<float>(hv)) * kP2pLoScale));
+                }
             }
         }
-        for (int line = wave; line < nzl; line += 8) {
-            const int c = line / 12, row = line - 12 * c;
-            const float* zr = zc + (static_cast<long long>(c) * 12 + row) * a.T_out;
-            for (int t = lane; t < T_seg; t += 64) {
-                const float v = zr[t0 + t] * zs;
-                const _Float16 hv = static_cast<_Float16>(v);
-                const int e = (row * 16 + c) * a.ZP + t;
+        for (int l0 = wave; l0 < nzl; l0 += 8 * kU) {
+            float v[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int line = min(l0 + 8 * u, nzl - 1);
+                v[u] = zc[static_cast<long long>(line) * a.T_out + t0 + (lane < T_seg ? lane : T_seg - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int line = l0 + 8 * u;
+                if (line >= nzl || lane >= T_seg) continue;
+                const int c = line / 12, row = line - 12 * c;
+                const float x = v[u] * zs;
+                const _Float16 hv = static_cast<_Float16>(x);
+                const int e = (row * 16 + c) * a.ZP + lane;
                 zH[e] = __builtin_bit_cast(unsigned short, hv);
-                zL[e] = static_cast<unsigned short>(f16_bits((v - static_cast<float>(hv)) * kP2pLoScale));
+                zL[e] = static_cast<unsigned short>(f16_bits((x - static_cast<float>(hv)) * kP2pLoScale));
             }
         }
     }
