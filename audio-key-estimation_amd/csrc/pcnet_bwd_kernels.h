@@ -708,38 +708,88 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs wa) {
             __syncthreads();
             // ---- stage the input patch of channels [c_lo, c_lo+cc) (same loader as the forward conv) ----
             {
+                // (four patch rows in flight per wave -- up to 12 loads per lane -- instead of one dependent round trip per row; loads branch-free
+                // through clamped addresses, validity re-derived for the stores)
                 const int nrows = cc * R_in;
-                for (int rr = wave; rr < nrows; rr += nw) {
+                constexpr int kU = 4, kH = 3;                          // (Tp <= 192: at most three 64-frame pieces per row)
+                struct RowGeom { const float* srow; int cs; bool row_ok; };
+                auto row_geom = [&](int rr) {
                     const int cl = rr / R_in, rj = rr - cl * R_in;
-                    const int cs = c_lo + cl;
+                    RowGeom g;
+                    g.cs = c_lo + cl;
                     int row = y0 - a.py + rj;
-                    const bool row_ok = !a.rows_zero || (row >= 0 && row < a.H);       // rows_zero: zero padding instead of the circular wrap
+                    g.row_ok = !a.rows_zero || (row >= 0 && row < a.H);       // rows_zero: zero padding instead of the circular wrap
                     row += row < 0 ? a.H : 0;
                     row -= row >= a.H ? a.H : 0;
-                    float asc = 1.f, ash = 0.f, ang = 1.f;
-                    if (a.in_affine) { asc = a.in_affine[3 * cs]; ash = a.in_affine[3 * cs + 1]; ang = a.in_affine[3 * cs + 2]; }
-                    const float* srow = cs < a.c0 ? s0 + (static_cast<long long>(cs) * a.H + row) * a.T_in
-                                                  : s1 + (static_cast<long long>(cs - a.c0) * a.h1 + (row % a.h1)) * a.T_in;
-                    for (int h = 0; h < ncb; ++h) {
-                        const int tj = lane + 64 * h;
-                        if (tj >= Tp) break;
-                        int tin = t0 - a.pad_l + tj;
-                        float v = 0.f;
-                        bool ok = true;
-                        if (a.time_circ) {
-                            if (fast_wrap) { tin += tin < 0 ? a.T_in : 0; tin -= tin >= a.T_in ? a.T_in : 0; }
-                            else tin = wrap(tin, a.T_in);
-                        } else ok = tin >= 0 && tin < a.T_in;
-                        if (ok && row_ok) { const float x = fmaf(srow[tin], asc, ash); v = x > 0.f ? x : x * ang; }
-                        lds[rr * Tp + tj] = v;
+                    g.srow = g.cs < a.c0 ? s0 + (static_cast<long long>(g.cs) * a.H + row) * a.T_in
+                                         : s1 + (static_cast<long long>(g.cs - a.c0) * a.h1 + (row % a.h1)) * a.T_in;
+                    return g;
+                };
+                auto frame_of = [&](int tj, bool& ok) {                // input frame of patch column tj (clamped into the row when outside: ok = false)
+                    int tin = t0 - a.pad_l + tj;
+                    ok = true;
+                    if (a.time_circ) {
+                        if (fast_wrap) { tin += tin < 0 ? a.T_in : 0; tin -= tin >= a.T_in ? a.T_in : 0; }
+                        else tin = wrap(tin, a.T_in);
+                    } else {
+                        ok = tin >= 0 && tin < a.T_in;
+                        tin = tin < 0 ? 0 : (tin >= a.T_in ? a.T_in - 1 : tin);
+                    }
+                    return tin;
+                };
+                for (int r0 = wave; r0 < nrows; r0 += nw * kU) {
+                    float v[kU][kH];
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const RowGeom g = row_geom(min(r0 + nw * u, nrows - 1));
+#pragma unroll
+                        for (int h = 0; h < kH; ++h) {
+                            bool ok;
+                            v[u][h] = h < ncb ? g.srow[frame_of(min(lane + 64 * h, Tp - 1), ok)] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const int rr = r0 + nw * u;
+                        if (rr >= nrows) break;
+                        const RowGeom g = row_geom(rr);
+                        float asc = 1.f, ash = 0.f, ang = 1.f;
+                        if (a.in_affine) { asc = a.in_affine[3 * g.cs]; ash = a.in_affine[3 * g.cs + 1]; ang = a.in_affine[3 * g.cs + 2]; }
+#pragma unroll
+                        for (int h = 0; h < kH; ++h) {
+                            const int tj = lane + 64 * h;
+                            if (h >= ncb || tj >= Tp) break;
+                            bool ok;
+                            (void)frame_of(tj, ok);
+                            float val = 0.f;
+                            if (ok && g.row_ok) { const float x = fmaf(v[u][h], asc, ash); val = x > 0.f ? x : x * ang; }
+                            lds[rr * Tp + tj] = val;
+                        }
                     }
                 }
                 // ---- dz tile, zero outside the valid rows / frames ----
                 const int nz = a.cout * a.R;
-                for (int rr = wave; rr < nz; rr += nw) {
-                    const int co = rr / a.R, ry = rr - co * a.R;
-                    const float* zrow = dzc + (static_cast<long long>(a.dst_coff + co) * a.H_out + y0 + ry) * a.T_out + t0;
-                    for (int tj = lane; tj < TTp; tj += 64) ldsZ[rr * TTp + tj] = (ry < rows_here && tj < tt_here) ? zrow[tj] : 0.f;
+                for (int r0 = wave; r0 < nz; r0 += nw * kU) {
+                    float v[kU][2];                                    // (TTp <= 128: two pieces)
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const int rr = min(r0 + nw * u, nz - 1);
+                        const int co = rr / a.R, ry = min(rr - co * a.R, rows_here - 1);
+                        const float* zrow = dzc + (static_cast<long long>(a.dst_coff + co) * a.H_out + y0 + ry) * a.T_out + t0;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) v[u][h] = zrow[min(lane + 64 * h, tt_here - 1)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const int rr = r0 + nw * u;
+                        if (rr >= nz) break;
+                        const int co = rr / a.R, ry = rr - co * a.R;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int tj = lane + 64 * h;
+                            if (tj < TTp) ldsZ[rr * TTp + tj] = (ry < rows_here && tj < tt_here) ? v[u][h] : 0.f;
+                        }
+                    }
                 }
             }
             __syncthreads();
