@@ -46,7 +46,7 @@ struct Bwd {
         unsigned int* cell = reinterpret_cast<unsigned int*>(b.stats2 + static_cast<size_t>(3) * n->bn_channels * kBwdStatSlots) + static_cast<size_t>(bn) * kAmaxSlots;
         {
             ake::ProfScope ps("bn_bwd_apply_kernel", s);
-            hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, g, z, coef, ctot, coff, HT, cell);
+            hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, g, z, aff, coef, ctot, coff, HT, cell);
         }
         amax_of = g; amax_cell = cell;
     }

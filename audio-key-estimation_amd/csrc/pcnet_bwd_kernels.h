@@ -140,7 +140,9 @@ constexpr int kBwdStatSlots = 16;
 // The third sum is what makes the gradient leave this block with sum(dz) == 0 to rounding: the consumers (weight
 // gradients) multiply dz with activations that have a large common mean, so a per-channel offset of a few 1e-8 in dz
 // would otherwise show up as a 1e-3 relative error in dW.
-__global__ __launch_bounds__(256) void act_bwd_stats_kernel(float* __restrict__ g, const float* __restrict__ z,
+// (Round 3: this pass only READS.  It used to store g1 = ga * act'(z) back into g for the apply pass -- 179 MB per pitch convolution and step;
+// bn_bwd_apply_kernel recomputes it from the same two values it loads anyway.)
+__global__ __launch_bounds__(256) void act_bwd_stats_kernel(const float* __restrict__ g, const float* __restrict__ z,
                                                             const float* __restrict__ aff, const float* __restrict__ bstats,
                                                             double* __restrict__ stats2, long long slot_stride, int ctot, int coff, int HT) {
     const int c = blockIdx.x, clip = blockIdx.y;
@@ -160,16 +162,15 @@ __global__ __launch_bounds__(256) void act_bwd_stats_kernel(float* __restrict__ 
     // 16-byte accesses when the slice allows it (the pass is memory-bound: 0.87 ms per step with 4-byte accesses)
     const bool vec = (HT & 3) == 0 && (base & 3) == 0 && ((reinterpret_cast<unsigned long long>(g) | reinterpret_cast<unsigned long long>(z)) & 15) == 0;
     if (vec) {
-        float4* g4 = reinterpret_cast<float4*>(g + base);
+        const float4* g4 = reinterpret_cast<const float4*>(g + base);
         const float4* z4 = reinterpret_cast<const float4*>(z + base);
         for (int i = threadIdx.x; i < HT / 4; i += 256) {
-            float4 gv = g4[i];
+            const float4 gv = g4[i];
             const float4 zv = z4[i];
-            gv.x = one(gv.x, zv.x); gv.y = one(gv.y, zv.y); gv.z = one(gv.z, zv.z); gv.w = one(gv.w, zv.w);
-            g4[i] = gv;
+            (void)one(gv.x, zv.x); (void)one(gv.y, zv.y); (void)one(gv.z, zv.z); (void)one(gv.w, zv.w);
         }
     } else {
-        for (int i = threadIdx.x; i < HT; i += 256) g[base + i] = one(g[base + i], z[base + i]);
+        for (int i = threadIdx.x; i < HT; i += 256) (void)one(g[base + i], z[base + i]);
     }
     __shared__ float r1[4], r2[4], r3[4];
 #pragma unroll
@@ -213,11 +214,13 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ stats2, long long 
 // amax (nullable): the bits of the largest |dz| of the whole tensor (atomicMax on the bit pattern of a non-negative float: order-independent,
 // so the step stays bit-reproducible).  The f16 x 3 data-gradient kernels that read this dz scale it by a power of two taken from it before
 // the hi / lo split (at 256 clips x 76 frames most dz are 1e-6..1e-9, f16's subnormal range).
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ z,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ z, const float* __restrict__ aff,
                                                            const float* __restrict__ coef, int ctot, int coff, int HT, unsigned int* __restrict__ amax) {
     const int c = blockIdx.x, clip = blockIdx.y;
     const long long base = (static_cast<long long>(clip) * ctot + coff + c) * HT;
     const float c0 = coef[4 * c], c1 = coef[4 * c + 1], c2 = coef[4 * c + 2], mu = coef[4 * c + 3];
+    const float sc = aff[3 * c], sh = aff[3 * c + 1], ng = aff[3 * c + 2];
+    auto g1 = [&](float ga, float zz) { return ga * (fmaf(zz, sc, sh) > 0.f ? 1.f : ng); };      // the activation's derivative, exactly as act_bwd_stats_kernel took it
     const bool vec = (HT & 3) == 0 && (base & 3) == 0 && ((reinterpret_cast<unsigned long long>(g) | reinterpret_cast<unsigned long long>(z)) & 15) == 0;
     float m = 0.f;
     if (vec) {
@@ -226,14 +229,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
         for (int i = threadIdx.x; i < HT / 4; i += 256) {
             float4 gv = g4[i];
             const float4 zv = z4[i];
-            gv.x = fmaf(gv.x, c0, fmaf(zv.x - mu, c1, c2)); gv.y = fmaf(gv.y, c0, fmaf(zv.y - mu, c1, c2));
-            gv.z = fmaf(gv.z, c0, fmaf(zv.z - mu, c1, c2)); gv.w = fmaf(gv.w, c0, fmaf(zv.w - mu, c1, c2));
+            gv.x = fmaf(g1(gv.x, zv.x), c0, fmaf(zv.x - mu, c1, c2)); gv.y = fmaf(g1(gv.y, zv.y), c0, fmaf(zv.y - mu, c1, c2));
+            gv.z = fmaf(g1(gv.z, zv.z), c0, fmaf(zv.z - mu, c1, c2)); gv.w = fmaf(g1(gv.w, zv.w), c0, fmaf(zv.w - mu, c1, c2));
             m = fmaxf(fmaxf(m, fmaxf(fabsf(gv.x), fabsf(gv.y))), fmaxf(fabsf(gv.z), fabsf(gv.w)));
             g4[i] = gv;
         }
     } else {
         for (int i = threadIdx.x; i < HT; i += 256) {
-            const float v = fmaf(g[base + i], c0, fmaf(z[base + i] - mu, c1, c2));
+            const float v = fmaf(g1(g[base + i], z[base + i]), c0, fmaf(z[base + i] - mu, c1, c2));
             m = fmaxf(m, fabsf(v));
             g[base + i] = v;
         }
