@@ -550,16 +550,19 @@ __global__ __launch_bounds__(256) void cqt_bank_kernel(
 // x = xh + xl and w = wh + wl (each bf16, residual <= 2^-17 relative); acc += xh*wh + xl*wh + xh*wl on
 // v_mfma_f32_16x16x32_bf16 (f32 accumulation): 3 MFMAs of 16 cycles per 32 taps and N-tile instead of 8 f32 MFMAs of 32
 // cycles, at ~1e-5 relative accuracy (the multirate design itself is specified to 1.6e-4).
-// Workgroup = (frame t, octave o, 256 clips): the whole phase table of (o, t) is staged in LDS ONCE (<= 92 KB) and shared
-// by 16 waves of one 16-clip M-tile each.  A operand: lane (row r = clip, q) holds taps 32*blk + 8q .. +7 of its clip =
+// Workgroup = (frame t, octave o, kBankClips clips): the phase table of (o, t) is staged in LDS in chunks (51 KB) and shared
+// by the workgroup's waves, one 16-clip M-tile each.  A operand: lane (row r = clip, q) holds taps 32*blk + 8q .. +7 of its clip =
 // two dword-aligned 16-byte loads of interleaved (hi, lo) words, de-interleaved with 8 v_perm_b32 (the signals are padded,
 // no bounds checks).
+constexpr int kBankWaves = 8;           // waves (M-tiles of 16 clips) per workgroup: 128 clips.  (16 waves = 256 clips read each phase table once, but at 80
+                                        // registers only ONE such workgroup fits a CU; three of these do, and a workgroup's two table chunks are latency chains)
+constexpr int kBankClips = 16 * kBankWaves, kBankThreads = 64 * kBankWaves;
 constexpr int kBank2Chunk = 5;          // 32-tap blocks of the phase table resident in LDS at a time (51 KB: two workgroups per CU)
 typedef unsigned int u32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4b __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(1024) void cqt_bank_bf16_kernel(
+__global__ __launch_bounds__(kBankThreads) void cqt_bank_bf16_kernel(
     BankCall2 call, const OctDesc2* __restrict__ octs, const uint4* __restrict__ table,
     int batch, int hop, int hop_twos, float* __restrict__ out, long long out_clip_stride, int n_bins_total, int n_frames, int o_first) {
     extern __shared__ __attribute__((aligned(16))) uint4 ldsW[];
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(1024) void cqt_bank_bf16_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, q = lane >> 4;
-    const int clip_raw = blockIdx.z * 256 + wave * 16 + r16;
+    const int clip_raw = blockIdx.z * kBankClips + wave * 16 + r16;
     const int clip = clip_raw < batch ? clip_raw : batch - 1;       // idle rows redo the last clip (never stored)
     const long long c = static_cast<long long>(t) * hop;
     const int c_int = static_cast<int>(c >> o);
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(1024) void cqt_bank_bf16_kernel(
     f32x4b acc[kMaxTiles];
 #pragma unroll
     for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4b{0.f, 0.f, 0.f, 0.f};
-    const bool idle = blockIdx.z * 256 + wave * 16 >= batch;        // whole M-tile beyond the batch: only helps staging
+    const bool idle = blockIdx.z * kBankClips + wave * 16 >= batch;        // whole M-tile beyond the batch: only helps staging
 #pragma unroll 1                                                      // (unrolled by two the chunks' A fragments are live together: 485 spills)
     for (int b0 = 0; b0 < g.n_blk; b0 += kBank2Chunk) {             // the phase table in chunks of kBank2Chunk blocks
         const int nbc = g.n_blk - b0 < kBank2Chunk ? g.n_blk - b0 : kBank2Chunk;
@@ -605,10 +608,10 @@ __global__ __launch_bounds__(1024) void cqt_bank_bf16_kernel(
             // (0.070 -> 0.066 ms per 256 clips).
             const uint4* src = w + static_cast<long long>(b0) * (kMaxTiles * 2 * 64);
             const int total = nbc * kMaxTiles * 2 * 64;                      // a multiple of 64: a wave's piece is whole or absent
-            constexpr int kU = (kBank2Chunk * kMaxTiles * 2 * 64 + 1023) / 1024;
+            constexpr int kU = (kBank2Chunk * kMaxTiles * 2 * 64 + kBankThreads - 1) / kBankThreads;
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-                const int i0 = wave * 64 + 1024 * u;
+                const int i0 = wave * 64 + kBankThreads * u;
                 if (i0 < total) {
                     const uint4* sp = src + i0 + lane;
                     const unsigned int lds_dst = static_cast<unsigned int>(reinterpret_cast<unsigned long long>(ldsW + i0));   // LDS aperture: low 32 bits = byte address
@@ -653,7 +656,7 @@ __global__ __launch_bounds__(1024) void cqt_bank_bf16_kernel(
         for (int reg = 0; reg < 4; ++reg) {
             const float v2 = acc[j][reg] * acc[j][reg];
             const float m2 = v2 + __shfl_xor(v2, 1);
-            const int cl2 = blockIdx.z * 256 + wave * 16 + 4 * q + reg;
+            const int cl2 = blockIdx.z * kBankClips + wave * 16 + 4 * q + reg;
             // KeyDataset.py:497-499 is literally log(1 + |C|); v_sqrt_f32 / v_log_f32 (1 ulp class) instead of libm's log1pf
             if ((r16 & 1) == 0 && j < g.n_tiles && b < g.n_bins && cl2 < batch)
                 out[cl2 * out_clip_stride + static_cast<long long>(t) * n_bins_total + g.k0 + b] = __logf(1.f + __builtin_amdgcn_sqrtf(m2));
@@ -1156,9 +1159,9 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
         }
         launch_cascade(ca);
         scratch = frames_major ? out : c.take<float>(static_cast<size_t>(batch) * T * p->cfg.n_bins);
-        dim3 grid(static_cast<unsigned>((T + 7) / 8 * 8), p->n_oct, (batch + 255) / 256);
+        dim3 grid(static_cast<unsigned>((T + 7) / 8 * 8), p->n_oct, (batch + kBankClips - 1) / kBankClips);
         ake::ProfScope ps("cqt_bank_bf16_kernel", stream);
-        hipLaunchKernelGGL(cqt_bank_bf16_kernel, grid, dim3(1024), p->bank2_lds, stream, call2, p->octs2_dev, p->table2_dev, batch,
+        hipLaunchKernelGGL(cqt_bank_bf16_kernel, grid, dim3(kBankThreads), p->bank2_lds, stream, call2, p->octs2_dev, p->table2_dev, batch,
                            p->cfg.hop_length, p->hop_twos, scratch, static_cast<long long>(T) * p->cfg.n_bins, p->cfg.n_bins, static_cast<int>(T), 0);
     } else if (p->engine == 3) {
         BankCall2 call2;
@@ -1182,9 +1185,9 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
         }
         launch_cascade(a);
         scratch = frames_major ? out : c.take<float>(static_cast<size_t>(batch) * T * p->cfg.n_bins);
-        dim3 grid(static_cast<unsigned>((T + 7) / 8 * 8), p->n_oct, (batch + 255) / 256);
+        dim3 grid(static_cast<unsigned>((T + 7) / 8 * 8), p->n_oct, (batch + kBankClips - 1) / kBankClips);
         ake::ProfScope ps("cqt_bank_bf16_kernel", stream);
-        hipLaunchKernelGGL(cqt_bank_bf16_kernel, grid, dim3(1024), p->bank2_lds, stream, call2, p->octs2_dev, p->table2_dev, batch,
+        hipLaunchKernelGGL(cqt_bank_bf16_kernel, grid, dim3(kBankThreads), p->bank2_lds, stream, call2, p->octs2_dev, p->table2_dev, batch,
                            p->cfg.hop_length, p->hop_twos, scratch, static_cast<long long>(T) * p->cfg.n_bins, p->cfg.n_bins, static_cast<int>(T), 0);
     } else {
         BankCall call;
