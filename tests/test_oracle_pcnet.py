@@ -212,7 +212,7 @@ def test_denseblock_training_step_against_reference_fixture():
     out = pcnet_oracle.pcnet_forward(sd, torch.from_numpy(gold["x"]).double(), torch.from_numpy(gold["seq_length"]), training=True)
     loss = (F.binary_cross_entropy(out[0], torch.from_numpy(gold["key_labels"])) + F.cross_entropy(out[1], torch.from_numpy(gold["tonic_idx"]))
             + 0.1 * F.cross_entropy(out[2], torch.from_numpy(gold["genre_idx"])))
-    assert abs(float(loss) - float(gold["loss"])) < 1e-12
+    assert abs(float(loss.detach()) - float(gold["loss"])) < 1e-12
     loss.backward()
     names = [k[5:] for k in gold.files if k.startswith("grad/")]
     gmax = max(float(np.abs(gold["grad/" + k]).max()) for k in names)
