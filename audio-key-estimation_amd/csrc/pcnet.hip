@@ -670,7 +670,7 @@ bool run_p2p_f16_ps(const ake_pcnet* n, const PackedConv& pc, const unsigned sho
 // 7 x 7 circular pitch convolution with f32-equivalent products (conv_p2p_f16x3_kernel): train-mode forward (in_aff, bias, statistics)
 // and data gradient (none of them).  false when the shape does not qualify: the caller then runs conv_mfma_kernel.
 bool run_p2p_f16x3(const ake_pcnet* n, long long frag_off, const Src& src, const float* in_aff, const float* bias, int batch, int H, int T, float* dst,
-                   int cout, double* stats, int stats_stride, hipStream_t s, const char* name, const unsigned int* in_amax = nullptr) {
+                   int cout, double* stats, int stats_stride, hipStream_t s, const char* name, const unsigned int* in_amax = nullptr, bool lrelu = false) {
     static const bool off = ake::diag_env("AKE_P2P_TRAIN_F32") != nullptr;
     if (off || frag_off < 0 || T < 2 || (T & 1) || src.c0 < 1 || src.c0 + src.c1 > 8 || cout > 8 || src.ctot0 != 0) return false;
     P2pTrArgs a;
@@ -692,7 +692,7 @@ bool run_p2p_f16x3(const ake_pcnet* n, long long frag_off, const Src& src, const
     a.p = src.p0; a.c0 = src.c0; a.u = src.p1 ? src.p1 : src.p0; a.c1 = src.p1 ? src.c1 : 0; a.h1 = src.h1 > 0 ? src.h1 : 1;
     a.in_aff = in_aff; a.bfrag = n->bf_frags_dev + frag_off; a.bias = bias;
     a.dst = dst; a.dst_clip_stride = clip_stride; a.cout = cout;
-    a.stats = stats; a.stats_stride = stats_stride; a.in_amax = in_amax;
+    a.stats = stats; a.stats_stride = stats_stride; a.in_amax = in_amax; a.lrelu = lrelu ? 1 : 0;
     static ake::DeviceOnce attr_set;
     if (attr_set.need()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p2p_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
@@ -2516,6 +2516,14 @@ struct Fwd {
                         in_aff = out_aff;
                         continue;
                     }
+                }
+                // inference in the f32x3 precision mode: the same persistent kernel with the EVAL fragments (BatchNorm folded; f16 hi + lo operands,
+                // three products: f32-equivalent to 2^-22) and LeakyReLU in its epilogue, instead of the f32-MFMA kernel at the vector rate
+                if (!train && c.precision == AKE_PRECISION_F32X3 && !c.pc2p_mem && !c.stay_sixth && !g_keep_taps && n->p2p[i][j].bf_off >= 0 &&
+                    run_p2p_f16x3(n, n->p2p[i][j].bf_off, sdesc, nullptr, n->blob_dev + n->p2p[i][j].b_off, B, P, Ti, out, d.out_p, nullptr, 0, s,
+                                  "conv_p2p_f16x3_kernel/p2p", nullptr, true)) {
+                    sdesc = Src{out, d.out_p, nullptr, 0, 0};
+                    continue;
                 }
                 if ((rc = conv(n->p2p[i][j], train ? n->p2p_t[i][j] : n->p2p[i][j], m + "p2p.layer." + std::to_string(3 * j + 1), 0, sdesc,
                                in_aff, B, P, Ti, true, out, d.out_p, 0, out_aff, "conv_mfma_kernel/p2p")))

@@ -1281,6 +1281,7 @@ struct P2pTrArgs {
     int stats_stride;
     int H, T, R, J, Tp, n_row_tiles, n_tiles, plane_pos;
     const unsigned int* in_amax;  // data gradient (in_aff == null): bits of the largest |dz|; dz is staged times f16_weight_scale(max), divided out in the epilogue
+    int lrelu;                    // 1: LeakyReLU on the stored value (inference in the f32x3 precision mode: BatchNorm is folded into bfrag / bias)
 };
 
 __global__ __launch_bounds__(512) void conv_p2p_f16x3_kernel(P2pTrArgs a) {
@@ -1435,7 +1436,7 @@ __global__ __launch_bounds__(512) void conv_p2p_f16x3_kernel(P2pTrArgs a) {
             for (int i = 0; i < 4; ++i) {
                 const float v = fmaf(fmaf(accl[mt][i], kP2pLoInv, acc[mt][i]), iscale, bias);
                 if ((wave * MT + mt) * 16 + 4 * q + i < mblk) sst.add(v);
-                st[co * 36 + (4 * q + i) * 2 + tau] = v;
+                st[co * 36 + (4 * q + i) * 2 + tau] = a.lrelu ? fmaxf(v, v * kSlope) : v;
             }
         }
         if (next >= 0) write_lds(cur ^ 1);

@@ -29,8 +29,8 @@ PRECISIONS = {"mixed": 0, "f32x3": 1, 0: 0, 1: 1}
 PRECISION_DTYPES = {
     0: "f32 accumulation everywhere; pitch / semitone / layer-0 convolutions: f16 activations x f16 weights (per-channel power-of-two scaled) on "
        "MFMA, one product; last layer's pitch-class convolutions and heads: 3-term split-bf16 on MFMA (hi*hi + lo*hi + hi*lo)",
-    1: "f32 accumulation everywhere; pitch / semitone / layer-0 convolutions: exact f32 (v_mfma_f32_16x16x4_f32 / VALU); pitch-class "
-       "convolutions and heads: 3-term split-bf16 on MFMA (operands to 2^-17)",
+    1: "f32 accumulation everywhere; pitch convolutions: f16 hi + lo operands, three MFMA products (f32-equivalent to 2^-22); semitone / layer-0 "
+       "convolutions: exact f32 (v_mfma_f32_16x16x4_f32 / VALU); pitch-class convolutions and heads: 3-term split-bf16 on MFMA (operands to 2^-17)",
 }
 
 

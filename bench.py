@@ -403,8 +403,9 @@ def main():
     net = net.to(dev).eval()
     net_dtype = net.precision_dtype()                                   # read back from the device handle (ake_pcnet_precision)
     # the dominant kernel of each mode: the three 7x7 pitch convolutions (65 % of the MACs)
-    DOM = "conv_p2p_f16_kernel" if args.precision == "mixed" else "conv_mfma_kernel/p2p"
-    DOM_PEAK = PEAK_BF16_TFLOPS if args.precision == "mixed" else PEAK_FP32_TFLOPS
+    # f32x3: the same persistent pitch-conv kernel with f16 hi + lo operands, three MFMA products per MAC (f32-equivalent to 2^-22)
+    DOM = "conv_p2p_f16_kernel" if args.precision == "mixed" else "conv_p2p_f16x3_kernel/p2p"
+    DOM_PEAK = PEAK_BF16_TFLOPS
     est = ake_amd.KeyEstimator(net, SR, FRAMES, streams=args.streams)
     est1 = est if args.streams == 1 else ake_amd.KeyEstimator(net, SR, FRAMES)      # second, untimed pass: one step after the other
     B, R = args.batch, max(1, args.rotate)
@@ -537,10 +538,10 @@ def main():
                                 "v_mfma_f32_16x16x32_f16 with f32 accumulation: 1 MFMA product per algorithmic MAC), 3 launches per step; the third "
                                 "also runs the semitone conv and the octave maximum on its output tiles and writes only the folded maps")
                                if args.precision == "mixed" else
-                               "conv_mfma_kernel (7x7 circular pitch convolution as an implicit GEMM on v_mfma_f32_16x16x4_f32: exact f32, the vector rate), 3 launches per step",
+                               "conv_p2p_f16x3_kernel (the persistent 7x7 circular pitch convolution with f16 hi + lo operands: three v_mfma_f32_16x16x32_f16 products per algorithmic MAC, f32-equivalent to 2^-22; f32 NCHW in and out), 3 launches per step",
                      "achieved": round(achieved, 2) if achieved else None, "peak": DOM_PEAK, "unit": "TFLOP/s",
                      "frac": round(achieved / DOM_PEAK, 4) if achieved else None,
-                     "mfma_products_per_mac": 1 if args.precision == "mixed" else None,
+                     "mfma_products_per_mac": 1 if args.precision == "mixed" else 3,
                      "traffic": p2p_traffic,
                      "traffic_source": f"profiles/{traffic_src}: mean HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE" if p2p_traffic else traffic_stale,
                      # mean over the three launches: (1 CQT + 4 x 36-row up_sixth channels, f32 -> 8 channels, f16), (8 -> 8, f16 both), (8 f16 -> 8
