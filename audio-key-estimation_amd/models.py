@@ -340,7 +340,7 @@ class PitchClassNet(LightningModule):
         self.pc2p_mem = bool(_opt_get(opt, "pc2p_mem", False))
         self.p2pc_conv = bool(_opt_get(opt, "p2pc_conv", False))
         self.stay_sixth = bool(_opt_get(opt, "stay_sixth", False))
-        # --denseblock (models.py:188-189, 225-226, 456-648): DenseNet-style stacks.  Inference only here.
+        # --denseblock (models.py:188-189, 225-226, 456-648): DenseNet-style stacks (inference and training).
         self.denseblock = bool(_opt_get(opt, "denseblock", False))
         if self.denseblock and (self.resblock or self.pc2p_mem or self.p2pc_conv or self.stay_sixth or self.local):
             raise NotImplementedError("--denseblock together with --resblock / --pc2p_mem / --p2pc_conv / --stay_sixth / --local is not built")
