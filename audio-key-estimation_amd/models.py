@@ -327,7 +327,7 @@ class PitchClassNet(LightningModule):
                                           "(SURVEY.md section 2.1); only the default PitchClassNet family is available")
         nf, k = self.n_filters, kernel_size
         # --local (sliding-window key tracking, models.py:720-722): no time pooling in the layers, the key / tonic heads end in
-        # MaxPool2d((1, W), stride 1) -- parameter-free, so the state_dict is the default net's.  Inference only here.
+        # MaxPool2d((1, W), stride 1) -- parameter-free, so the state_dict is the default net's (inference and training).
         self.local = bool(_opt_get(opt, "local", False))
         self.local_window = 0
         if self.local:
@@ -335,7 +335,7 @@ class PitchClassNet(LightningModule):
                                     - _opt_get(opt, "head_layers", 2) * (kernel_size - 1))
             if self.local_window < 1:
                 raise ValueError("--local: frames * loc_window_size must exceed head_layers * (kernel_size - 1)")
-        # --resblock (models.py:181-187, 218-224, 402-454): the stacks are one conv + conv_layers residual blocks.  Inference only here.
+        # --resblock (models.py:181-187, 218-224, 402-454): the stacks are one conv + conv_layers residual blocks (inference and training).
         self.resblock = bool(_opt_get(opt, "resblock", False))
         self.pc2p_mem = bool(_opt_get(opt, "pc2p_mem", False))
         self.p2pc_conv = bool(_opt_get(opt, "p2pc_conv", False))
