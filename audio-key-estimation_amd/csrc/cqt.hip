@@ -389,7 +389,11 @@ __global__ __launch_bounds__(NT) void cqt_cascade_kernel(CascArgs a) {
     __syncthreads();
     unsigned long long sm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts[10];
     for (int k = k_start; k < k_end; ++k) {
-        if (STAMP) ts[0] = casc_stamp();
+        if (STAMP) {
+            ts[0] = casc_stamp();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // how long the prefetched chunk is still outstanding
+            sm[9] += casc_stamp() - ts[0];
+        }
         const bool owned = k >= k_own;
         if (S == 1 && k > k_start) {                                  // single stage: level 0 is also the deepest level
             float4 h = {0.f, 0.f, 0.f, 0.f};
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(NT) void cqt_cascade_kernel(CascArgs a) {
     }
     if (STAMP && blockIdx.x == 1 && blockIdx.y == 0 && (tid & 63) == 0 && a.stamps) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) a.stamps[(tid >> 6) * 16 + i] = sm[i];
+        for (int i = 0; i < 10; ++i) a.stamps[(tid >> 6) * 16 + i] = sm[i];
     }
 }
 
@@ -1100,7 +1104,7 @@ int cqt_logmag_impl(const ake_cqt_plan* p, const float* audio, int batch, int64_
                 for (int wv = 0; wv < 4; ++wv) {
                     fprintf(stderr, "cascade stamps wave %d: ticks %llu  cycles/tick: level-0 write+barrier %.0f", wv, hb[wv * 16 + 8], hb[wv * 16] / double(hb[wv * 16 + 8]));
                     for (int i = 1; i < 8; ++i) fprintf(stderr, "  stage %d: %.0f", i - 1, hb[wv * 16 + i] / double(hb[wv * 16 + 8]));
-                    fprintf(stderr, "\n");
+                    fprintf(stderr, "  (audio prefetch still outstanding at tick start: %.0f)\n", hb[wv * 16 + 9] / double(hb[wv * 16 + 8]));
                 }
             } else hipLaunchKernelGGL((cqt_cascade_kernel<12, C, NT, true>), grid, dim3(NT), 0, stream, a);
         }
