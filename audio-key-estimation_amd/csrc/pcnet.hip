@@ -730,7 +730,7 @@ bool pc2pc_fuses(const ake_pcnet* n, int i, int T) {
     static const bool off = ake::diag_env("AKE_PC_FUSED") != nullptr && std::atoi(ake::diag_env("AKE_PC_FUSED")) == 0;
     const auto& c = n->cfg;
     if (off || g_keep_taps || i < 1 || i != c.num_layers - 1 || c.time_pool_size != 2 || c.conv_layers < 1 || c.conv_layers > 4) return false;
-    if (!pc2pc_uses_bf16(n, i, T) || T % 4 || 12 * T > 1024) return false;
+    if (!pc2pc_uses_bf16(n, i, T) || T % 4 || 12 * T > 1024 || 3 * ((T + 15) / 16) > 16) return false;   // (16 waves: 3 row groups x 16-frame tiles)
     for (const PackedConv& pc : n->pc2pc[i])
         if (pc.cout != 16 || pc.cin > 16 || pc.kh != 12) return false;
     return (static_cast<size_t>(4) * 12 * (T + 8) * 2 + 2 * 512) * sizeof(uint4) <= 160 * 1024;     // two maps + the weight ring

@@ -1708,7 +1708,11 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
     uint4* const wring = lds4 + 4 * n16;
     constexpr int kRow = 4 * 2 * 64;                          // uint4 per kernel row
     for (int i = threadIdx.x; i < 4 * n16; i += 1024) lds4[i] = make_uint4(0, 0, 0, 0);
-    if (threadIdx.x < kRow) wring[threadIdx.x] = a.bfrag[0][threadIdx.x];
+    // ring chunk c = (p = c / 3, dq = c % 3): the fragments of k-step pair p of kernel rows 4 dq .. 4 dq + 3, [i][hi | lo][64 lanes];
+    // thread x < 512 copies fragment (i = x >> 7, h = (x >> 6) & 1, lane x & 63) from the packed order [dy][p][h][lane]
+    const int wsrc0 = (((threadIdx.x >> 7) * 4) * 2 + ((threadIdx.x >> 6) & 1)) * 64 + (threadIdx.x & 63);
+    auto wsrc = [&](int p, int dq) { return wsrc0 + (16 * dq * 2 + p * 2) * 64; };
+    if (threadIdx.x < kRow) wring[threadIdx.x] = a.bfrag[0][wsrc(0, 0)];
     __syncthreads();
     {   // input: NCHW f32 -> split channels-last, frame t at patch position t + 3
         const float* src = a.src + clip * a.src_clip_stride;
@@ -1730,19 +1734,18 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
         }
     }
     __syncthreads();
-    const int Mtot = 12 * T;
-    const int tile0 = wave * MT;
-    const bool active = tile0 * 16 < Mtot;
-    int ay[MT], at[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int m = (tile0 + mt) * 16 + r16;
-        if (m >= Mtot) m = Mtot - 1;
-        ay[mt] = m / T;
-        at[mt] = m - ay[mt] * T;
-    }
+    // Wave = (16-frame tile tt, four output rows y0 .. y0 + 3).  Output row y at kernel row dy reads input row (y + dy) % 12, so the
+    // A fragment tile mt used at dy is the one tile mt + 1 used at dy - 1: per kernel row ONE new fragment pair is read from LDS, not
+    // four (the multiply loop was bound by its A-fragment reads: 10 ds_read_b128 per 12 MFMAs, 1 280 LDS cycles per CU next to 768
+    // matrix cycles; now 4 per 12).  The k-step pair p is the outer loop -- the four slots hold one p -- and the weight ring moves
+    // in chunks of (p, four kernel rows).
+    const int n_tt = (T + 15) >> 4;
+    const bool active = wave < 3 * n_tt;
+    const int tt = wave / 3, y0 = 4 * (wave - 3 * tt);
+    const int t0 = 16 * tt;
     typedef float f32x4c __attribute__((ext_vector_type(4)));
     const int dxq = q >> 1, half = q & 1;
+    const int lane_off = ((t0 + r16 + dxq) << 1) + half;      // (frames past the row's end read the next row: those output rows are never stored)
     const int Tf = T / 2;
     float* const pooled_c = a.pooled + static_cast<long long>(clip) * 16 * 12 * Tf;
     unsigned short* const fh_c = a.fh ? a.fh + static_cast<long long>(clip) * 12 * Tf * 16 : nullptr;
@@ -1762,51 +1765,59 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
             f32x4c acc[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
+            bf16x8c fh[4], fl[4];                             // slot s: input row y0 + (fragment index == s mod 4)
+            int c = 0;
 #pragma unroll 1
-            for (int dy = 0; dy < 12; ++dy) {   // (not unrolled: with all 48 k-steps in one block hipcc serialises every load against its MFMA)
-                // the next kernel row's fragments travel to registers during this row's MFMAs and into the other half of the ring after them
-                uint4 wpre = make_uint4(0, 0, 0, 0);
-                const bool fetch = threadIdx.x < kRow && (dy + 1 < 12 || j + 1 < a.n_conv);
-                if (fetch) wpre = dy + 1 < 12 ? bfrag_j[(dy + 1) * kRow + threadIdx.x] : bfrag_n[threadIdx.x];
-                const uint4* const wr = wring + (dy & 1) * kRow + lane;
+            for (int p = 0; p < 4; ++p) {
                 if (active) {
-                int rowoff[MT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    int row = ay[mt] + dy;
-                    row -= row >= 12 ? 12 : 0;
-                    rowoff[mt] = ((row * Tp + at[mt] + dxq) << 1) + half;
-                }
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const bf16x8c bh = __builtin_bit_cast(bf16x8c, wr[(p * 2 + 0) * 64]), bl = __builtin_bit_cast(bf16x8c, wr[(p * 2 + 1) * 64]);
-                    bf16x8c ah[MT], al[MT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        ah[mt] = __builtin_bit_cast(bf16x8c, pH[rowoff[mt] + 4 * p]);
-                        al[mt] = __builtin_bit_cast(bf16x8c, pL[rowoff[mt] + 4 * p]);
+                    for (int s = 0; s < 4; ++s) {
+                        const int off = (((y0 + s) * Tp) << 1) + lane_off + 4 * p;
+                        fh[s] = __builtin_bit_cast(bf16x8c, pH[off]);
+                        fl[s] = __builtin_bit_cast(bf16x8c, pL[off]);
                     }
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt], 0, 0, 0);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt], 0, 0, 0);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt], 0, 0, 0);
                 }
+#pragma unroll 1
+                for (int dq = 0; dq < 3; ++dq, ++c) {
+                    // the next chunk's fragments travel to registers during this chunk's MFMAs and into the other half of the ring after them
+                    uint4 wpre = make_uint4(0, 0, 0, 0);
+                    const bool fetch = threadIdx.x < kRow && (c + 1 < 12 || j + 1 < a.n_conv);
+                    if (fetch) wpre = c + 1 < 12 ? bfrag_j[dq < 2 ? wsrc(p, dq + 1) : wsrc(p + 1, 0)] : bfrag_n[wsrc(0, 0)];
+                    const uint4* const wr = wring + (c & 1) * kRow + lane;
+                    if (active) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {         // kernel row dy = 4 dq + i: tile mt reads fragment dy + mt = slot (mt + i) & 3
+                            const bf16x8c bh = __builtin_bit_cast(bf16x8c, wr[(i * 2 + 0) * 64]), bl = __builtin_bit_cast(bf16x8c, wr[(i * 2 + 1) * 64]);
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[(mt + i) & 3], bh, acc[mt], 0, 0, 0);
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[(mt + i) & 3], bh, acc[mt], 0, 0, 0);
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[(mt + i) & 3], bl, acc[mt], 0, 0, 0);
+                            const int s_new = 4 * dq + i + 4;  // slot i (tile 0's) is free: fragment dy + 4, needed from the next kernel row on
+                            if (s_new < 12 + MT - 1) {
+                                int row = y0 + s_new;
+                                row -= row >= 12 ? 12 : 0;
+                                const int off = ((row * Tp) << 1) + lane_off + 4 * p;
+                                fh[i] = __builtin_bit_cast(bf16x8c, pH[off]);
+                                fl[i] = __builtin_bit_cast(bf16x8c, pL[off]);
+                            }
+                        }
+                    }
+                    // (12 chunks: chunk 11 read half 1, so the next convolution's chunk 0 lands in half 0, where it expects it)
+                    if (fetch) wring[((c + 1) & 1) * kRow + threadIdx.x] = wpre;
+                    if (c + 1 < 12) __syncthreads();          // (after the last chunk the barrier at the end of the convolution serves)
                 }
-                // (12 is even: row 11 read half 1, so the next convolution's row 0 lands in half 0, where it expects it)
-                if (fetch) wring[((dy + 1) & 1) * kRow + threadIdx.x] = wpre;
-                if (dy + 1 < 12) __syncthreads();             // (after the last row the barrier at the end of the convolution serves)
             }
             if (active) {
-            // ---- epilogue: D[row m = 4q + i][col = co]; T % 4 == 0: the four positions of a lane share a row, frames t0 .. t0 + 3 ----
+            // ---- epilogue: D[row m = 4q + i][col = co]; T % 4 == 0: a lane's four positions are frames t0 + 4q .. + 3 of row y0 + mt ----
             const int co = r16;
             const float bias = bias_j[co];
+            const int tq0 = t0 + 4 * q;
+            if (tq0 < T) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int m0 = (tile0 + mt) * 16 + 4 * q;
-                if (m0 < Mtot) {
-                    const int y = m0 / T, t0 = m0 - y * T;
+                    const int y = y0 + mt;
                     float v[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -1816,7 +1827,7 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
                     if (!last) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const int e = ((((y * Tp + t0 + i + 3) << 1) + (co >> 3)) << 3) + (co & 7);
+                            const int e = ((((y * Tp + tq0 + i + 3) << 1) + (co >> 3)) << 3) + (co & 7);
                             const unsigned int hb = bf16_bits(v[i]);
                             oH[e] = static_cast<unsigned short>(hb);
                             oL[e] = static_cast<unsigned short>(bf16_bits(v[i] - __uint_as_float(hb << 16)));
@@ -1825,7 +1836,7 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
 #pragma unroll
                         for (int i = 0; i < 4; i += 2) {
                             const float pv = fmaxf(v[i], v[i + 1]);
-                            const int tq = (t0 + i) >> 1;
+                            const int tq = (tq0 + i) >> 1;
                             pooled_c[(co * 12 + y) * Tf + tq] = pv;      // (uniform clip base + 32-bit offsets: few address registers)
                             if (a.fh) {
                                 const int e = (y * Tf + tq) * 16 + co;
@@ -1835,7 +1846,7 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
                             }
                         }
                     }
-                }
+            }
             }
             }
         }
