@@ -1466,8 +1466,9 @@ __global__ __launch_bounds__(512) void conv_p2p_f16x3_kernel(P2pTrArgs a) {
 // key / tonic heads.  Same idea as conv_p2p_f16_kernel: channels-last activations [clip][12][T][16] as bf16 hi / lo planes,
 //   m = (pitch class y, frame t)       A[m][k] = X[(y + dy) mod 12][t + dx - pad][ci]
 //   n = output channel (NT tiles of 16)  B[k][n] = w[co][ci][dy][dx]
-//   k-step = (dy, tap pair p): lane q holds tap dx = 2p + (q >> 1), channels 8 (q & 1) .. +7   -> 12 x 4 = 48 k-steps (dx = 7 is
-//   a zero tap), three MFMAs per k-step, M-tile and N-tile.  The whole clip (12 rows, all frames) is one LDS patch; the weight
+//   k-step = (dy, tap pair p): lane q holds tap dx = 2p + (q >> 1), channels 8 (q & 1) .. +7; the seventh taps of kernel rows dy and
+//   dy + 1 (dy even) share the k-step p = 3 of row dy, which has none at odd dy -> 12 x 3 + 6 = 42 k-steps (a single kernel row: 4,
+//   dx = 7 a zero tap), three MFMAs per k-step, M-tile and N-tile.  The whole clip (12 rows, all frames) is one LDS patch; the weight
 //   fragments (96 KB per N-tile) come through a double-buffered LDS ring, one kernel row (4 k-steps) ahead, fetched once per workgroup.
 // ==========================================================================================
 struct PcBfArgs {
@@ -1569,19 +1570,27 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
             if (F16X3) accl[mt][nt] = f32x4c{0.f, 0.f, 0.f, 0.f};
         }
     const int dxq = q >> 1, half = q & 1;
+    const bool pair = !(a.KH & 1);
     for (int dy = 0; dy < a.KH; ++dy) {
         if (dy + 1 < a.KH) fetch_row(dy + 1);                 // lands in the other half during this row's MFMAs
         const uint4* const wr = wring + (dy & 1) * kRow + lane;
         if (active) {
-        int rowoff[MT];
+        int rowoff[MT], rowoff3[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             int row = ay[mt] + dy;
             row -= row >= 12 ? 12 : 0;
             rowoff[mt] = ((row * Tp + at[mt] + dxq) << 1) + half;
+            // An even number of kernel rows: the seventh taps of rows dy and dy + 1 share ONE k-step (at even dy; lanes of the second tap
+            // slot read the next input row at the same frame) instead of each filling half a k-step next to a zero tap: 7 k-steps per
+            // pair of kernel rows instead of 8 (pack_pc_bf16_kernel / pack_pc_f16x3_body build the fragments to match)
+            int row3 = ay[mt] + dy + dxq;
+            row3 -= row3 >= 12 ? 12 : 0;
+            rowoff3[mt] = pair ? ((row3 * Tp + at[mt] + 6) << 1) + half : rowoff[mt] + 12;
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
+            if (p == 3 && pair && (dy & 1)) break;
             uint4 bhu[NT], blu[NT], ahu[MT], alu[MT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -1590,8 +1599,8 @@ __global__ __launch_bounds__(512) void conv_pc_bf16_kernel(PcBfArgs a) {
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                ahu[mt] = pH[rowoff[mt] + 4 * p];
-                alu[mt] = pL[rowoff[mt] + 4 * p];
+                ahu[mt] = pH[p == 3 ? rowoff3[mt] : rowoff[mt] + 4 * p];
+                alu[mt] = pL[p == 3 ? rowoff3[mt] : rowoff[mt] + 4 * p];
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -1746,6 +1755,14 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
     typedef float f32x4c __attribute__((ext_vector_type(4)));
     const int dxq = q >> 1, half = q & 1;
     const int lane_off = ((t0 + r16 + dxq) << 1) + half;      // (frames past the row's end read the next row: those output rows are never stored)
+    const int lane_off3 = ((t0 + r16 + 6) << 1) + half;
+    // fragment s of k-step pair p: input row y0 + s for p < 3; p == 3 holds the paired seventh taps (conv_pc_bf16_kernel): the first tap
+    // slot's lanes read row y0 + s, the second's row y0 + s + 1, both at frame + 6, and it exists for even kernel rows only
+    auto frag_off = [&](int s, int p) {
+        int row = y0 + s + (p == 3 ? dxq : 0);
+        row -= row >= 12 ? 12 : 0;
+        return ((row * Tp) << 1) + (p == 3 ? lane_off3 : lane_off + 4 * p);
+    };
     const int Tf = T / 2;
     float* const pooled_c = a.pooled + static_cast<long long>(clip) * 16 * 12 * Tf;
     unsigned short* const fh_c = a.fh ? a.fh + static_cast<long long>(clip) * 12 * Tf * 16 : nullptr;
@@ -1767,12 +1784,14 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
             for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4c{0.f, 0.f, 0.f, 0.f};
             bf16x8c fh[4], fl[4];                             // slot s: input row y0 + (fragment index == s mod 4)
             int c = 0;
-#pragma unroll 1
-            for (int p = 0; p < 4; ++p) {
+            // one k-step pair p: three ring chunks of four kernel rows.  PAIR (p == 3): the paired seventh taps -- even kernel rows only,
+            // the fragments move two slots per step
+            auto run_p = [&](auto pair_c, const int p) __attribute__((always_inline)) {
+                constexpr bool PAIR = decltype(pair_c)::value;
                 if (active) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        const int off = (((y0 + s) * Tp) << 1) + lane_off + 4 * p;
+                        const int off = frag_off(s, PAIR ? 3 : p);
                         fh[s] = __builtin_bit_cast(bf16x8c, pH[off]);
                         fl[s] = __builtin_bit_cast(bf16x8c, pL[off]);
                     }
@@ -1786,7 +1805,7 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
                     const uint4* const wr = wring + (c & 1) * kRow + lane;
                     if (active) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {         // kernel row dy = 4 dq + i: tile mt reads fragment dy + mt = slot (mt + i) & 3
+                        for (int i = 0; i < 4; i += PAIR ? 2 : 1) {   // kernel row dy = 4 dq + i: tile mt reads fragment dy + mt = slot (mt + i) & 3
                             const bf16x8c bh = __builtin_bit_cast(bf16x8c, wr[(i * 2 + 0) * 64]), bl = __builtin_bit_cast(bf16x8c, wr[(i * 2 + 1) * 64]);
 #pragma unroll
                             for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[(mt + i) & 3], bh, acc[mt], 0, 0, 0);
@@ -1794,13 +1813,15 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
                             for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[(mt + i) & 3], bh, acc[mt], 0, 0, 0);
 #pragma unroll
                             for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[(mt + i) & 3], bl, acc[mt], 0, 0, 0);
-                            const int s_new = 4 * dq + i + 4;  // slot i (tile 0's) is free: fragment dy + 4, needed from the next kernel row on
-                            if (s_new < 12 + MT - 1) {
-                                int row = y0 + s_new;
-                                row -= row >= 12 ? 12 : 0;
-                                const int off = ((row * Tp) << 1) + lane_off + 4 * p;
-                                fh[i] = __builtin_bit_cast(bf16x8c, pH[off]);
-                                fl[i] = __builtin_bit_cast(bf16x8c, pL[off]);
+                            // slot i (tile 0's; PAIR: and slot i + 1, tile 1's) is free: the fragment(s) the next step's last tile(s) need
+#pragma unroll
+                            for (int u = 0; u < (PAIR ? 2 : 1); ++u) {
+                                const int s_new = 4 * dq + i + 4 + u;
+                                if (s_new < 12 + MT - (PAIR ? 2 : 1)) {
+                                    const int off = frag_off(s_new, PAIR ? 3 : p);
+                                    fh[i + u] = __builtin_bit_cast(bf16x8c, pH[off]);
+                                    fl[i + u] = __builtin_bit_cast(bf16x8c, pL[off]);
+                                }
                             }
                         }
                     }
@@ -1808,7 +1829,10 @@ __global__ __launch_bounds__(1024) void pc2pc_fused_kernel(Pc2pcFusedArgs a) {
                     if (fetch) wring[((c + 1) & 1) * kRow + threadIdx.x] = wpre;
                     if (c + 1 < 12) __syncthreads();          // (after the last chunk the barrier at the end of the convolution serves)
                 }
-            }
+            };
+#pragma unroll 1
+            for (int p = 0; p < 3; ++p) run_p(std::false_type{}, p);
+            run_p(std::true_type{}, 3);
             if (active) {
             // ---- epilogue: D[row m = 4q + i][col = co]; T % 4 == 0: a lane's four positions are frames t0 + 4q .. + 3 of row y0 + mt ----
             const int co = r16;
@@ -2027,12 +2051,17 @@ __global__ void pack_pc_bf16_kernel(const float* __restrict__ w, uint4* __restri
     const int lane = i & 63, nt = (i >> 6) % NT, ks = i / (64 * NT);
     const int dy = ks >> 2, p = ks & 3;
     const int co = nt * 16 + (lane & 15), qq = lane >> 4;
-    const int dx = 2 * p + (qq >> 1), c8 = 8 * (qq & 1);
+    const int c8 = 8 * (qq & 1);
+    int dx = 2 * p + (qq >> 1), dyw = dy;
+    if (p == 3 && !(KH & 1)) {           // paired seventh taps (see conv_pc_bf16_kernel): [tap 6 of row dy | tap 6 of row dy + 1] at even dy
+        dx = (dy & 1) ? 7 : 6;
+        dyw = dy + (qq >> 1);
+    }
     unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
     for (int e = 0; e < 8; ++e) {
         const int ci = c8 + e;
         float v = 0.f;
-        if (dx < 7 && ci < cin && co < cout) v = w[((((co / CO) * cin + ci) * KH + dy) * 7 + dx) * CO + (co % CO)];
+        if (dx < 7 && ci < cin && co < cout) v = w[((((co / CO) * cin + ci) * KH + dyw) * 7 + dx) * CO + (co % CO)];
         const unsigned int hb = bf16_bits(v);
         const unsigned int lb = bf16_bits(v - __uint_as_float(hb << 16));
         hi[e >> 1] |= hb << (16 * (e & 1));
@@ -2149,13 +2178,18 @@ __device__ __forceinline__ void pack_pc_f16x3_body(const float* __restrict__ w, 
     const int lane = i & 63, nt = (i >> 6) % NT, ks = i / (64 * NT);
     const int dy = ks >> 2, p = ks & 3;
     const int co = nt * 16 + (lane & 15), qq = lane >> 4;
-    const int dx = 2 * p + (qq >> 1), c8 = 8 * (qq & 1);
+    const int c8 = 8 * (qq & 1);
+    int dx = 2 * p + (qq >> 1), dyw = dy;
+    if (p == 3 && !(KH & 1)) {           // paired seventh taps, as pack_pc_bf16_kernel
+        dx = (dy & 1) ? 7 : 6;
+        dyw = dy + (qq >> 1);
+    }
     const float sc = co < cout ? 1.f / reinterpret_cast<const float*>(out + KH * 4 * NT * 2 * 64)[co] : 1.f;      // a power of two: exact
     unsigned int hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
     for (int e = 0; e < 8; ++e) {
         const int ci = ci_off + c8 + e;
         float v = 0.f;
-        if (dx < 7 && ci < cin && co < cout) v = sc * w[((((co / CO) * cin + ci) * KH + (dy + dy_rot) % KH) * 7 + dx) * CO + (co % CO)];
+        if (dx < 7 && ci < cin && co < cout) v = sc * w[((((co / CO) * cin + ci) * KH + (dyw + dy_rot) % KH) * 7 + dx) * CO + (co % CO)];
         const _Float16 hv = static_cast<_Float16>(v);
         hi[e >> 1] |= static_cast<unsigned int>(__builtin_bit_cast(unsigned short, hv)) << (16 * (e & 1));
         lo[e >> 1] |= f16_bits((v - static_cast<float>(hv)) * kP2pLoScale) << (16 * (e & 1));

@@ -25,8 +25,10 @@ from oracle import pcnet_oracle
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 # model.0.pool_semi_b.weight: see tests/test_gpu_backward.py.  The last biases of the tonic / genre heads: the softmax gradient sums to zero over
-# the classes and the bias reaches every class alike, so their gradient is an exactly cancelling sum (|ref| ~ 1e-8 next to 1e-1)
-ILL_CONDITIONED = {"model.0.pool_semi_b.weight": 2e-3, "tonic_classifier.3.conv2d.bias": 2e-3, "genre_classifier.3.bias": 2e-3}
+# the classes and the bias reaches every class alike, so their gradient is an exactly cancelling sum (|ref| ~ 1e-8 next to 1e-1).
+# model.0.pool_semi_b.bias: the same BatchNorm's other cancelling sum (2e-5 between 512 and 256 clips where its weight shows 5e-4)
+ILL_CONDITIONED = {"model.0.pool_semi_b.weight": 2e-3, "model.0.pool_semi_b.bias": 2e-4, "tonic_classifier.3.conv2d.bias": 2e-3,
+                   "genre_classifier.3.bias": 2e-3}
 
 
 def big_case(batch, frames, seed):
