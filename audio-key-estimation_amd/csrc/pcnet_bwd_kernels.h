@@ -1078,10 +1078,19 @@ __device__ __forceinline__ f16x8p shifted8(const uint4& c0, const uint4& c1) {
 template <int R>
 __device__ __forceinline__ void wgrad_pc_multiply(const WgradPcArgs& a, const unsigned short* aH, const unsigned short* aL, const unsigned short* zH,
                                                   const unsigned short* zL, int base0, int ksteps, int r16, int q, f32x4p (&acc)[12], f32x4p (&accl)[12]) {
-    // the shifted operand is built ONCE per (input row, k-step) and meets the 12 dz rows it pairs with (row = y + dy): two aligned reads
-    // per tile instead of four, the alignbits outside the tap loop
-    for (int row = 0; row < 12; ++row)
-        for (int ks = 0; ks < ksteps; ++ks) {
+    // The 12 dz rows of a k-step stay in REGISTERS (96 of the 256 a wave of this one-workgroup-per-CU kernel may hold) and meet every
+    // input row's shifted operand, which is built once per (input row, k-step): 24 + 12 x 4 LDS reads per 432 MFMAs.  (Reading the dz
+    // fragment again for every (input row, dy) was 2 reads per 3 MFMAs: the LDS array busier than the matrix pipe.)
+    for (int ks = 0; ks < ksteps; ++ks) {
+        f16x8p zh[12], zl[12];
+#pragma unroll
+        for (int y = 0; y < 12; ++y) {
+            const int zo = (y * 16 + r16) * a.ZP + 32 * ks + 8 * q;
+            zh[y] = __builtin_bit_cast(f16x8p, *reinterpret_cast<const uint4*>(zH + zo));
+            zl[y] = __builtin_bit_cast(f16x8p, *reinterpret_cast<const uint4*>(zL + zo));
+        }
+#pragma unroll
+        for (int row = 0; row < 12; ++row) {
             const int o = (row * 16 + r16) * a.AP + base0 + 32 * ks + 8 * q;       // aligned start of the shifted window inside the plane row
             const uint4 h0 = *reinterpret_cast<const uint4*>(aH + o);
             const uint4 l0 = *reinterpret_cast<const uint4*>(aL + o);
@@ -1089,17 +1098,14 @@ __device__ __forceinline__ void wgrad_pc_multiply(const WgradPcArgs& a, const un
             if (R != 0) { h1 = *reinterpret_cast<const uint4*>(aH + o + 8); l1 = *reinterpret_cast<const uint4*>(aL + o + 8); }
             const f16x8p bh = shifted8<R>(h0, h1), bl = shifted8<R>(l0, l1);
 #pragma unroll
-            for (int dy = 0; dy < 12; ++dy) {
-                int y = row - dy;
-                y += y < 0 ? 12 : 0;
-                const int zo = (y * 16 + r16) * a.ZP + 32 * ks + 8 * q;
-                const f16x8p ah = __builtin_bit_cast(f16x8p, *reinterpret_cast<const uint4*>(zH + zo));
-                const f16x8p al = __builtin_bit_cast(f16x8p, *reinterpret_cast<const uint4*>(zL + zo));
-                acc[dy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[dy], 0, 0, 0);
-                accl[dy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, accl[dy], 0, 0, 0);
-                accl[dy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, accl[dy], 0, 0, 0);
-            }
+            for (int dy = 0; dy < 12; ++dy) acc[dy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh[(row - dy + 12) % 12], bh, acc[dy], 0, 0, 0);
+#pragma unroll
+            for (int dy = 0; dy < 12; ++dy) accl[dy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl[(row - dy + 12) % 12], bh, accl[dy], 0, 0, 0);
+#pragma unroll
+            for (int dy = 0; dy < 12; ++dy) accl[dy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh[(row - dy + 12) % 12], bl, accl[dy], 0, 0, 0);
+            if (row & 1) __builtin_amdgcn_sched_barrier(0);   // (fully unrolled, hipcc hoists every row's reads to the top: 256 registers + spills)
         }
+    }
 }
 
 __global__ __launch_bounds__(512) void conv_wgrad_pc_f16x3_kernel(WgradPcArgs a) {
