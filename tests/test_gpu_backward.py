@@ -68,6 +68,21 @@ def grad_errors(net, ref):
     return rows
 
 
+def cancelling_ok(net, ref, rows, tight):
+    """The tensors left out of `tight` are sums that cancel to (nearly) zero -- the loss does not depend on them -- so their error is noise
+    of the summation (it moves by 1e-7 when one fused multiply-add of a reduction is contracted differently: 9e-2 of a 1.1e-6 gradient) and is
+    bounded against the step's LARGEST gradient instead of their own size: 1e-5 of it."""
+    params = dict(net.named_parameters())
+    gmax = max(float(ref[n].abs().max()) for n in params)
+    bad = []
+    for name in {r[1] for r in rows} - {r[1] for r in tight}:
+        err = float((params[name].grad.detach().cpu().double() - ref[name]).abs().max())
+        if not err < 1e-5 * gmax:
+            bad.append((name, err, gmax))
+    assert not bad, bad
+    return True
+
+
 def check_grads(net, ref, tol, verbose=False):
     rows = grad_errors(net, ref)
     if verbose:
@@ -200,7 +215,7 @@ def test_three_layer_net_gradients(n_filters, seed):
     # model.0.pool_semi_b.weight: max |ref| ~1e-6 next to O(1) gradients, a cancelling sum (see grad_errors); with ONE filter the same holds for
     # the single-channel BatchNorm inside layer 0's stack (its scale is removed by the next BatchNorm: the exact gradient is zero, |ref| 1.1e-6)
     tight = [r for r in rows if r[1] != "model.0.pool_semi_b.weight" and not (n_filters == 1 and r[1] == "model.0.pc2pc.layer.1.weight")]
-    assert tight[0][0] < 3e-4 and rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
+    assert tight[0][0] < 3e-4 and cancelling_ok(net, ref, rows, tight) and rows[len(rows) // 2][0] < 2e-5, rows[:5]
 
 
 @pytest.mark.parametrize("num_layers,n_filters,conv_layers,batch,frames,seed", [(2, 4, 2, 2, 52, 2), (1, 4, 2, 2, 52, 1), (3, 1, 1, 2, 96, 2),
@@ -225,7 +240,7 @@ def test_resblock_net_gradients(num_layers, n_filters, conv_layers, batch, frame
     loss.backward()
     rows = grad_errors(net, ref)
     tight = [r for r in rows if r[1] != "model.0.pool_semi_b.weight"]      # (a cancelling sum at 1e-5 of the other gradients, see grad_errors)
-    assert tight[0][0] < 3e-4 and rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
+    assert tight[0][0] < 3e-4 and cancelling_ok(net, ref, rows, tight) and rows[len(rows) // 2][0] < 2e-5, rows[:5]
 
 
 @pytest.mark.parametrize("flag,num_layers,n_filters,conv_layers,frames,seed", [("pc2p_mem", 2, 4, 3, 52, 1), ("pc2p_mem", 3, 2, 2, 96, 2),
@@ -258,7 +273,7 @@ def test_variant_net_gradients(flag, num_layers, n_filters, conv_layers, frames,
     # gamma of a BatchNorm whose (positively homogeneous) output feeds a convolution + BatchNorm: the loss does not depend on it, its
     # gradient is a cancelling sum at 1e-5 of the others (see grad_errors) -- layer 0's pool_semi_b and, with --p2pc_conv, pool.bn
     tight = [r for r in rows if r[1] not in ("model.0.pool_semi_b.weight", "model.0.pool.bn.weight")]
-    assert tight[0][0] < 3e-4 and rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
+    assert tight[0][0] < 3e-4 and cancelling_ok(net, ref, rows, tight) and rows[len(rows) // 2][0] < 2e-5, rows[:5]
 
 
 @pytest.mark.parametrize("ksz,frames,seed", [(3, 52, 1), (3, 40, 3), (5, 52, 1), (5, 40, 2)])
@@ -281,7 +296,7 @@ def test_kernel_size_gradients(ksz, frames, seed):
     loss.backward()
     rows = grad_errors(net, ref)
     tight = [r for r in rows if r[1] not in ILL_CONDITIONED]
-    assert tight[0][0] < 3e-5 and rows[0][0] < 5e-2 and rows[len(rows) // 2][0] < 2e-5, rows[:5]
+    assert tight[0][0] < 3e-5 and cancelling_ok(net, ref, rows, tight) and rows[len(rows) // 2][0] < 2e-5, rows[:5]
 
 
 # --denseblock: gamma of the FIRST norm1 of layer 0's block normalises one channel (the fold) and feeds conv1 + norm2: the loss does not depend
@@ -311,7 +326,7 @@ def test_denseblock_training_step_against_reference_fixture():
     ref = {k[5:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("grad/")}
     rows = grad_errors(net, ref)
     tight = [r for r in rows if r[1] not in DENSE_ILL]
-    assert tight[0][0] < 3e-5 and rows[0][0] < 5e-2, rows[:5]
+    assert tight[0][0] < 3e-5 and cancelling_ok(net, ref, rows, tight), rows[:5]
     sd_after = net.state_dict()
     for k in gold.files:
         if not k.startswith("after/"):
