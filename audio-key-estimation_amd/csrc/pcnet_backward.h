@@ -64,10 +64,10 @@ struct Bwd {
             w.src1_clip_stride = static_cast<long long>(src.c1) * w.h1 * T_in;
             w.in_affine = in_aff; w.dz = dz; w.dW = dW; w.slot_stride = static_cast<long long>(n->grad_floats);
             w.cin = pc.cin; w.H = H; w.T = T_in;
-            const int wgs_per_clip = std::max(4, std::min(H, (2 * std::max(tiling_cus(1), 1) + B - 1) / B));
+            const int wgs_per_clip = std::max(3, std::min(H, (3 * std::max(tiling_cus(1), 1) + B - 1) / B));   // three workgroups fit a CU
             w.rows_per_wg = (H + wgs_per_clip - 1) / wgs_per_clip;
             dim3 grid((H + w.rows_per_wg - 1) / w.rows_per_wg, 1, B);
-            const size_t lds = (static_cast<size_t>(6) * 64 * kWgKP + kWgKP) * sizeof(unsigned short);
+            const size_t lds = (static_cast<size_t>(2 * kWgARows + 2 * 64) * kWgKP + kWgKP) * sizeof(unsigned short);
             static ake::DeviceOnce attr_set;
             if (attr_set.need()) {
                 AKE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_p2p_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));

@@ -859,6 +859,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs wa) {
 // Workgroup = (clip, block of a-rows), 4 waves = the 4 M-tiles; partial sums go to the gradient slots with one atomic per weight.
 constexpr int kWgKP = 104;                  // LDS row pitch in bf16 (>= 96 frames; 52 dwords: conflict-free 16-byte reads)
 constexpr int kWgMaxT = 96;
+constexpr int kWgARows = 56;                // rows of the rotated a-row copy: 7 dx x 8 ci
 
 struct WgradBfArgs {
     const float* src0;        // [clip][c0][H][T] raw
@@ -880,18 +881,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_p2p_bf16_kernel(WgradBfArgs a)
     // two copies of the rotated a-row [8 dx][8 ci][kWgKP] (hi, lo) -- the next row is written while this one is multiplied --,
     // the dz ring [8 slots][8 co][kWgKP] (hi, lo; 7 slots live, the 8th receives the next row), one zero row
     extern __shared__ __attribute__((aligned(16))) unsigned short wg_lds[];
-    constexpr int kA = 64 * kWgKP;                                 // one plane of one a-row copy
-    unsigned short* const aBase = wg_lds;                          // [buf 2][hi|lo][64 rows][kWgKP]
-    unsigned short* const zH = wg_lds + 4 * kA;
-    unsigned short* const zL = zH + kA;
-    const unsigned short* const zero = zL + kA;
+    // ONE copy of the rotated a-row, 56 rows (7 dx x 8 ci): 50 KB per workgroup, three per CU.  (Two copies of 64 rows -- the next row
+    // written while this one is multiplied, one barrier per row -- were 80 KB, two workgroups per CU: counters showed the matrix pipes
+    // 17-20 % busy and 56 % of the wave cycles parked, profiles/r03_h_train_pmc_mfma.md; more waves per SIMD hide what a second
+    // buffer hid, and the rest.)
+    constexpr int kA = kWgARows * kWgKP;                           // one plane of the a-row copy
+    constexpr int kZ = 64 * kWgKP;                                 // one plane of the dz ring
+    unsigned short* const aBase = wg_lds;                          // [hi|lo][56 rows][kWgKP]
+    unsigned short* const zH = wg_lds + 2 * kA;
+    unsigned short* const zL = zH + kZ;
+    const unsigned short* const zero = zL + kZ;
     const int clip = blockIdx.z;
     const int y0 = blockIdx.x * a.rows_per_wg;
     const int rows = a.H - y0 < a.rows_per_wg ? a.H - y0 : a.rows_per_wg;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, q = lane >> 4;
-    for (int i = tid; i < (6 * kA + kWgKP) / 2; i += 256) reinterpret_cast<unsigned int*>(wg_lds)[i] = 0u;
+    for (int i = tid; i < (2 * kA + 2 * kZ + kWgKP) / 2; i += 256) reinterpret_cast<unsigned int*>(wg_lds)[i] = 0u;
     __syncthreads();
     const float* s0 = a.src0 + clip * a.src0_clip_stride;
     const float* s1 = a.src1 ? a.src1 + clip * a.src1_clip_stride : nullptr;
@@ -916,8 +922,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_p2p_bf16_kernel(WgradBfArgs a)
             zv[i] = t < a.T ? zp[t] : 0.f;
         }
     };
-    auto commit = [&](int yl, const float (&av)[3], const float (&zv)[3]) {   // registers -> LDS: a-row copy (yl & 1), dz slot (yl + 3) & 7
-        unsigned short* aH = aBase + (yl & 1) * 2 * kA;
+    auto commit = [&](int yl, const float (&av)[3], const float (&zv)[3]) {   // registers -> LDS: the a-row copy, dz slot (yl + 3) & 7
+        unsigned short* aH = aBase;
         unsigned short* aL = aH + kA;
         const int slot = (yl + 3 + 8) & 7;
 #pragma unroll
@@ -975,7 +981,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_p2p_bf16_kernel(WgradBfArgs a)
     fetch(3, avs[0], zvs[0]);
     __syncthreads();
     auto multiply = [&](int yl) {
-        const unsigned short* aH = aBase + (yl & 1) * 2 * kA;
+        const unsigned short* aH = aBase;
         const unsigned short* aL = aH + kA;
         const int slot = (yl - dy + 3 + 8) & 7;
         const unsigned short* zh = dy < 7 ? zH + (slot * 8 + co) * kWgKP : zero;
@@ -996,11 +1002,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_p2p_bf16_kernel(WgradBfArgs a)
             }
         }
     };
-    // row yl multiplies while row yl + 1 (register set (yl + 1) % 3, loaded three rows ago) goes to the other a-row copy and the free ring
-    // slot; its registers then take row yl + 4
+    // row yl multiplies; then row yl + 1 (register set (yl + 1) % 3, loaded three rows ago) replaces it and takes the free ring slot; its
+    // registers then take row yl + 4
 #define AKE_WG_ROW(J_)                                                          \
         if (yl < rows) {                                                         \
             multiply(yl);                                                        \
+            __syncthreads();                                                     \
             if (yl + 1 < rows) {                                                 \
                 commit(yl + 1, avs[J_], zvs[J_]);                                \
                 fetch(yl + 4, avs[J_], zvs[J_]);                                 \
